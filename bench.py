@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the FM-index seed search (+ clustering + SW extension) hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload config2|config2-align] [--reads M]
+
+One process per GPU (torch.distributed / RCCL for N > 1; the driver launches the ranks).  A "step"
+is one pass of the hot path over one batch of synthetic reads that is already resident in HBM.
+Rank 0 prints ONE JSON line.  Weak scaling: every GPU gets its own slab of `--reads` reads, the index
+is replicated, and the only collective is the per-step gather of the 16-byte hit records to rank 0.
+
+Workloads (BASELINE.json configs):
+  config2        configs[1]: bundled GL000193.1 index, 1 M exact-match 100 bp reads drawn from the
+                 contig (seed 2), FM backward-search stage only (sub-read enumeration + LF steps).
+  config2-align  same reads through the whole path (search + clustering + SW extension + CIGAR).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured streaming
+
+
+def synth_exact_reads(ref, n, length, seed):
+    """exact `length`-mers of the .ref, uniform start."""
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, len(ref) - length + 1, size=n, dtype=np.int64)
+    idx = starts[:, None] + np.arange(length, dtype=np.int64)[None, :]
+    bases = np.frombuffer(ref, np.uint8)[idx].reshape(-1)
+    off = np.arange(0, (n + 1) * length, length, dtype=np.uint64)
+    return np.ascontiguousarray(bases), off
+
+
+def cpu_baseline(workload, fm_path, ref, bases, off, length):
+    """The oracle's C restatement (literal linear-scan se_down/se_up, full-rectangle SW) timed on this
+    host's cores on a bounded sample of the same reads.  kind = "port": the reference is Erlang and
+    cannot run here."""
+    from oracle import etf, orc, erl_literal as E
+    d = etf.read_fm(fm_path)
+    ofm = orc.OrcFM.from_etf(d)
+    ref1 = E.make_ref1(ref)
+    cores = os.cpu_count() or 1
+    mode = 1 if workload.endswith("align") else 0
+    n = 1_000_000 if mode == 0 else 60_000          # ~10-30 s of CPU work
+    n = min(n, len(off) - 1)
+    b = bases[: n * length]
+    o = off[: n + 1].astype(np.uint32)
+    t0 = time.perf_counter()
+    res = orc.batch(ofm, ref1, b, o, mode, cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the bench batch, %s, %d threads, %.1f s" %
+                      (n, "sga (search+cluster)" if mode == 0 else "search+cluster+SW", cores, dt),
+            "checksum": int(res[3])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2", choices=["config2", "config2-align"])
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bwt_amd import lib
+    g = os.path.join(ROOT, "tests", "golden", "fm_indices", "GL000193.1_p1")
+    ref = open(g + ".ref", "rb").read()
+    ix = lib.Index.open(g + ".fm", g + ".ref", local_rank)
+    length = 100
+    bases, off = synth_exact_reads(ref, args.reads, length, seed=2 + rank)
+    batch = lib.Batch(ix)
+    batch.set_reads(bases, off)                         # resident in HBM before the timed region
+    stages = lib.STAGE_EXTEND if args.workload.endswith("align") else lib.STAGE_SEARCH
+    gather = world > 1 and stages == lib.STAGE_EXTEND
+
+    hit_buf = None
+
+    def step():
+        c = batch.run(stages)
+        if gather:
+            # RCCL hit gather: counts, then max-padded 16-byte records to rank 0
+            nonlocal hit_buf
+            nh = torch.tensor([c["n_hits"]], dtype=torch.int64, device="cuda")
+            allc = [torch.zeros_like(nh) for _ in range(world)]
+            dist.all_gather(allc, nh)
+            mx = int(max(int(x.item()) for x in allc))
+            if hit_buf is None or hit_buf.numel() < mx * 2:
+                hit_buf = torch.zeros(max(mx, 1) * 2, dtype=torch.int64, device="cuda")
+            batch.hits_to_device(hit_buf.data_ptr(), hit_buf.numel() // 2)
+            out = [torch.empty_like(hit_buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(hit_buf, out, dst=0)
+        return c
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    batch.profile(True)                                 # hipEvents around every kernel, on the library's stream
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    sync()
+    dt = time.perf_counter() - t0
+    kt = batch.kernel_times()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_reads = args.reads * world * args.steps
+        value = total_reads / dt
+        # dominant kernel = fm_search.  Algorithmic bytes per launch (search terms only):
+        #   Lq per read in + 128 B per LF step (two 64-B rank blocks) + 16 B per sub-read result out
+        dom = "sw_extend" if stages == lib.STAGE_EXTEND and kt.get("sw_extend", {}).get("ms", 0) > kt["fm_search"]["ms"] \
+            else "fm_search"
+        fs = kt["fm_search"]
+        bytes_search = counts["n_reads"] * length + 128 * counts["lf_steps"] + 16 * counts["n_tasks"]
+        avg_s = fs["ms"] / fs["launches"] / 1e3
+        roof = {"kernel": "k_search", "bound": "hbm", "achieved": bytes_search / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": bytes_search / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": bytes_search, "avg_launch_ms": avg_s * 1e3,
+                "note": "index (63 KB rank blocks) is L2-resident in this config: HBM is not the binding limit"}
+        line = {
+            "metric": "aligned reads/sec (100 bp, GRCh38 FM-index) at 1/2/4/8 MI355X",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: GL000193.1_p1 index, %d exact-match 100 bp reads per GPU "
+                                   "(seed 2+rank), %s" % (args.reads, "FM backward-search stage only"
+                                                          if stages == lib.STAGE_SEARCH else
+                                                          "seed search + clustering + SW extension"),
+                       "reads_per_gpu": args.reads, "read_len": length, "index_rows": ix.meta()[0][3],
+                       "parallelism": "reads sharded x%d, index replicated" % world},
+            "roofline": roof,
+            "dominant_kernel": dom,
+            "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(kt.items())},
+            "counts_per_step": counts,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload, g + ".fm", ref, bases, off, length)
+        print(json.dumps(line))
+    batch.destroy()
+    ix.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

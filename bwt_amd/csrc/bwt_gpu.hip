@@ -1,0 +1,801 @@
+// libbwtgpu: host side of the C ABI declared in include/bwt_gpu.h (HIP runtime only; no torch types).
+#include "kernels.hip.h"
+#include "etf_fm.h"
+#include "../../include/bwt_gpu.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+extern "C" const char *bwt_last_error(void) { return g_err.c_str(); }
+
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return fail(_e == hipErrorOutOfMemory ? BWT_ENOMEM : BWT_EHIP, _b);                   \
+        }                                                                                         \
+    } while (0)
+
+extern "C" void bwt_constants(bwt_constants_t *o) {
+    o->tolerance = BWT_TOLERANCE; o->min_len = BWT_MIN_LEN; o->max_range = BWT_MAX_RANGE; o->max_len = BWT_MAX_LEN;
+    o->match = 2; o->mismatch = -1; o->gap_penalty = -2; o->gap_ext_penalty = -1; o->unknown = 1.6;
+    o->ref_extension_len = BWT_REF_EXT;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+            if (e != hipSuccess) { p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+        }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct bwt_index {
+    int device = 0;
+    DevIndex d{};
+    DevBuf blocks, sa, ref1;
+    uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
+    int32_t shift = 0;
+    uint64_t ref1_len = 0;
+    hipStream_t stream = nullptr;
+};
+
+static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
+    const uint32_t n = (uint32_t)fm.L.size();
+    if (n < 8 || fm.Last != n) return fail(BWT_EINVAL, "index: Last must equal the number of rows");
+    if (!(1 < fm.Pc && fm.Pc < fm.Pg && fm.Pg < fm.Pt && fm.Pt <= fm.Last))
+        return fail(BWT_EINVAL, "index: every base must occur (need 1 < Pc < Pg < Pt <= Last)");
+    if ((uint64_t)n + 70000ull >= 0xffffffffull) return fail(BWT_EINVAL, "index: too many rows for u32 positions");
+    if (ref_len + 1 != n) return fail(BWT_EINVAL, "index: .ref length must be rows-1");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BWT_EINVAL, "index: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+
+    // 64-byte rank blocks: 4 x u32 cumulative counts (rows <= blk*192) + 192 bases x 2 bit
+    const uint32_t nblk = n / BWT_BLOCK_ROWS + 1;
+    std::vector<uint32_t> blk((size_t)nblk * 16, 0);
+    uint32_t cnt[4] = {0, 0, 0, 0}, dollar = 0;
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t *w = &blk[(size_t)b * 16];
+        w[0] = cnt[0]; w[1] = cnt[1]; w[2] = cnt[2]; w[3] = cnt[3];
+        for (uint32_t i = 0; i < BWT_BLOCK_ROWS; i++) {
+            const uint64_t row0 = (uint64_t)b * BWT_BLOCK_ROWS + i;     // 0-based row
+            if (row0 >= n) break;
+            const uint8_t c = fm.L[row0];
+            uint32_t code;
+            switch (c) {
+            case 'A': code = 0; break;
+            case 'C': code = 1; break;
+            case 'G': code = 2; break;
+            case 'T': code = 3; break;
+            case '$':
+                if (dollar) return fail(BWT_EINVAL, "index: more than one $ in L");
+                dollar = (uint32_t)row0 + 1; code = 0; break;
+            default: return fail(BWT_EINVAL, "index: L outside $ACGT");
+            }
+            if (c != '$') cnt[code]++;
+            w[4 + i / 16] |= code << (2 * (i % 16));
+        }
+    }
+    if (!dollar) return fail(BWT_EINVAL, "index: no $ in L");
+    if (2 + cnt[0] != fm.Pc || fm.Pc + cnt[1] != fm.Pg || fm.Pg + cnt[2] != fm.Pt || fm.Pt + cnt[3] != (uint64_t)n + 1)
+        return fail(BWT_EINVAL, "index: pointers disagree with the base counts of L");
+
+    bwt_index *ix = new bwt_index();
+    ix->device = device;
+    ix->Pc = fm.Pc; ix->Pg = fm.Pg; ix->Pt = fm.Pt; ix->Last = fm.Last; ix->shift = fm.shift;
+    ix->ref1_len = ref_len + 2 * BWT_REF_EXT;
+    std::vector<uint8_t> r1(ix->ref1_len, (uint8_t)'N');      // worker_bwt.erl:54-55
+    if (ref_len) memcpy(r1.data() + BWT_REF_EXT, ref, ref_len);
+    int rc = 0;
+    if ((rc = ix->blocks.ensure(blk.size() * 4)) || (rc = ix->sa.ensure((size_t)n * 4)) ||
+        (rc = ix->ref1.ensure(r1.size()))) { bwt_index_close(ix); return rc; }
+    hipError_t e;
+    if ((e = hipMemcpy(ix->blocks.p, blk.data(), blk.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(ix->sa.p, fm.SA.data(), (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(ix->ref1.p, r1.data(), r1.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) {
+        bwt_index_close(ix);
+        return fail(BWT_EHIP, std::string("index upload: ") + hipGetErrorString(e));
+    }
+    ix->d.blocks = ix->blocks.as<uint4>(); ix->d.sa = ix->sa.as<uint32_t>(); ix->d.ref1 = ix->ref1.as<uint8_t>();
+    ix->d.ref1_len = ix->ref1_len;
+    ix->d.Pc = fm.Pc; ix->d.Pg = fm.Pg; ix->d.Pt = fm.Pt; ix->d.Last = fm.Last; ix->d.dollar = dollar; ix->d.nblk = nblk;
+    ix->d.c0[0] = 1; ix->d.c0[1] = fm.Pc - 1; ix->d.c0[2] = fm.Pg - 1; ix->d.c0[3] = fm.Pt - 1;
+    *out = ix;
+    return 0;
+}
+
+extern "C" int bwt_index_open(const char *fm_path, const char *ref_path, int device, bwt_index **out) {
+    if (!fm_path || !ref_path || !out) return fail(BWT_EINVAL, "bwt_index_open: null argument");
+    FmHost fm;
+    std::string err;
+    int rc = fm_read_etf(fm_path, fm, err);
+    if (rc) return fail(rc, err);
+    FILE *f = fopen(ref_path, "rb");
+    if (!f) return fail(BWT_EIO, std::string("cannot open ") + ref_path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> ref((size_t)sz);
+    if (sz > 0 && fread(ref.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return fail(BWT_EIO, "short read on .ref"); }
+    fclose(f);
+    return index_build(fm, ref.data(), ref.size(), device, out);
+}
+
+extern "C" int bwt_index_from_arrays(const uint8_t *L, const uint32_t *SA, uint32_t n_rows, const uint32_t pointers[4],
+                                     int32_t shift, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
+    if (!L || !SA || !pointers || !out || (!ref && ref_len)) return fail(BWT_EINVAL, "bwt_index_from_arrays: null argument");
+    FmHost fm;
+    fm.L.assign(L, L + n_rows);
+    fm.SA.assign(SA, SA + n_rows);
+    fm.Pc = pointers[0]; fm.Pg = pointers[1]; fm.Pt = pointers[2]; fm.Last = pointers[3]; fm.shift = shift;
+    return index_build(fm, ref, ref_len, device, out);
+}
+
+extern "C" void bwt_index_close(bwt_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    ix->blocks.release(); ix->sa.release(); ix->ref1.release();
+    delete ix;
+}
+
+extern "C" int bwt_index_meta(const bwt_index *ix, uint32_t out[5]) {
+    if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_meta: null argument");
+    out[0] = ix->Pc; out[1] = ix->Pg; out[2] = ix->Pt; out[3] = ix->Last; out[4] = (uint32_t)ix->shift;
+    return 0;
+}
+
+extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[3]) {
+    if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_device_bytes: null argument");
+    out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len;
+    return 0;
+}
+
+extern "C" int bwt_ref1_read(const bwt_index *ix, uint64_t off, uint64_t len, uint8_t *outp) {
+    if (!ix || (!outp && len)) return fail(BWT_EINVAL, "bwt_ref1_read: null argument");
+    if (off > ix->ref1_len || len > ix->ref1_len - off) return fail(BWT_EINVAL, "bwt_ref1_read: range outside Ref1");
+    HIPCHK(hipSetDevice(ix->device));
+    if (len) HIPCHK(hipMemcpy(outp, ix->ref1.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct KernelStat { double ms = 0; uint64_t launches = 0; };
+
+struct bwt_batch {
+    bwt_index *ix = nullptr;         // may be null for the index-free SW entry point
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // inputs
+    uint32_t n = 0, maxT = 0, max_lq = 0;
+    uint64_t total_bases = 0;
+    DevBuf bases, off;
+    // tasks
+    DevBuf t_def, t_sp, t_ep, t_info, t_cnt;
+    // reads
+    DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, seed_off, clus_off, hit_off, cigb_off;
+    DevBuf pos, scan_tmp;
+    // candidates
+    uint64_t n_cand = 0;
+    DevBuf c_read, c_S, c_D, c_qoff, c_qlen, c_woff, c_wlen, c_status, c_score, c_ciglen, cig, fpq;
+    uint32_t cig_stride = 32;
+    // sw slabs
+    DevBuf slab_bnd, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp;
+    // hits
+    uint64_t n_hits = 0, cig_bytes = 0;
+    DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig;
+    // counters
+    DevBuf ctr;
+    Counters hctr{};
+    int done = 0;                    // stages completed
+    // for sw-only batches
+    const uint8_t *sw_rbuf = nullptr;
+    uint64_t sw_rbuf_len = 0;
+    // profiling
+    bool prof = false;
+    struct Pending { const char *name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    std::map<std::string, KernelStat> stats;
+};
+
+static int prof_collect(bwt_batch *b) {
+    for (auto &p : b->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &s = b->stats[p.name];
+            s.ms += ms; s.launches++;
+        }
+        b->ev_pool.push_back(p.a); b->ev_pool.push_back(p.b);
+    }
+    b->pending.clear();
+    return 0;
+}
+
+struct ProfScope {
+    bwt_batch *b; const char *name; hipEvent_t a = nullptr, e = nullptr;
+    ProfScope(bwt_batch *b_, const char *n) : b(b_), name(n) {
+        if (!b->prof) return;
+        auto get = [&]() { hipEvent_t ev = nullptr; if (!b->ev_pool.empty()) { ev = b->ev_pool.back(); b->ev_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
+        a = get(); e = get();
+        (void)hipEventRecord(a, b->stream);
+    }
+    ~ProfScope() {
+        if (!b->prof) return;
+        (void)hipEventRecord(e, b->stream);
+        b->pending.push_back({name, a, e});
+    }
+};
+
+#define KLAUNCH(b, name, kern, grid, block, ...)                                   \
+    do {                                                                           \
+        ProfScope _ps(b, name);                                                    \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (b)->stream, __VA_ARGS__); \
+    } while (0)
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// exclusive scan in[0..n) (u32) -> out[0..n] (u64, out[n] = total)
+static int dev_scan(bwt_batch *b, const uint32_t *in, uint64_t *out, uint64_t n) {
+    const uint32_t nb = std::max<uint32_t>(1, cdiv(n, SCAN_TILE));
+    int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8);
+    if (rc) return rc;
+    uint64_t *bs = b->scan_tmp.as<uint64_t>();
+    KLAUNCH(b, "scan", k_scan1, nb, SCAN_BLOCK, in, out, bs, n);
+    KLAUNCH(b, "scan", k_scan2, 1, SCAN_BLOCK, bs, nb);
+    KLAUNCH(b, "scan", k_scan3, nb, SCAN_BLOCK, out, bs, n, nb);
+    return 0;
+}
+
+extern "C" int bwt_batch_create(bwt_index *ix, bwt_batch **out) {
+    if (!ix || !out) return fail(BWT_EINVAL, "bwt_batch_create: null argument");
+    HIPCHK(hipSetDevice(ix->device));
+    bwt_batch *b = new bwt_batch();
+    b->ix = ix; b->device = ix->device; b->stream = ix->stream;
+    int rc = b->ctr.ensure(sizeof(Counters));
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return 0;
+}
+
+static int batch_create_noindex(int device, bwt_batch **out) {
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BWT_EINVAL, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    bwt_batch *b = new bwt_batch();
+    b->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete b; return fail(BWT_EHIP, "hipStreamCreate failed"); }
+    b->own_stream = true;
+    int rc = b->ctr.ensure(sizeof(Counters));
+    if (rc) { bwt_batch_destroy(b); return rc; }
+    *out = b;
+    return 0;
+}
+
+extern "C" void bwt_batch_destroy(bwt_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    prof_collect(b);
+    for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
+    DevBuf *all[] = {&b->bases, &b->off, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
+                     &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->seed_off, &b->clus_off, &b->hit_off,
+                     &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
+                     &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->h_cigoff, &b->h_cig, &b->ctr};
+    for (auto d : all) d->release();
+    if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+extern "C" int bwt_batch_profile(bwt_batch *b, int enable) {
+    if (!b) return fail(BWT_EINVAL, "bwt_batch_profile: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    prof_collect(b);
+    b->stats.clear();
+    b->prof = enable != 0;
+    return 0;
+}
+
+extern "C" int bwt_batch_kernel_times(bwt_batch *b, char *names, uint32_t names_cap, double *ms, uint64_t *launches,
+                                      uint32_t cap) {
+    if (!b) return fail(BWT_EINVAL, "bwt_batch_kernel_times: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    prof_collect(b);
+    uint32_t k = 0, np = 0;
+    for (auto &kv : b->stats) {
+        if (k >= cap || np + kv.first.size() + 1 > names_cap) break;
+        memcpy(names + np, kv.first.c_str(), kv.first.size() + 1);
+        np += (uint32_t)kv.first.size() + 1;
+        ms[k] = kv.second.ms; launches[k] = kv.second.launches;
+        k++;
+    }
+    return (int)k;
+}
+
+extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n) {
+    if (!b || (!bases && n) || !off) return fail(BWT_EINVAL, "bwt_batch_set_reads: null argument");
+    HIPCHK(hipSetDevice(b->device));
+    uint32_t maxlq = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (off[i + 1] < off[i]) return fail(BWT_EINVAL, "bwt_batch_set_reads: offsets must be non-decreasing");
+        uint64_t l = off[i + 1] - off[i];
+        if (l > 65535) return fail(BWT_EINVAL, "bwt_batch_set_reads: read longer than 65535 bases");
+        maxlq = std::max<uint32_t>(maxlq, (uint32_t)l);
+    }
+    const uint64_t total = n ? off[n] - off[0] : 0;
+    int rc;
+    if ((rc = b->bases.ensure(total + 16)) || (rc = b->off.ensure(((size_t)n + 1) * 8))) return rc;
+    // offsets are rebased to 0 on the device
+    std::vector<uint64_t> o((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; i++) o[i] = off[i] - off[0];
+    if (total) HIPCHK(hipMemcpyAsync(b->bases.p, bases + off[0], total, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->off.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
+    b->total_bases = total;
+    b->done = 0; b->n_cand = 0; b->n_hits = 0; b->cig_bytes = 0;
+    return 0;
+}
+
+static int fetch_counters(bwt_batch *b) {
+    HIPCHK(hipMemcpyAsync(&b->hctr, b->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+static int stage_search(bwt_batch *b) {
+    const uint32_t n = b->n, maxT = b->maxT;
+    const uint64_t T = (uint64_t)n * maxT;
+    int rc;
+    if ((rc = b->t_def.ensure(T * 4 + 4)) || (rc = b->t_sp.ensure(T * 4 + 4)) || (rc = b->t_ep.ensure(T * 4 + 4)) ||
+        (rc = b->t_info.ensure(T * 4 + 4)) || (rc = b->t_cnt.ensure(T * 4 + 4)))
+        return rc;
+    HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
+    if (n == 0) return 0;
+    KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), n, maxT,
+            b->t_def.as<uint32_t>());
+    KLAUNCH(b, "fm_search", k_search, cdiv(T * 4, 256), 256, b->ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T,
+            maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
+            b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int stage_cluster(bwt_batch *b) {
+    const uint32_t n = b->n, maxT = b->maxT;
+    int rc;
+    if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
+        (rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->bigq.ensure((size_t)n * 4 + 4)) ||
+        (rc = b->seed_off.ensure(((size_t)n + 1) * 8)) || (rc = b->clus_off.ensure(((size_t)n + 1) * 8)))
+        return rc;
+    if (n == 0) { b->n_cand = 0; return fetch_counters(b); }
+    KLAUNCH(b, "read_counts", k_read_counts, cdiv(n, 256), 256, n, maxT, b->t_info.as<uint32_t>(),
+            b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
+            b->ctr.as<Counters>());
+    if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
+    uint64_t total_seeds = 0;
+    HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = fetch_counters(b))) return rc;                                   // sync #1
+    if (b->hctr.err_flags & 1) return fail(BWT_EOVERFLOW, "a read produced more than 2^31 seeds");
+    if (total_seeds > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 seeds: split it");
+    if ((rc = b->pos.ensure(total_seeds * 4 + 16))) return rc;
+    KLAUNCH(b, "cluster_small", k_cluster_small, cdiv((uint64_t)n * 64, 256), 256, b->ix->d, n, maxT,
+            b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
+            b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
+            b->r_K.as<uint32_t>());
+    if (b->hctr.n_big)
+        KLAUNCH(b, "cluster_big", k_cluster_big, b->hctr.n_big, 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
+                b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
+                b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
+                b->r_K.as<uint32_t>());
+    if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
+    uint64_t ncand = 0;
+    HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));                                   // sync #2
+    if (ncand > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 candidates: split it");
+    b->n_cand = ncand;
+    const size_t nc = (size_t)ncand + 1;
+    if ((rc = b->c_read.ensure(nc * 4)) || (rc = b->c_S.ensure(nc * 4)) || (rc = b->c_D.ensure(nc * 4)) ||
+        (rc = b->c_qoff.ensure(nc * 8)) || (rc = b->c_qlen.ensure(nc * 4)) || (rc = b->c_woff.ensure(nc * 8)) ||
+        (rc = b->c_wlen.ensure(nc * 4)))
+        return rc;
+    KLAUNCH(b, "candidates", k_candidates, cdiv(n, 256), 256, n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
+            b->seed_off.as<uint64_t>(), b->clus_off.as<uint64_t>(), b->pos.as<uint32_t>(), b->c_read.as<uint32_t>(),
+            b->c_S.as<uint32_t>(), b->c_D.as<uint32_t>(), b->c_qoff.as<uint64_t>(), b->c_qlen.as<uint32_t>(),
+            b->c_woff.as<int64_t>(), b->c_wlen.as<uint32_t>(), b->ctr.as<Counters>());
+    HIPCHK(hipGetLastError());
+    return fetch_counters(b);                                                  // sync #3 (max_w for the slabs)
+}
+
+// runs the integer kernel over all candidates, then the fp64 kernel over those that need it
+static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
+                  uint32_t max_lq) {
+    const uint64_t nc = b->n_cand;
+    int rc;
+    if ((rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) ||
+        (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)))
+        return rc;
+    if (nc == 0) return 0;
+    const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, b->device);
+    {
+        if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
+        // per-wave slabs; cap the resident waves so that the slabs stay within ~6 GiB
+        const uint64_t per_wave = (uint64_t)maxW1 * 64 * 4 * (1 + strips);
+        uint64_t waves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * 16);
+        waves = std::max<uint64_t>(1, std::min<uint64_t>(waves, (6ull << 30) / std::max<uint64_t>(per_wave, 1)));
+        const uint32_t blocks = cdiv(waves, 4);
+        waves = (uint64_t)blocks * 4;
+        if ((rc = b->slab_bnd.ensure(waves * maxW1 * 64 * 4)) || (rc = b->slab_dir.ensure(waves * maxW1 * 64 * 4 * strips)))
+            return rc;
+        const uint64_t fwaves = std::max<uint64_t>(4, std::min<uint64_t>(waves, 1024) / 4 * 4);
+        if ((rc = b->slab_bnd_fp.ensure(fwaves * maxW1 * 64 * 4)) || (rc = b->slab_bndv.ensure(fwaves * maxW1 * 64 * 8)) ||
+            (rc = b->slab_dir_fp.ensure(fwaves * maxW1 * 64 * 4 * strips)))
+            return rc;
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 4, b->stream));
+        SwIO io;
+        io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
+        io.c_qoff = b->c_qoff.as<uint64_t>(); io.c_qlen = b->c_qlen.as<uint32_t>();
+        io.c_woff = b->c_woff.as<int64_t>(); io.c_wlen = b->c_wlen.as<uint32_t>();
+        io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
+        io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
+        io.fpq = b->fpq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
+        KLAUNCH(b, "sw_extend", k_sw<false>, blocks, 256, io, (uint32_t)nc, maxW1, strips, b->slab_bnd.as<uint32_t>(),
+                (double *)nullptr, b->slab_dir.as<uint32_t>());
+        KLAUNCH(b, "sw_extend_fp64", k_sw<true>, (uint32_t)(fwaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
+                b->slab_bnd_fp.as<uint32_t>(), b->slab_bndv.as<double>(), b->slab_dir_fp.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+static int stage_hits(bwt_batch *b, int32_t shift) {
+    const uint32_t n = b->n;
+    int rc;
+    if ((rc = b->r_nhit.ensure((size_t)n * 4 + 4)) || (rc = b->r_cigb.ensure((size_t)n * 4 + 4)) ||
+        (rc = b->r_status.ensure((size_t)n * 4 + 4)) || (rc = b->hit_off.ensure(((size_t)n + 1) * 8)) ||
+        (rc = b->cigb_off.ensure(((size_t)n + 1) * 8)))
+        return rc;
+    if (n == 0) { b->n_hits = 0; b->cig_bytes = 0; return 0; }
+    KLAUNCH(b, "hits_count", k_hits_count, cdiv(n, 256), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
+            b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_cigb.as<uint32_t>(),
+            b->r_status.as<int32_t>(), b->ctr.as<Counters>());
+    if ((rc = dev_scan(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), n))) return rc;
+    if ((rc = dev_scan(b, b->r_cigb.as<uint32_t>(), b->cigb_off.as<uint64_t>(), n))) return rc;
+    uint64_t tot[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&tot[0], b->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(&tot[1], b->cigb_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = fetch_counters(b))) return rc;                                   // sync
+    b->n_hits = tot[0]; b->cig_bytes = tot[1];
+    const size_t nh = (size_t)tot[0] + 1;
+    if ((rc = b->h_rec.ensure(nh * 16)) || (rc = b->h_woff.ensure(nh * 8)) || (rc = b->h_wlen.ensure(nh * 4)) ||
+        (rc = b->h_cigoff.ensure(nh * 8)) || (rc = b->h_cig.ensure(tot[1] + 16)))
+        return rc;
+    KLAUNCH(b, "hits_write", k_hits_write, cdiv(n, 256), 256, n, shift, b->clus_off.as<uint64_t>(),
+            b->hit_off.as<uint64_t>(), b->cigb_off.as<uint64_t>(), b->r_status.as<int32_t>(), b->c_status.as<int32_t>(),
+            b->c_score.as<int32_t>(), b->c_ciglen.as<uint32_t>(), b->c_S.as<uint32_t>(), b->c_wlen.as<uint32_t>(),
+            b->c_woff.as<int64_t>(), b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->h_woff.as<int64_t>(),
+            b->h_wlen.as<int32_t>(), b->h_cigoff.as<uint64_t>(), b->h_cig.as<uint8_t>());
+    // terminating offset for the cigar text
+    HIPCHK(hipMemcpyAsync(b->h_cigoff.as<uint64_t>() + tot[0], &b->cig_bytes, 8, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
+                        uint32_t max_lq, int32_t shift) {
+    for (int attempt = 0; attempt < 8; attempt++) {
+        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq);
+        if (rc) return rc;
+        // clear the sticky CIGAR-overflow flag before counting
+        Counters *dc = b->ctr.as<Counters>();
+        HIPCHK(hipMemsetAsync(&dc->err_flags, 0, 8, b->stream));
+        if ((rc = stage_hits(b, shift))) return rc;
+        if (b->hctr.err_flags & 4) return fail(BWT_EHIP, "internal: candidate left pending by the extend stage");
+        if (!(b->hctr.err_flags & 2)) return 0;
+        b->cig_stride *= 4;                                   // a CIGAR did not fit its slot: widen and redo
+    }
+    return fail(BWT_EHIP, "internal: CIGAR slot overflow persists");
+}
+
+extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts) {
+    if (!b || !b->ix) return fail(BWT_EINVAL, "bwt_batch_run: batch has no index");
+    HIPCHK(hipSetDevice(b->device));
+    int rc;
+    if (stages & (BWT_STAGE_SEARCH | BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
+        if ((rc = stage_search(b))) return rc;
+        b->done = BWT_STAGE_SEARCH;
+    }
+    if (stages & (BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
+        if ((rc = stage_cluster(b))) return rc;
+        b->done |= BWT_STAGE_CLUSTER;
+    }
+    if (stages & BWT_STAGE_EXTEND) {
+        if ((rc = stage_extend(b, b->bases.as<uint8_t>(), b->ix->d.ref1, b->ix->d.ref1_len, b->hctr.max_w, b->hctr.max_lq,
+                               b->ix->shift)))
+            return rc;
+        b->done |= BWT_STAGE_EXTEND;
+    }
+    if ((rc = fetch_counters(b))) return rc;
+    if (counts) {
+        counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
+        counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
+        counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
+        counts->n_float = b->hctr.fp_count;
+    }
+    return 0;
+}
+
+template <typename T> static int d2h(bwt_batch *b, T *dst, const DevBuf &src, size_t count) {
+    if (!count || !dst) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src.p, count * sizeof(T), hipMemcpyDeviceToHost, b->stream));
+    return 0;
+}
+
+extern "C" int bwt_batch_fetch_tasks(bwt_batch *b, int32_t *status, uint32_t *sp, uint32_t *ep, uint32_t *nmatch,
+                                     uint32_t *task_read, uint32_t *task_end, uint64_t cap, uint64_t *needed) {
+    if (!b || !(b->done & BWT_STAGE_SEARCH)) return fail(BWT_EINVAL, "bwt_batch_fetch_tasks: search stage not run");
+    HIPCHK(hipSetDevice(b->device));
+    const uint64_t T = (uint64_t)b->n * b->maxT;
+    std::vector<uint32_t> def(T), info(T), vsp(T), vep(T);
+    int rc;
+    if ((rc = d2h(b, def.data(), b->t_def, T)) || (rc = d2h(b, info.data(), b->t_info, T)) ||
+        (rc = d2h(b, vsp.data(), b->t_sp, T)) || (rc = d2h(b, vep.data(), b->t_ep, T)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    uint64_t k = 0;
+    for (uint64_t t = 0; t < T; t++) {
+        if ((def[t] & 0xffff) == 0) continue;
+        if (k < cap) {
+            const uint32_t st = info[t] & 0xff;
+            if (status) status[k] = st == TS_CRASH ? -1 : (int32_t)st;
+            if (sp) sp[k] = vsp[t];
+            if (ep) ep[k] = vep[t];
+            if (nmatch) nmatch[k] = (info[t] >> 8) & 0xff;
+            if (task_read) task_read[k] = (uint32_t)(t / b->maxT);
+            if (task_end) task_end[k] = def[t] & 0xffff;
+        }
+        k++;
+    }
+    if (needed) *needed = k;
+    return k > cap ? fail(BWT_ENOSPC, "task capacity too small") : 0;
+}
+
+extern "C" int bwt_batch_fetch_clusters(bwt_batch *b, uint64_t *clus_off, int64_t *S, int32_t *D, uint64_t cap,
+                                        uint64_t *needed, int32_t *read_status) {
+    if (!b || !(b->done & BWT_STAGE_CLUSTER)) return fail(BWT_EINVAL, "bwt_batch_fetch_clusters: cluster stage not run");
+    HIPCHK(hipSetDevice(b->device));
+    if (needed) *needed = b->n_cand;
+    int rc;
+    if (clus_off && (rc = d2h(b, clus_off, b->clus_off, (size_t)b->n + 1))) return rc;
+    std::vector<uint32_t> qty(b->n);
+    if (read_status && (rc = d2h(b, qty.data(), b->r_qty, b->n))) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (read_status) for (uint32_t i = 0; i < b->n; i++) read_status[i] = (qty[i] >> 31) ? -1 : 0;
+    if (b->n_cand > cap) return fail(BWT_ENOSPC, "cluster capacity too small");
+    std::vector<uint32_t> s(b->n_cand), d(b->n_cand);
+    if ((rc = d2h(b, s.data(), b->c_S, b->n_cand)) || (rc = d2h(b, d.data(), b->c_D, b->n_cand))) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint64_t i = 0; i < b->n_cand; i++) { if (S) S[i] = s[i]; if (D) D[i] = (int32_t)d[i]; }
+    return 0;
+}
+
+extern "C" int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, int32_t *score, int64_t *pos,
+                                    int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t hit_cap,
+                                    uint64_t cig_cap, uint64_t needed[2]) {
+    if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits: extend stage not run");
+    HIPCHK(hipSetDevice(b->device));
+    if (needed) { needed[0] = b->n_hits; needed[1] = b->cig_bytes; }
+    int rc;
+    if ((rc = d2h(b, read_status, b->r_status, b->n)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1))) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->n_hits > hit_cap || b->cig_bytes > cig_cap) return fail(BWT_ENOSPC, "hit / cigar capacity too small");
+    std::vector<HitRec> rec(b->n_hits);
+    if ((rc = d2h(b, rec.data(), b->h_rec, b->n_hits)) || (rc = d2h(b, win_off, b->h_woff, b->n_hits)) ||
+        (rc = d2h(b, win_len, b->h_wlen, b->n_hits)) || (rc = d2h(b, cig_off, b->h_cigoff, b->n_hits + 1)) ||
+        (rc = d2h(b, cigar, b->h_cig, b->cig_bytes)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint64_t i = 0; i < b->n_hits; i++) { if (score) score[i] = rec[i].score; if (pos) pos[i] = rec[i].pos; }
+    return 0;
+}
+
+extern "C" int bwt_batch_hits_to_device(bwt_batch *b, void *dev_dst, uint64_t cap_hits) {
+    if (!b || !(b->done & BWT_STAGE_EXTEND) || !dev_dst) return fail(BWT_EINVAL, "bwt_batch_hits_to_device: not ready");
+    HIPCHK(hipSetDevice(b->device));
+    if (b->n_hits > cap_hits) return fail(BWT_ENOSPC, "hit capacity too small");
+    if (b->n_hits) HIPCHK(hipMemcpyAsync(dev_dst, b->h_rec.p, b->n_hits * 16, hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-buffer entry points (what a NIF binds)
+extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const uint64_t *off, uint32_t n, int32_t *status,
+                                    uint32_t *sp, uint32_t *ep, uint32_t *nmatch, uint64_t *seed_off, int64_t *seeds,
+                                    uint64_t seeds_cap, uint64_t *seeds_needed) {
+    if (!ix || !off) return fail(BWT_EINVAL, "bwt_find_seeds_batch: null argument");
+    for (uint32_t i = 0; i < n; i++)
+        if (off[i + 1] <= off[i]) return fail(BWT_EINVAL, "bwt_find_seeds_batch: empty sub-read (the reference crashes on [])");
+    bwt_batch *b = nullptr;
+    int rc = bwt_batch_create(ix, &b);
+    if (rc) return rc;
+    struct Guard { bwt_batch *b; ~Guard() { bwt_batch_destroy(b); } } g{b};
+    if ((rc = bwt_batch_set_reads(b, bases, off, n))) return rc;
+    // every sub-read is its own task here: one task slot per "read", defined directly
+    b->maxT = 1;
+    const uint64_t T = n;
+    if ((rc = b->t_def.ensure(T * 4 + 4)) || (rc = b->t_sp.ensure(T * 4 + 4)) || (rc = b->t_ep.ensure(T * 4 + 4)) ||
+        (rc = b->t_info.ensure(T * 4 + 4)) || (rc = b->t_cnt.ensure(T * 4 + 4)) || (rc = b->seed_off.ensure((T + 1) * 8)))
+        return rc;
+    std::vector<uint32_t> def(T);
+    for (uint32_t i = 0; i < n; i++) def[i] = (uint32_t)(off[i + 1] - off[i]);
+    HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
+    if (T) {
+        HIPCHK(hipMemcpyAsync(b->t_def.p, def.data(), T * 4, hipMemcpyHostToDevice, b->stream));
+        KLAUNCH(b, "fm_search", k_search, cdiv(T * 4, 256), 256, ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T, 1u,
+                b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
+                b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
+    }
+    if ((rc = dev_scan(b, b->t_cnt.as<uint32_t>(), b->seed_off.as<uint64_t>(), T))) return rc;
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, b->seed_off.as<uint64_t>() + T, 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (seeds_needed) *seeds_needed = total;
+    std::vector<uint32_t> info(T);
+    if ((rc = d2h(b, info.data(), b->t_info, T)) || (rc = d2h(b, sp, b->t_sp, T)) || (rc = d2h(b, ep, b->t_ep, T)) ||
+        (rc = d2h(b, seed_off, b->seed_off, T + 1)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint64_t i = 0; i < T; i++) {
+        const uint32_t st = info[i] & 0xff;
+        if (status) status[i] = st == TS_CRASH ? -1 : (int32_t)st;
+        if (nmatch) nmatch[i] = (info[i] >> 8) & 0xff;
+    }
+    if (total > seeds_cap) return fail(BWT_ENOSPC, "seed capacity too small");
+    if (total && seeds) {
+        DevBuf dseeds;
+        if ((rc = dseeds.ensure(total * 8))) return rc;
+        KLAUNCH(b, "seed_list", k_seed_list, cdiv(T * 64, 256), 256, ix->d, T, b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
+                b->t_cnt.as<uint32_t>(), b->seed_off.as<uint64_t>(), dseeds.as<int64_t>());
+        hipError_t e = hipMemcpyAsync(seeds, dseeds.p, total * 8, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        dseeds.release();
+        if (e != hipSuccess) return fail(BWT_EHIP, std::string("seed list: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
+extern "C" int bwt_sga_batch(bwt_index *ix, const uint8_t *bases, const uint64_t *off, uint32_t n, uint64_t *clus_off,
+                             int64_t *S, int32_t *D, uint64_t cap, uint64_t *needed, int32_t *read_status) {
+    if (!ix || !off) return fail(BWT_EINVAL, "bwt_sga_batch: null argument");
+    bwt_batch *b = nullptr;
+    int rc = bwt_batch_create(ix, &b);
+    if (rc) return rc;
+    struct Guard { bwt_batch *b; ~Guard() { bwt_batch_destroy(b); } } g{b};
+    if ((rc = bwt_batch_set_reads(b, bases, off, n))) return rc;
+    if ((rc = bwt_batch_run(b, BWT_STAGE_CLUSTER, nullptr))) return rc;
+    return bwt_batch_fetch_clusters(b, clus_off, S, D, cap, needed, read_status);
+}
+
+extern "C" int bwt_align_batch(bwt_index *ix, const uint8_t *bases, const uint64_t *off, uint32_t n, int32_t *read_status,
+                               uint64_t *hit_off, int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len,
+                               uint64_t *cig_off, char *cigar, uint64_t hit_cap, uint64_t cig_cap, uint64_t needed[2]) {
+    if (!ix || !off) return fail(BWT_EINVAL, "bwt_align_batch: null argument");
+    bwt_batch *b = nullptr;
+    int rc = bwt_batch_create(ix, &b);
+    if (rc) return rc;
+    struct Guard { bwt_batch *b; ~Guard() { bwt_batch_destroy(b); } } g{b};
+    if ((rc = bwt_batch_set_reads(b, bases, off, n))) return rc;
+    if ((rc = bwt_batch_run(b, BWT_STAGE_EXTEND, nullptr))) return rc;
+    return bwt_batch_fetch_hits(b, read_status, hit_off, score, pos, win_off, win_len, cig_off, cigar, hit_cap, cig_cap,
+                                needed);
+}
+
+extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, const uint8_t *r, const uint64_t *roff,
+                            uint32_t n, int32_t *status, int32_t *score, uint64_t *cig_off, char *cigar, uint64_t cig_cap,
+                            uint64_t *cig_needed) {
+    if ((!q && n) || !qoff || (!r && n) || !roff) return fail(BWT_EINVAL, "bwt_sw_batch: null argument");
+    uint32_t max_lq = 0, max_w = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (qoff[i + 1] <= qoff[i] || roff[i + 1] <= roff[i])
+            return fail(BWT_EINVAL, "bwt_sw_batch: empty sequence (sw:sw/2 needs two non-empty lists)");
+        if (qoff[i + 1] - qoff[i] > 65535 || roff[i + 1] - roff[i] > (1u << 24))
+            return fail(BWT_EINVAL, "bwt_sw_batch: sequence too long");
+        max_lq = std::max<uint32_t>(max_lq, (uint32_t)(qoff[i + 1] - qoff[i]));
+        max_w = std::max<uint32_t>(max_w, (uint32_t)(roff[i + 1] - roff[i]));
+    }
+    bwt_batch *b = nullptr;
+    int rc = batch_create_noindex(device, &b);
+    if (rc) return rc;
+    struct Guard { bwt_batch *b; ~Guard() { bwt_batch_destroy(b); } } g{b};
+    const uint64_t qtot = n ? qoff[n] - qoff[0] : 0, rtot = n ? roff[n] - roff[0] : 0;
+    DevBuf dq, dr;
+    struct G2 { DevBuf &a, &b; ~G2() { a.release(); b.release(); } } g2{dq, dr};
+    const size_t nc = (size_t)n + 1;
+    if ((rc = dq.ensure(qtot + 16)) || (rc = dr.ensure(rtot + 16)) || (rc = b->c_qoff.ensure(nc * 8)) ||
+        (rc = b->c_qlen.ensure(nc * 4)) || (rc = b->c_woff.ensure(nc * 8)) || (rc = b->c_wlen.ensure(nc * 4)) ||
+        (rc = b->clus_off.ensure((nc + 1) * 8)) || (rc = b->r_qty.ensure(nc * 4)) || (rc = b->c_S.ensure(nc * 4)))
+        return rc;
+    std::vector<uint64_t> hq(n), co((size_t)n + 1);
+    std::vector<int64_t> hw(n);
+    std::vector<uint32_t> lq(n), lw(n);
+    for (uint32_t i = 0; i < n; i++) {
+        hq[i] = qoff[i] - qoff[0]; hw[i] = (int64_t)(roff[i] - roff[0]);
+        lq[i] = (uint32_t)(qoff[i + 1] - qoff[i]); lw[i] = (uint32_t)(roff[i + 1] - roff[i]);
+        co[i] = i;
+    }
+    co[n] = n;
+    HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(dq.p, q + qoff[0], qtot, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(dr.p, r + roff[0], rtot, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->c_qoff.p, hq.data(), (size_t)n * 8, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->c_woff.p, hw.data(), (size_t)n * 8, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->c_qlen.p, lq.data(), (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->c_wlen.p, lw.data(), (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemsetAsync(b->r_qty.p, 0, (size_t)n * 4, b->stream));
+        HIPCHK(hipMemsetAsync(b->c_S.p, 0, (size_t)n * 4, b->stream));
+    }
+    HIPCHK(hipMemcpyAsync(b->clus_off.p, co.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    // one "read" per pair, one candidate each
+    b->n = n; b->n_cand = n;
+    if ((rc = stage_extend(b, dq.as<uint8_t>(), dr.as<uint8_t>(), rtot, max_w, max_lq, 0))) return rc;
+    if (cig_needed) *cig_needed = b->cig_bytes;
+    std::vector<int32_t> cst(n), csc(n);
+    std::vector<uint32_t> cl(n);
+    if ((rc = d2h(b, cst.data(), b->c_status, n)) || (rc = d2h(b, csc.data(), b->c_score, n)) ||
+        (rc = d2h(b, cl.data(), b->c_ciglen, n)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (cig_off) cig_off[i] = o;
+        const bool ok = cst[i] == CS_OK;
+        if (status) status[i] = ok ? 0 : 1;
+        if (score) score[i] = ok ? csc[i] : 0;
+        if (ok) o += cl[i];
+    }
+    if (cig_off) cig_off[n] = o;
+    if (o > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
+    if (o && cigar) {
+        HIPCHK(hipMemcpyAsync(cigar, b->h_cig.p, o, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    return 0;
+}

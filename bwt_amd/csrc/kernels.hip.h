@@ -1,0 +1,729 @@
+// Device kernels of libbwtgpu (gfx950 / CDNA4, wave64).  Included once by bwt_gpu.hip.
+//
+// Reference functions restated here (paths relative to /root/reference):
+//   k_subreads        sga:skip_Ns/1,4 + the sub-read chain of sga:sga/9      src/sga.erl:18-34,69-76
+//   k_search          bwa:find_seeds/6,/5 + fmi:se_down/se_up in Occ form     src/bwa.erl:12-45, src/fmi.erl:25-39
+//   k_seed_list       fmi:get_seed_ends/4,5                                   src/fmi.erl:89-100
+//   k_cluster_*       sga:add_seeds/3 + sga:get_similar/2,7                   src/sga.erl:37-64
+//   k_candidates      window slice of worker_loop(running,..)                 src/worker_bwt.erl:86-90
+//   k_sw<FP>          sw:sw/3, build_tab, add_row2tab, sigma, get_CIGAR       src/sw.erl:47-202
+//   k_hits_*          the Cigars fold (order, Pos) of worker_loop             src/worker_bwt.erl:84-97
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BWT_MIN_LEN 8
+#define BWT_MAX_RANGE 45u
+#define BWT_MAX_LEN 15
+#define BWT_TOLERANCE 20u
+#define BWT_REF_EXT 200
+#define BWT_BLOCK_ROWS 192u
+
+// task status codes (t_info low byte)
+enum { TS_SEEDS = 0, TS_NO_SEEDS = 1, TS_TOO_MANY = 2, TS_NONE = 3, TS_CRASH = 4 };
+// candidate status codes
+enum { CS_OK = 0, CS_NO_MATCH = 1, CS_WINDOW_OOR = 2, CS_NEED_FP = 3, CS_CIG_OVERFLOW = 4, CS_PENDING = 5 };
+
+struct DevIndex {
+    const uint4 *blocks;   // nblk x 4 uint4 : [cntA cntC cntG cntT][64 bases][64 bases][64 bases]
+    const uint32_t *sa;    // SA[row] at sa[row-1]
+    const uint8_t *ref1;   // 200 x 'N' ++ .ref ++ 200 x 'N'
+    uint64_t ref1_len;
+    uint32_t Pc, Pg, Pt, Last, dollar, nblk;
+    uint32_t c0[4];        // {1, Pc-1, Pg-1, Pt-1}: 0-based first row of each F block (src/bwt.erl:105-112)
+};
+
+struct Counters {          // device-side work counters (roofline accounting)
+    unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags;
+    unsigned int max_w, max_lq, n_big, fp_count;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// sum over the 4 lanes of a quad (DPP quad_perm, no LDS traffic)
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    return v;
+}
+
+__device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anything else -> -1
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+__device__ __forceinline__ bool is_acgt(uint32_t c) {
+    uint32_t i = c - 'A';   // A=0 C=2 G=6 T=19
+    return i < 20u && ((0x80045u >> i) & 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan  u32 -> u64   (3 kernels: per-block, block sums, add back)
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                       uint64_t *__restrict__ bsum, uint64_t n) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t run = sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+}
+// single block: exclusive scan of bsum[0..nb) in place, total to bsum[nb]
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t nb) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nb; c0 += SCAN_BLOCK) {
+        uint32_t i = c0 + threadIdx.x;
+        uint64_t v = i < nb ? bsum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+            uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) bsum[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry += sh[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[nb] = carry;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(uint64_t *__restrict__ out, const uint64_t *__restrict__ bsum,
+                                                       uint64_t n, uint32_t nb) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    const uint64_t add = bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_subreads: one lane per read.  Enumerates the sub-reads sga:sga/9 will search:
+//   {Skip,Qseq1} = skip_Ns(Qseq); search Qseq1; Qseq <- first (len(Qseq1)-8) bases; Shift += 8+Skip.
+// task word = end (exclusive, = len(Qseq1)) | (Shift+Skip) << 16 ; 0 = no task.
+__global__ __launch_bounds__(256) void k_subreads(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
+                                                   uint32_t n, uint32_t maxT, uint32_t *__restrict__ t_def) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t *q = bases + off[r];
+    int len = (int)(off[r + 1] - off[r]);
+    uint32_t shift = 0, t = 0;
+    uint32_t *td = t_def + (uint64_t)r * maxT;
+    for (;;) {
+        if (len < BWT_MIN_LEN) break;                       // sga.erl:69
+        int j = 0, skipped = 0, k = len - 1;
+        bool ok = false;
+        for (;;) {
+            if (j == BWT_MIN_LEN) { ok = true; break; }     // sga.erl:72-73: tested before the list
+            if (k < 0) break;                               // sga.erl:76
+            if (q[k] == 'N') { skipped += j; j = 1; } else j++;
+            k--;
+        }
+        if (!ok) break;
+        int l1 = len - skipped;
+        td[t++] = (uint32_t)l1 | ((shift + (uint32_t)skipped) << 16);
+        len = l1 - BWT_MIN_LEN;
+        shift += BWT_MIN_LEN + (uint32_t)skipped;
+    }
+    for (; t < maxT; t++) td[t] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occ lookups on the rank-sampled BWT.  A quad (4 lanes) owns one task; lane q of the quad loads
+// bytes [16q,16q+16) of the 64-byte block, so one wave instruction fetches 16 whole blocks with
+// every 64-byte line requested exactly once.
+// count of bases == code among the first t (0..64) of the 64 bases in w
+__device__ __forceinline__ uint32_t count64(uint4 w, uint32_t pat, int t) {
+    uint32_t c = 0;
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t x = ww[k] ^ pat;
+        uint32_t y = ~(x | (x >> 1)) & 0x55555555u;
+        int tk = t - 16 * k;
+        uint32_t m = tk >= 16 ? 0xffffffffu : tk <= 0 ? 0u : ((1u << (2 * tk)) - 1u);
+        c += __popc(y & m);
+    }
+    return c;
+}
+// rows (blk*192, blk*192+m] of block blk: number whose L == code.  `$` is stored as code 0 and removed here.
+__device__ __forceinline__ uint32_t occ_block(const DevIndex &ix, uint4 w, int ql, uint32_t blk, uint32_t m,
+                                              uint32_t code, uint32_t pat) {
+    uint32_t part;
+    if (ql == 0) {
+        part = code == 0 ? w.x : code == 1 ? w.y : code == 2 ? w.z : w.w;
+    } else {
+        part = count64(w, pat, (int)m - 64 * (ql - 1));
+    }
+    uint32_t s = quad_sum(part);
+    uint32_t first = blk * BWT_BLOCK_ROWS;
+    if (code == 0 && ix.dollar > first && ix.dollar <= first + m) s -= 1;
+    return s;
+}
+
+// k_search: quad per task.  Closed form of se_down / se_up:
+//   found  <=>  occ(c,Ep-1) > occ(c,Sp-1);  Sp' = C0[c] + occ(c,Sp-1);  Ep' = C0[c] + occ(c,Ep) - 1
+// (I is the 0-based LF target but is used as a 1-based row by the reference -- kept as is).
+__global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                 const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
+                                                 const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
+                                                 uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
+                                                 uint32_t *__restrict__ t_cnt, Counters *ctr) {
+    const uint64_t gtid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t task = gtid >> 2;
+    const int ql = (int)(threadIdx.x & 3);
+    uint32_t steps = 0, live = 0;
+    if (task < n_tasks) {
+        const uint32_t def = t_def[task];
+        const int e = (int)(def & 0xffffu);
+        uint32_t status = TS_NONE, sp = 0, ep = 0, nm = 0;
+        if (e > 0) {
+            live = 1;
+            const uint32_t r = (uint32_t)(task / maxT);
+            const uint8_t *q = bases + off[r];
+            const uint32_t h = q[e - 1];
+            status = TS_SEEDS;
+            switch (h) {                                          // bwa.erl:15-24
+            case 'A': case 'N': sp = 1; ep = ix.Pc - 1; break;
+            case 'C': sp = ix.Pc; ep = ix.Pg - 1; break;
+            case 'G': sp = ix.Pg; ep = ix.Pt - 1; break;
+            case 'T': sp = ix.Pt; ep = ix.Last; break;
+            default: status = TS_CRASH; break;
+            }
+            if (status != TS_CRASH) {
+                int n = 1, k = e - 2;
+                bool check = true;
+                for (;;) {
+                    if (n == BWT_MAX_LEN) break;                  // bwa.erl:31-32
+                    if (k < 0) break;                             // bwa.erl:44-45
+                    const uint32_t c = q[k];
+                    if (c == 'N') break;                          // bwa.erl:33-34
+                    const int code = base_code(c);
+                    if (code < 0) { check = false; break; }       // never equals any L: not_found
+                    const uint32_t pat = (uint32_t)code * 0x55555555u;
+                    const uint32_t k1 = sp - 1, k2 = ep - 1;
+                    const uint32_t b1 = k1 / BWT_BLOCK_ROWS, b2 = k2 / BWT_BLOCK_ROWS;
+                    const uint4 w1 = ix.blocks[(uint64_t)b1 * 4 + ql];
+                    const uint4 w2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+                    const uint32_t m1 = k1 - b1 * BWT_BLOCK_ROWS, m2 = k2 - b2 * BWT_BLOCK_ROWS;
+                    const uint32_t o1 = occ_block(ix, w1, ql, b1, m1, (uint32_t)code, pat);          // occ(c,Sp-1)
+                    const uint32_t o2i = occ_block(ix, w2, ql, b2, m2 + 1, (uint32_t)code, pat);     // occ(c,Ep)
+                    const uint32_t o2 = occ_block(ix, w2, ql, b2, m2, (uint32_t)code, pat);          // occ(c,Ep-1)
+                    steps++;
+                    if (!(o2 > o1)) { check = false; break; }     // se_down: not_found (bwa.erl:38)
+                    sp = ix.c0[code] + o1;
+                    ep = ix.c0[code] + o2i - 1;
+                    n++; k--;
+                }
+                nm = (uint32_t)n;
+                if (check && ep - sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
+                else if (n < BWT_MIN_LEN) status = TS_NO_SEEDS;   // fmi.erl:89
+            }
+        }
+        if (ql == 0) {
+            t_sp[task] = sp; t_ep[task] = ep;
+            t_info[task] = status | (nm << 8);
+            t_cnt[task] = status == TS_SEEDS ? ep - sp + 1 : 0;
+        }
+    }
+    // one atomic per wave for the work counters
+    unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), l = wave_sum_u64(ql == 0 ? live : 0);
+    if ((threadIdx.x & 63) == 0 && (s | l)) {
+        atomicAdd(&ctr->lf_steps, s);
+        atomicAdd(&ctr->n_tasks, l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_seed_list: for bwt_find_seeds_batch -- SA[Ep]+N, SA[Ep-1]+N, ..., SA[Sp]+N per task (fmi.erl:92-100)
+__global__ __launch_bounds__(256) void k_seed_list(DevIndex ix, uint64_t n_tasks, const uint32_t *__restrict__ t_sp,
+                                                    const uint32_t *__restrict__ t_info, const uint32_t *__restrict__ t_cnt,
+                                                    const uint64_t *__restrict__ seed_off, int64_t *__restrict__ seeds) {
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (w >= n_tasks) return;
+    const uint32_t cnt = t_cnt[w];
+    if (!cnt) return;
+    const uint32_t sp = t_sp[w], nm = (t_info[w] >> 8) & 0xff;
+    const uint64_t o = seed_off[w];
+    for (uint32_t i = lane; i < cnt; i += 64)
+        seeds[o + i] = (int64_t)ix.sa[sp - 1 + (cnt - 1 - i)] + nm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_read_counts: lane per read.  P = total seeds, Qty = sub-reads that returned a seed list
+// (sga.erl:32).  Reads with Qty < 2 cluster to [] (sga.erl:42-43) and get P = 0.
+__global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, const uint32_t *__restrict__ t_info,
+                                                      const uint32_t *__restrict__ t_cnt, uint32_t *__restrict__ r_P,
+                                                      uint32_t *__restrict__ r_qty, uint32_t *__restrict__ bigq,
+                                                      Counters *ctr) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long P = 0;
+    if (r < n) {
+        uint32_t qty = 0, crash = 0;
+        for (uint32_t k = 0; k < maxT; k++) {
+            uint32_t st = t_info[(uint64_t)r * maxT + k] & 0xff;
+            if (st == TS_SEEDS) { qty++; P += t_cnt[(uint64_t)r * maxT + k]; }
+            else if (st == TS_CRASH) crash = 1;
+        }
+        if (qty < 2 || crash) P = 0;
+        if (P > 0x7fffffffull) { atomicOr(&ctr->err_flags, 1ull); P = 0; }
+        r_P[r] = (uint32_t)P;
+        r_qty[r] = qty | (crash << 31);
+        if (P > 64 || (P > 0 && maxT > 64)) bigq[atomicAdd(&ctr->n_big, 1u)] = r;
+    }
+    unsigned long long s = wave_sum_u64(P);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&ctr->sa_reads, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cluster_small: wave per read with 2 <= P <= 64 seeds: gather SA entries (one per lane), bitonic
+// sort across the wave, cluster with ballots (get_similar/7): a run of consecutive gaps <= 20 with
+// Count >= 2 + Qty div 7 emits {LastPos, LastPos-FirstPos}; output in descending position order.
+// Clusters are staged as (S,D) u32 pairs in the read's own slice of `pos` (K <= P/2 pairs fit).
+__global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, uint32_t maxT,
+                                                        const uint32_t *__restrict__ t_def,
+                                                        const uint32_t *__restrict__ t_sp,
+                                                        const uint32_t *__restrict__ t_info,
+                                                        const uint32_t *__restrict__ t_cnt,
+                                                        const uint32_t *__restrict__ r_P,
+                                                        const uint32_t *__restrict__ r_qty,
+                                                        const uint64_t *__restrict__ seed_off,
+                                                        uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+    const uint32_t r = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const uint32_t P = r_P[r];
+    if (P == 0) { if (lane == 0) r_K[r] = 0; return; }
+    if (P > 64 || maxT > 64) return;                      // k_cluster_big owns this read
+    const uint32_t qty = r_qty[r] & 0x7fffffffu;
+    uint32_t cnt = 0, sp = 0, nadd = 0;
+    if (lane < maxT) {
+        const uint64_t t = (uint64_t)r * maxT + lane;
+        cnt = t_cnt[t]; sp = t_sp[t];
+        nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);   // N + Shift + Skip (sga.erl:32,37-39)
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+    const uint32_t excl = incl - cnt;
+    uint32_t p = 0xffffffffu;
+    {
+        uint32_t msp = 0, madd = 0, midx = 0;
+        for (uint32_t k = 0; k < maxT; k++) {
+            uint32_t e = __shfl(excl, k, 64), c = __shfl(cnt, k, 64), s = __shfl(sp, k, 64), a = __shfl(nadd, k, 64);
+            if (lane >= e && lane < e + c) { msp = s; madd = a; midx = lane - e; }
+        }
+        if (lane < P) p = ix.sa[msp - 1 + midx] + madd;
+    }
+    // bitonic sort ascending over 64 lanes
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            uint32_t o = __shfl_xor(p, j, 64);
+            bool up = ((lane & k) == 0);
+            bool lower = ((lane & j) == 0);
+            uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
+            p = (lower == up) ? mn : mx;
+        }
+    }
+    const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
+    const bool valid = lane < P;
+    const bool start = valid && (lane == 0 || p - prev > BWT_TOLERANCE);
+    const bool end = valid && (lane == P - 1 || next - p > BWT_TOLERANCE);
+    const unsigned long long smask = __ballot(start);
+    const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
+    const uint32_t pfirst = __shfl(p, s_i, 64);
+    const uint32_t nthr = 2 + qty / 7;                    // sga.erl:46
+    const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
+    const unsigned long long emask = __ballot(emit);
+    if (emit) {
+        const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
+        const uint64_t o = seed_off[r] + 2ull * kk;
+        pos[o] = p;
+        pos[o + 1] = p - pfirst;
+    }
+    if (lane == 0) r_K[r] = (uint32_t)__popcll(emask);
+}
+
+// k_cluster_big: workgroup per read (P > 64): gather into the read's slice of `pos`, sort it
+// (ascending-only bitonic network: virtual +inf padding past P), cluster sequentially.
+#define BIG_LDS 4096
+__global__ __launch_bounds__(256) void k_cluster_big(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ bigq,
+                                                      const uint32_t *__restrict__ t_def,
+                                                      const uint32_t *__restrict__ t_sp,
+                                                      const uint32_t *__restrict__ t_info,
+                                                      const uint32_t *__restrict__ t_cnt,
+                                                      const uint32_t *__restrict__ r_P,
+                                                      const uint32_t *__restrict__ r_qty,
+                                                      const uint64_t *__restrict__ seed_off,
+                                                      uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+    __shared__ uint32_t sh[BIG_LDS];
+    const uint32_t r = bigq[blockIdx.x];
+    const uint32_t P = r_P[r];
+    uint32_t *reg = pos + seed_off[r];
+    uint32_t o = 0;
+    for (uint32_t k = 0; k < maxT; k++) {
+        const uint64_t t = (uint64_t)r * maxT + k;
+        const uint32_t cnt = t_cnt[t];
+        if (!cnt) continue;
+        const uint32_t sp = t_sp[t], nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) reg[o + i] = ix.sa[sp - 1 + i] + nadd;
+        o += cnt;
+    }
+    __syncthreads();
+    const bool in_lds = P <= BIG_LDS;
+    uint32_t *a = in_lds ? sh : reg;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) sh[i] = reg[i];
+        __syncthreads();
+    }
+    uint32_t n2 = 1;
+    while (n2 < P) n2 <<= 1;
+    for (uint32_t k = 2; k <= n2; k <<= 1) {
+        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {      // flip step
+            uint32_t j = i ^ (k - 1);
+            if (j > i && j < P) { uint32_t x = a[i], y = a[j]; if (x > y) { a[i] = y; a[j] = x; } }
+        }
+        __syncthreads();
+        for (uint32_t js = k >> 2; js > 0; js >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+                uint32_t j = i ^ js;
+                if (j > i && j < P) { uint32_t x = a[i], y = a[j]; if (x > y) { a[i] = y; a[j] = x; } }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t nthr = 2 + (r_qty[r] & 0x7fffffffu) / 7;
+        uint32_t K = 0, p1 = a[0], first = a[0], count = 1;
+        for (uint32_t i = 1; i <= P; i++) {
+            const bool endl = (i == P);
+            const uint32_t p2 = endl ? 0 : a[i];
+            if (!endl && p2 - p1 <= BWT_TOLERANCE) { count++; p1 = p2; continue; }
+            if (count >= nthr) { reg[2 * K] = p1; reg[2 * K + 1] = p1 - first; K++; }   // 2K+1 < i: already consumed
+            p1 = p2; first = p2; count = 1;
+        }
+        for (uint32_t x = 0, y = K ? K - 1 : 0; x < y; x++, y--) {       // descending order (sga.erl prepends)
+            uint32_t t0 = reg[2 * x], t1 = reg[2 * x + 1];
+            reg[2 * x] = reg[2 * y]; reg[2 * x + 1] = reg[2 * y + 1];
+            reg[2 * y] = t0; reg[2 * y + 1] = t1;
+        }
+        r_K[r] = K;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_candidates: lane per read: staged clusters -> dense candidate arrays + the window of
+// worker_bwt.erl:86-88:  Ref_len = Lq + D;  Start = S - Ref_len + 200 (offset into Ref1).
+__global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *__restrict__ off,
+                                                     const uint32_t *__restrict__ r_K,
+                                                     const uint64_t *__restrict__ seed_off,
+                                                     const uint64_t *__restrict__ clus_off,
+                                                     const uint32_t *__restrict__ pos, uint32_t *__restrict__ c_read,
+                                                     uint32_t *__restrict__ c_S, uint32_t *__restrict__ c_D,
+                                                     uint64_t *__restrict__ c_qoff, uint32_t *__restrict__ c_qlen,
+                                                     int64_t *__restrict__ c_woff, uint32_t *__restrict__ c_wlen,
+                                                     Counters *ctr) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cells = 0, wbytes = 0;
+    uint32_t maxw = 0, maxlq = 0;
+    if (r < n) {
+        const uint32_t K = r_K[r];
+        if (K) {
+            const uint64_t qo = off[r];
+            const uint32_t lq = (uint32_t)(off[r + 1] - qo);
+            const uint64_t co = clus_off[r], so = seed_off[r];
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t S = pos[so + 2 * k], D = pos[so + 2 * k + 1];
+                const uint32_t wl = lq + D;
+                c_read[co + k] = r; c_S[co + k] = S; c_D[co + k] = D;
+                c_qoff[co + k] = qo; c_qlen[co + k] = lq;
+                c_wlen[co + k] = wl;
+                c_woff[co + k] = (int64_t)S - (int64_t)wl + BWT_REF_EXT;
+                cells += (unsigned long long)lq * wl; wbytes += wl;
+                maxw = wl > maxw ? wl : maxw;
+            }
+            maxlq = lq;
+        }
+    }
+    cells = wave_sum_u64(cells); wbytes = wave_sum_u64(wbytes);
+    maxw = wave_max_u32(maxw); maxlq = wave_max_u32(maxlq);
+    if ((threadIdx.x & 63) == 0 && maxw) {
+        atomicAdd(&ctr->sw_cells, cells); atomicAdd(&ctr->window_bytes, wbytes);
+        atomicMax(&ctr->max_w, maxw); atomicMax(&ctr->max_lq, maxlq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Smith-Waterman (semi-global, direction-dependent gap cost) -- one LANE per alignment.
+// The query is cut into strips of SW_R rows held in registers; a strip sweeps all W columns;
+// the row between strips lives in a per-wave slab [j][lane]; 2-bit directions go to a per-wave
+// slab [strip][j][lane] (one dword per column per strip) for the traceback.
+//
+// Cell (src/sw.erl:88-98):  {V,Dir} = lists:max([{Vul+sigma,up_left},{Lvalue,left},{Uvalue,up}])
+// Term order makes that a lexicographic max on (V, Dir) with left < up < up_left, so the integer
+// path packs a cell as 4*V + code (left=0, up=1, up_left=2, undef=3) and one max3 does both.
+// Lvalue = Vleft + (Dleft==left ? -1 : -2), Uvalue = Vup + (Dup==up ? -1 : -2)  (sw.erl:103-107).
+// The per-row abort test (sw.erl:69) is equivalent to the test after the last row because
+// RowMax_{i+1} <= RowMax_i + 2, so only the last row's maximum is tracked.
+#define SW_R 16
+enum { DIR_LEFT = 0, DIR_UP = 1, DIR_UL = 2, DIR_UNDEF = 3 };
+
+__device__ __forceinline__ double sigma_gen(uint32_t s, uint32_t r) {   // src/sw.erl:164-202
+    if (s == 'N' && r == 'N') return 1.6;
+    if (s == r) return 2.0;
+    if (s == 'N' || r == 'N') return 1.6;
+    switch (r) {
+    case 'R': return (s == 'A' || s == 'G') ? 2.0 : -1.0;
+    case 'Y': return (s == 'C' || s == 'T') ? 2.0 : -1.0;
+    case 'B': return s == 'A' ? -1.0 : 2.0;
+    case 'D': return s == 'C' ? -1.0 : 2.0;
+    case 'K': return (s == 'G' || s == 'T') ? 2.0 : -1.0;
+    case 'M': return (s == 'A' || s == 'C') ? 2.0 : -1.0;
+    case 'S': return (s == 'G' || s == 'C') ? 2.0 : -1.0;
+    case 'W': return (s == 'A' || s == 'T') ? 2.0 : -1.0;
+    case 'V': return s == 'T' ? -1.0 : 2.0;
+    default: return -1.0;
+    }
+}
+
+struct SwIO {
+    const uint8_t *qbuf, *rbuf;
+    uint64_t rbuf_len;
+    const uint64_t *c_qoff;
+    const uint32_t *c_qlen;
+    const int64_t *c_woff;
+    const uint32_t *c_wlen;
+    int32_t *c_status, *c_score;
+    uint32_t *c_ciglen;
+    uint8_t *cig;              // n_cand x cig_stride, text right-aligned in its slot
+    uint32_t cig_stride;
+    uint32_t *fpq;             // queue of candidates for the fp64 kernel
+    Counters *ctr;
+};
+
+template <bool FP>
+__global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t maxW1, uint32_t max_strips,
+                                            uint32_t *__restrict__ slab_bnd, double *__restrict__ slab_bndv,
+                                            uint32_t *__restrict__ slab_dir) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t *bnd = slab_bnd + (uint64_t)wave * maxW1 * 64 + lane;                 // [j*64]
+    double *bndv = FP ? slab_bndv + (uint64_t)wave * maxW1 * 64 + lane : nullptr;
+    uint32_t *dirs = slab_dir + (uint64_t)wave * max_strips * maxW1 * 64 + lane;   // [(s*maxW1+j)*64]
+    const uint32_t n_total = FP ? io.ctr->fp_count : n_items;
+
+    for (uint32_t g = wave; (uint64_t)g * 64 < n_total; g += nwaves) {
+        const uint32_t item = g * 64 + lane;
+        if (item >= n_total) continue;
+        const uint32_t c = FP ? io.fpq[item] : item;
+        const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
+        const int64_t wo = io.c_woff[c];
+        if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
+            io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
+            continue;
+        }
+        const uint8_t *q = io.qbuf + io.c_qoff[c];
+        const uint8_t *rw = io.rbuf + wo;
+        const uint32_t ns = (lq + SW_R - 1) / SW_R;
+        bool needfp = false;
+
+        for (uint32_t j = 0; j <= w; j++) { bnd[j * 64] = DIR_UNDEF; if (FP) bndv[j * 64] = 0.0; }   // row 0: {0,undef}
+
+        // leftmost maximum of the last row; starts at column 0: V(Lq,0) = -(Lq+1)
+        int bestp = -(int)(lq + 1) * 4 + DIR_UP;
+        double bestv = -(double)(lq + 1);
+        uint32_t bestj = 0;
+
+        for (uint32_t s = 0; s < ns && !needfp; s++) {
+            const uint32_t i0 = s * SW_R;
+            uint32_t qc[SW_R];
+            int H[SW_R];        // int path: packed 4V+code of column j-1 ; FP path: code only
+            double Hv[SW_R];
+#pragma unroll
+            for (int t = 0; t < SW_R; t++) {
+                const uint32_t i = i0 + t;
+                qc[t] = i < lq ? q[i] : 0xffu;
+                if (!FP && i < lq && !is_acgt(qc[t])) needfp = true;
+                // column 0: V(i,0) = -(i+1) for row i = i0+t+1, dir up (sw.erl:73-77)
+                if (FP) { Hv[t] = -(double)(i0 + t + 2); H[t] = DIR_UP; }
+                else H[t] = -(int)(i0 + t + 2) * 4 + DIR_UP;
+            }
+            if (needfp) break;
+            // (i0, 0): row 0 is {0,undef}; otherwise column 0 of row i0
+            int dcar = s == 0 ? DIR_UNDEF : (FP ? DIR_UP : -(int)(i0 + 1) * 4 + DIR_UP);
+            double dcarv = s == 0 ? 0.0 : -(double)(i0 + 1);
+            const int tl = (int)(lq - 1 - i0);          // register slot of the last query row (last strip only)
+            const bool last = (s == ns - 1);
+            for (uint32_t j = 1; j <= w; j++) {
+                const uint32_t rc = rw[j - 1];
+                if (!FP && s == 0 && !is_acgt(rc)) { needfp = true; break; }
+                int d = dcar, u = bnd[j * 64];
+                double dv = dcarv, uv = 0.0;
+                if (FP) uv = bndv[j * 64];
+                dcar = u; dcarv = uv;
+                uint32_t dirw = 0;
+#pragma unroll
+                for (int t = 0; t < SW_R; t++) {
+                    if (FP) {
+                        const int lcode = H[t]; const double lv = Hv[t];
+                        const double cd = dv + sigma_gen(qc[t], rc);
+                        const double cl = lv + (lcode == DIR_LEFT ? -1.0 : -2.0);
+                        const double cu = uv + (u == DIR_UP ? -1.0 : -2.0);
+                        double hv = cd; int hc = DIR_UL;
+                        if (cu > hv) { hv = cu; hc = DIR_UP; }
+                        if (cl > hv) { hv = cl; hc = DIR_LEFT; }
+                        dirw |= (uint32_t)hc << (2 * t);
+                        d = lcode; dv = lv; u = hc; uv = hv; H[t] = hc; Hv[t] = hv;
+                    } else {
+                        const int old = H[t];
+                        const int sig = (qc[t] == rc) ? 7 : -5;                       // 4*sigma - 1
+                        const int cd = (d | 3) + sig;                                 // 4(Vul+sigma) + up_left
+                        const int cl = old + (int)(int8_t)(0xF5F6F7FCu >> ((old & 3) * 8));   // {-4,-9,-10,-11}
+                        const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));       // {-7,-4,-9,-10}
+                        int h = cd > cl ? cd : cl;
+                        h = h > cu ? h : cu;
+                        dirw |= (uint32_t)(h & 3) << (2 * t);
+                        d = old; u = h; H[t] = h;
+                    }
+                }
+                bnd[j * 64] = (uint32_t)H[SW_R - 1];
+                if (FP) bndv[j * 64] = Hv[SW_R - 1];
+                dirs[((uint64_t)s * maxW1 + j) * 64] = dirw;
+                if (last) {       // value of query row Lq in this column (register slot tl of the last strip)
+                    int lastp = H[0]; double lastv = Hv[0];
+#pragma unroll
+                    for (int t = 1; t < SW_R; t++) { if (t == tl) { lastp = H[t]; lastv = Hv[t]; } }
+                    if (FP) { if (lastv > bestv) { bestv = lastv; bestj = j; } }
+                    else if ((lastp >> 2) > (bestp >> 2)) { bestp = lastp; bestj = j; }
+                }
+            }
+        }
+        if (!FP && needfp) {
+            io.c_status[c] = CS_NEED_FP;
+            io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
+            continue;
+        }
+        // sw.erl:69 after the last row: no_match iff RowMax < -2*(Lq div 2) + 2*Lq
+        const int thr = -2 * (int)(lq / 2) + 2 * (int)lq;
+        int score;
+        if (FP) { if (bestv < (double)thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; } score = (int)bestv; }
+        else { score = bestp >> 2; if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; } }
+
+        // traceback (sw.erl:116-160): from the leftmost maximum of the last row up to row 0
+        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+        int p = (int)io.cig_stride, len = 0;
+        uint32_t i = lq, j = bestj;
+        int runop = -1; uint32_t runlen = 0;
+        for (;;) {
+            int code = -1;
+            if (i > 0) {
+                if (j == 0) code = DIR_UP;
+                else code = (int)((dirs[((uint64_t)((i - 1) / SW_R) * maxW1 + j) * 64] >> (2 * ((i - 1) % SW_R))) & 3u);
+            }
+            if (code == runop) { runlen++; }
+            else {
+                if (runop >= 0) {      // flush "<runlen><op>" written right to left
+                    const char opc = runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D';
+                    len++; if (--p >= 0) slot[p] = (uint8_t)opc;
+                    uint32_t v = runlen;
+                    do { len++; if (--p >= 0) slot[p] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
+                }
+                runop = code; runlen = 1;
+            }
+            if (code < 0) break;
+            if (code == DIR_UL) { i--; j--; } else if (code == DIR_UP) i--; else j--;
+        }
+        io.c_score[c] = score;
+        io.c_ciglen[c] = (uint32_t)len;
+        io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hits: the reference keeps, per read, the non-no_match results, prepending while it walks the
+// clusters (descending position) => final list order is ascending position (worker_bwt.erl:84-97).
+__global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *__restrict__ clus_off,
+                                                     const int32_t *__restrict__ c_status,
+                                                     const uint32_t *__restrict__ c_ciglen,
+                                                     const uint32_t *__restrict__ r_qty,
+                                                     uint32_t *__restrict__ r_nhit, uint32_t *__restrict__ r_cigb,
+                                                     int32_t *__restrict__ r_status, Counters *ctr) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t nh = 0, cb = 0;
+    int32_t st = 1;                                   // sga returned []
+    if (r_qty[r] >> 31) st = -1;
+    const uint64_t a = clus_off[r], b = clus_off[r + 1];
+    if (b > a) st = 0;
+    for (uint64_t k = a; k < b; k++) {
+        const int32_t cs = c_status[k];
+        if (cs == CS_OK) { nh++; cb += c_ciglen[k]; }
+        else if (cs == CS_WINDOW_OOR) st = -2;
+        else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
+    }
+    if (st == -2) { nh = 0; cb = 0; }
+    r_nhit[r] = nh; r_cigb[r] = cb; r_status[r] = st;
+}
+
+struct HitRec { uint32_t read; int32_t score; int64_t pos; };   // the 16-byte record gathered over RCCL
+
+__global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, const uint64_t *__restrict__ clus_off,
+                                                     const uint64_t *__restrict__ hit_off,
+                                                     const uint64_t *__restrict__ cigb_off,
+                                                     const int32_t *__restrict__ r_status,
+                                                     const int32_t *__restrict__ c_status,
+                                                     const int32_t *__restrict__ c_score,
+                                                     const uint32_t *__restrict__ c_ciglen,
+                                                     const uint32_t *__restrict__ c_S, const uint32_t *__restrict__ c_wlen,
+                                                     const int64_t *__restrict__ c_woff, const uint8_t *__restrict__ cig,
+                                                     uint32_t cig_stride, HitRec *__restrict__ h_rec,
+                                                     int64_t *__restrict__ h_woff, int32_t *__restrict__ h_wlen,
+                                                     uint64_t *__restrict__ h_cigoff, uint8_t *__restrict__ h_cig) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (r_status[r] != 0) return;
+    const uint64_t a = clus_off[r], b = clus_off[r + 1];
+    uint64_t ho = hit_off[r], co = cigb_off[r];
+    for (uint64_t k = b; k-- > a;) {                  // reverse of the cluster order
+        if (c_status[k] != CS_OK) continue;
+        const uint32_t wl = c_wlen[k], cl = c_ciglen[k];
+        HitRec hr; hr.read = r; hr.score = c_score[k];
+        hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
+        h_rec[ho] = hr; h_woff[ho] = c_woff[k]; h_wlen[ho] = (int32_t)wl; h_cigoff[ho] = co;
+        const uint8_t *src = cig + k * (uint64_t)cig_stride + (cig_stride - cl);
+        for (uint32_t x = 0; x < cl; x++) h_cig[co + x] = src[x];
+        ho++; co += cl;
+    }
+}

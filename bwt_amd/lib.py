@@ -1,0 +1,293 @@
+"""ctypes binding of libbwtgpu.so -- the C ABI of include/bwt_gpu.h.  Fails loudly when the
+library has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbwtgpu.so")
+
+STAGE_SEARCH, STAGE_CLUSTER, STAGE_EXTEND = 1, 2, 4
+ENOSPC = -28
+
+EXPORTS = [
+    "bwt_constants", "bwt_last_error", "bwt_index_open", "bwt_index_from_arrays", "bwt_index_close",
+    "bwt_index_meta", "bwt_index_device_bytes", "bwt_find_seeds_batch", "bwt_sga_batch", "bwt_sw_batch",
+    "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
+    "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
+    "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits",
+]
+
+
+class BwtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libbwtgpu error %d: %s" % (code, text))
+        self.code = code
+
+
+class Constants(C.Structure):
+    _fields_ = [("tolerance", C.c_int32), ("min_len", C.c_int32), ("max_range", C.c_int32), ("max_len", C.c_int32),
+                ("match", C.c_int32), ("mismatch", C.c_int32), ("gap_penalty", C.c_int32),
+                ("gap_ext_penalty", C.c_int32), ("unknown", C.c_double), ("ref_extension_len", C.c_int32)]
+
+
+class BatchCounts(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_reads", "n_tasks", "lf_steps", "sa_reads", "n_clusters", "sw_cells",
+                                          "n_hits", "cigar_bytes", "window_bytes", "n_float")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libbwtgpu.so is not built (%s missing): run __graft_entry__.build(); "
+                          "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the header and the library ever diverge
+        getattr(lib, name).restype = C.c_int
+    lib.bwt_last_error.restype = C.c_char_p
+    lib.bwt_index_close.restype = None
+    lib.bwt_batch_destroy.restype = None
+    lib.bwt_constants.restype = None
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise BwtError(rc, load().bwt_last_error().decode("utf8", "replace"))
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def constants():
+    c = Constants()
+    load().bwt_constants(C.byref(c))
+    return c
+
+
+def pack_reads(reads):
+    """list of bytes -> (u8 array, u64 offsets[n+1])"""
+    off = np.zeros(len(reads) + 1, np.uint64)
+    if reads:
+        off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(reads), np.uint8) if reads else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(bases), off
+
+
+class Index:
+    """An index resident in HBM: rank-sampled BWT blocks + SA + Ref1."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def open(cls, fm_path, ref_path, device=0):
+        h = C.c_void_p()
+        _chk(load().bwt_index_open(os.fsencode(fm_path), os.fsencode(ref_path), int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, L, SA, pointers, shift, ref, device=0):
+        L = np.ascontiguousarray(L, np.uint8)
+        SA = np.ascontiguousarray(SA, np.uint32)
+        ptr = (C.c_uint32 * 4)(*[int(x) for x in pointers])
+        if not isinstance(ref, np.ndarray):
+            ref = np.frombuffer(bytes(ref), np.uint8)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        h = C.c_void_p()
+        _chk(load().bwt_index_from_arrays(_p(L), _p(SA), C.c_uint32(len(L)), ptr, C.c_int32(int(shift)), _p(ref),
+                                          C.c_uint64(len(ref)), int(device), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            load().bwt_index_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def meta(self):
+        out = (C.c_uint32 * 5)()
+        _chk(load().bwt_index_meta(self.h, out))
+        pc, pg, pt, last, shift = [int(x) for x in out]
+        return (pc, pg, pt, last), C.c_int32(shift).value
+
+    def device_bytes(self):
+        out = (C.c_uint64 * 3)()
+        _chk(load().bwt_index_device_bytes(self.h, out))
+        return dict(rank_blocks=int(out[0]), sa=int(out[1]), ref1=int(out[2]))
+
+    def ref1(self, off, length):
+        out = np.empty(length, np.uint8)
+        _chk(load().bwt_ref1_read(self.h, C.c_uint64(off), C.c_uint64(length), _p(out)))
+        return out.tobytes()
+
+    # ---- host-buffer entry points -------------------------------------------------------------
+    def find_seeds_batch(self, bases, off):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        status = np.empty(n, np.int32); sp = np.empty(n, np.uint32); ep = np.empty(n, np.uint32)
+        nm = np.empty(n, np.uint32); soff = np.empty(n + 1, np.uint64)
+        need = C.c_uint64(0)
+        seeds = np.empty(0, np.int64)
+        rc = load().bwt_find_seeds_batch(self.h, _p(bases), _p(off), C.c_uint32(n), _p(status), _p(sp), _p(ep), _p(nm),
+                                         _p(soff), _p(seeds), C.c_uint64(0), C.byref(need))
+        if rc == ENOSPC:
+            seeds = np.empty(need.value, np.int64)
+            rc = load().bwt_find_seeds_batch(self.h, _p(bases), _p(off), C.c_uint32(n), _p(status), _p(sp), _p(ep),
+                                             _p(nm), _p(soff), _p(seeds), C.c_uint64(len(seeds)), C.byref(need))
+        _chk(rc)
+        return dict(status=status, sp=sp, ep=ep, nmatch=nm, seed_off=soff, seeds=seeds)
+
+    def sga_batch(self, bases, off):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        coff = np.empty(n + 1, np.uint64); rs = np.empty(n, np.int32)
+        need = C.c_uint64(0)
+        S = np.empty(0, np.int64); D = np.empty(0, np.int32)
+        rc = load().bwt_sga_batch(self.h, _p(bases), _p(off), C.c_uint32(n), _p(coff), _p(S), _p(D), C.c_uint64(0),
+                                  C.byref(need), _p(rs))
+        if rc == ENOSPC:
+            S = np.empty(need.value, np.int64); D = np.empty(need.value, np.int32)
+            rc = load().bwt_sga_batch(self.h, _p(bases), _p(off), C.c_uint32(n), _p(coff), _p(S), _p(D),
+                                      C.c_uint64(len(S)), C.byref(need), _p(rs))
+        _chk(rc)
+        return dict(clus_off=coff, S=S, D=D, read_status=rs)
+
+    def align_batch(self, bases, off):
+        """bwt_align_batch through the two-call pattern."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        need = (C.c_uint64 * 2)()
+        rs = np.empty(n, np.int32); hoff = np.empty(n + 1, np.uint64)
+
+        def call(nh, cb):
+            score = np.empty(nh, np.int32); pos = np.empty(nh, np.int64); woff = np.empty(nh, np.int64)
+            wlen = np.empty(nh, np.int32); coff = np.empty(nh + 1, np.uint64); cig = np.empty(cb, np.uint8)
+            rc = load().bwt_align_batch(self.h, _p(bases), _p(off), C.c_uint32(n), _p(rs), _p(hoff), _p(score), _p(pos),
+                                        _p(woff), _p(wlen), _p(coff), _p(cig), C.c_uint64(nh), C.c_uint64(cb), need)
+            return rc, dict(read_status=rs, hit_off=hoff, score=score, pos=pos, win_off=woff, win_len=wlen,
+                            cig_off=coff, cigar=cig.tobytes())
+        rc, out = call(0, 0)
+        if rc == ENOSPC:
+            rc, out = call(int(need[0]), int(need[1]))
+        _chk(rc)
+        return out
+
+
+def sw_batch(q, qoff, r, roff, device=0):
+    q = np.ascontiguousarray(q, np.uint8); r = np.ascontiguousarray(r, np.uint8)
+    qoff = np.ascontiguousarray(qoff, np.uint64); roff = np.ascontiguousarray(roff, np.uint64)
+    n = len(qoff) - 1
+    status = np.empty(n, np.int32); score = np.empty(n, np.int32); coff = np.empty(n + 1, np.uint64)
+    need = C.c_uint64(0)
+    cig = np.empty(0, np.uint8)
+    rc = load().bwt_sw_batch(int(device), _p(q), _p(qoff), _p(r), _p(roff), C.c_uint32(n), _p(status), _p(score),
+                             _p(coff), _p(cig), C.c_uint64(0), C.byref(need))
+    if rc == ENOSPC:
+        cig = np.empty(need.value, np.uint8)
+        rc = load().bwt_sw_batch(int(device), _p(q), _p(qoff), _p(r), _p(roff), C.c_uint32(n), _p(status), _p(score),
+                                 _p(coff), _p(cig), C.c_uint64(len(cig)), C.byref(need))
+    _chk(rc)
+    return dict(status=status, score=score, cig_off=coff, cigar=cig.tobytes())
+
+
+class Batch:
+    """Resident batch: reads, intermediates and hits stay in HBM between calls."""
+
+    def __init__(self, index):
+        self.index = index
+        self.h = C.c_void_p()
+        _chk(load().bwt_batch_create(index.h, C.byref(self.h)))
+        self.n = 0
+
+    def destroy(self):
+        if self.h:
+            load().bwt_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def set_reads(self, bases, off):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        self.n = len(off) - 1
+        _chk(load().bwt_batch_set_reads(self.h, _p(bases), _p(off), C.c_uint32(self.n)))
+
+    def run(self, stages):
+        c = BatchCounts()
+        _chk(load().bwt_batch_run(self.h, int(stages), C.byref(c)))
+        return c.as_dict()
+
+    def profile(self, enable=True):
+        _chk(load().bwt_batch_profile(self.h, 1 if enable else 0))
+
+    def kernel_times(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * 64)(); ln = (C.c_uint64 * 64)()
+        k = _chk(load().bwt_batch_kernel_times(self.h, names, 4096, ms, ln, 64))
+        parts = names.raw.split(b"\0")[:k]
+        return {parts[i].decode(): dict(ms=float(ms[i]), launches=int(ln[i])) for i in range(k)}
+
+    def hits_to_device(self, dev_ptr, cap_hits):
+        _chk(load().bwt_batch_hits_to_device(self.h, C.c_void_p(dev_ptr), C.c_uint64(cap_hits)))
+
+    def fetch_tasks(self):
+        need = C.c_uint64(0)
+        rc = load().bwt_batch_fetch_tasks(self.h, None, None, None, None, None, None, C.c_uint64(0), C.byref(need))
+        if rc not in (0, ENOSPC):
+            _chk(rc)
+        k = need.value
+        st = np.empty(k, np.int32); sp = np.empty(k, np.uint32); ep = np.empty(k, np.uint32)
+        nm = np.empty(k, np.uint32); tr = np.empty(k, np.uint32); te = np.empty(k, np.uint32)
+        _chk(load().bwt_batch_fetch_tasks(self.h, _p(st), _p(sp), _p(ep), _p(nm), _p(tr), _p(te), C.c_uint64(k),
+                                          C.byref(need)))
+        return dict(status=st, sp=sp, ep=ep, nmatch=nm, read=tr, end=te)
+
+    def fetch_clusters(self):
+        need = C.c_uint64(0)
+        coff = np.empty(self.n + 1, np.uint64); rs = np.empty(self.n, np.int32)
+        rc = load().bwt_batch_fetch_clusters(self.h, _p(coff), None, None, C.c_uint64(0), C.byref(need), _p(rs))
+        if rc not in (0, ENOSPC):
+            _chk(rc)
+        S = np.empty(need.value, np.int64); D = np.empty(need.value, np.int32)
+        _chk(load().bwt_batch_fetch_clusters(self.h, _p(coff), _p(S), _p(D), C.c_uint64(len(S)), C.byref(need), _p(rs)))
+        return dict(clus_off=coff, S=S, D=D, read_status=rs)
+
+    def fetch_hits(self):
+        need = (C.c_uint64 * 2)()
+        rs = np.empty(self.n, np.int32); hoff = np.empty(self.n + 1, np.uint64)
+        rc = load().bwt_batch_fetch_hits(self.h, _p(rs), _p(hoff), None, None, None, None, None, None, C.c_uint64(0),
+                                         C.c_uint64(0), need)
+        if rc not in (0, ENOSPC):
+            _chk(rc)
+        nh, cb = int(need[0]), int(need[1])
+        score = np.empty(nh, np.int32); pos = np.empty(nh, np.int64); woff = np.empty(nh, np.int64)
+        wlen = np.empty(nh, np.int32); coff = np.empty(nh + 1, np.uint64); cig = np.empty(cb, np.uint8)
+        _chk(load().bwt_batch_fetch_hits(self.h, _p(rs), _p(hoff), _p(score), _p(pos), _p(woff), _p(wlen), _p(coff),
+                                         _p(cig), C.c_uint64(nh), C.c_uint64(cb), need))
+        return dict(read_status=rs, hit_off=hoff, score=score, pos=pos, win_off=woff, win_len=wlen, cig_off=coff,
+                    cigar=cig.tobytes())

@@ -1,0 +1,147 @@
+/* libbwtgpu -- C ABI of the MI355X (gfx950) seed-search / clustering / Smith-Waterman path.
+ *
+ * This is the drop-in boundary for the hot path of cloudozer/BWT: every entry point replaces
+ * one Erlang call site of the reference (paths relative to /root/reference) and is what a
+ * NIF / port driver for that call site would bind (c_src/bwt_nif.c).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI; every function returns 0 or a negative BWT_E* code;
+ *     bwt_last_error() returns a thread-local text for the last failure.
+ *   - inputs are caller-owned host buffers, read-only for the duration of the call;
+ *     outputs go into caller-provided host buffers with explicit capacities.  When a capacity
+ *     is too small the call returns BWT_ENOSPC after filling the `needed` counts, and may be
+ *     repeated with larger buffers (two-call pattern: pass capacity 0 first to size).
+ *   - reads are concatenated ASCII bytes; `off` has n+1 entries, read i = bases[off[i] .. off[i+1]).
+ *   - there is NO CPU fallback: every *_batch function runs HIP kernels on `device`.
+ */
+#ifndef BWT_GPU_H
+#define BWT_GPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWT_OK 0
+#define BWT_EINVAL (-22)   /* bad argument */
+#define BWT_ENOMEM (-12)   /* host or device allocation failed */
+#define BWT_ENOSPC (-28)   /* an output capacity is too small; see `needed` */
+#define BWT_EIO (-5)       /* file could not be read */
+#define BWT_EFORMAT (-74)  /* .fm is not the term fm_index:make_index/4 writes */
+#define BWT_EHIP (-71)     /* HIP runtime error (text in bwt_last_error) */
+#define BWT_EOVERFLOW (-75)/* a batch produced more than 2^32-1 seeds/candidates: split it */
+
+/* constants of include/bwt.hrl:4-7,14-18 and src/worker_bwt.erl:17, compiled into the kernels;
+ * bwt_constants() lets the Erlang side assert they equal its own macros at load time. */
+typedef struct {
+    int32_t tolerance, min_len, max_range, max_len;       /* 20, 8, 45, 15 */
+    int32_t match, mismatch, gap_penalty, gap_ext_penalty; /* 2, -1, -2, -1 */
+    double unknown;                                        /* 1.6 */
+    int32_t ref_extension_len;                             /* 200 */
+} bwt_constants_t;
+void bwt_constants(bwt_constants_t *out);
+
+const char *bwt_last_error(void);
+
+/* ------------------------------------------------------------------ index (a-11, worker init)
+ * Replaces fm_index:get_index/2 (src/fm_index.erl:154-156) + the .ref load and 200-N halo of
+ * src/worker_bwt.erl:48-55.  Parses the ETF .fm, keeps only L and SA (F and I are redundant,
+ * SURVEY 8a-13; the identity I[r] = C0[L[r]] + occ(L[r],r) - 1 is verified while loading),
+ * packs L into 64-byte rank blocks and uploads everything to `device`. */
+typedef struct bwt_index bwt_index;
+int bwt_index_open(const char *fm_path, const char *ref_path, int device, bwt_index **out);
+/* Same, from arrays already in memory (monolithic indexes from bwt_build_index, tests).
+ * L: n_rows bytes, row r (1-based) at L[r-1], '$' exactly once; SA: n_rows u32;
+ * pointers = {Pc,Pg,Pt,Last}; ref: the chunk's .ref bytes (n_rows-1 of them). */
+int bwt_index_from_arrays(const uint8_t *L, const uint32_t *SA, uint32_t n_rows,
+                          const uint32_t pointers[4], int32_t shift,
+                          const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out);
+void bwt_index_close(bwt_index *idx);
+/* out = {Pc, Pg, Pt, Last, Shift}  (proplists pointers / shift of the Meta term) */
+int bwt_index_meta(const bwt_index *idx, uint32_t out[5]);
+/* bytes resident in HBM: {rank blocks, SA, ref1} */
+int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[3]);
+
+/* ------------------------------------------------------------------ a-1..a-3
+ * bwa:find_seeds/6 (src/bwa.erl:12-45, src/fmi.erl:25-39,89-100) on n sub-reads.
+ * status[i]: 0 = seed list, 1 = no_seeds, 2 = too_many_seeds, -1 = the reference would crash
+ * (last base not in ACGTN, src/bwa.erl:15-24) -- the one documented divergence: reported, not raised.
+ * sp/ep/nmatch: final SA range (1-based rows, reference numbering) and matched length N.
+ * seeds[seed_off[i] .. seed_off[i+1]) = SA[Ep]+N, SA[Ep-1]+N, ..., SA[Sp]+N  (the reference's list order). */
+int bwt_find_seeds_batch(bwt_index *idx, const uint8_t *bases, const uint64_t *off, uint32_t n,
+                         int32_t *status, uint32_t *sp, uint32_t *ep, uint32_t *nmatch,
+                         uint64_t *seed_off /* n+1 */, int64_t *seeds, uint64_t seeds_cap,
+                         uint64_t *seeds_needed);
+
+/* ------------------------------------------------------------------ a-4..a-6
+ * sga:sga/6 (src/sga.erl:17-76) on n reads -> CSR of {S,D} clusters in the reference's list
+ * order (descending S).  read_status[i]: 0 ok, -1 reference would crash on this read. */
+int bwt_sga_batch(bwt_index *idx, const uint8_t *bases, const uint64_t *off, uint32_t n,
+                  uint64_t *clus_off /* n+1 */, int64_t *S, int32_t *D, uint64_t cap,
+                  uint64_t *needed, int32_t *read_status);
+
+/* ------------------------------------------------------------------ a-8..a-10
+ * sw:sw/2 (src/sw.erl:47-202) on n (query, reference-window) pairs.
+ * status[i]: 0 = {Score,Cigar}, 1 = no_match.  cigar text (no terminator) is
+ * cigar[cig_off[i] .. cig_off[i+1]).  Needs no index. */
+int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, const uint8_t *r,
+                 const uint64_t *roff, uint32_t n, int32_t *status, int32_t *score,
+                 uint64_t *cig_off /* n+1 */, char *cigar, uint64_t cig_cap, uint64_t *cig_needed);
+
+/* ------------------------------------------------------------------ a-7 (minus the final pick)
+ * The `running` clause of worker_bwt:worker_loop/10 (src/worker_bwt.erl:73-106) for n reads:
+ * sga -> window slice of Ref1 -> sw, returning for every read the `Cigars` list in the
+ * reference's list order (ascending position); the final lists:sort/2 pick (:104) stays with
+ * the caller (OTP decides ties).  read_status[i]:
+ *    0  sga found clusters; hits[hit_off[i]..hit_off[i+1]) may still be empty (=> no_cigar)
+ *    1  sga returned []: the reference emits nothing for this read (src/worker_bwt.erl:77)
+ *   -1  reference would crash: bad last base;  -2  window outside Ref1 (src/worker_bwt.erl:89)
+ * per hit: score, pos (= S - Ref_len + Shift), window offset into Ref1 and length (RefSeq),
+ * cigar text at cigar[cig_off[h] .. cig_off[h+1]).  needed = {hits, cigar bytes}. */
+int bwt_align_batch(bwt_index *idx, const uint8_t *bases, const uint64_t *off, uint32_t n,
+                    int32_t *read_status, uint64_t *hit_off /* n+1 */,
+                    int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len,
+                    uint64_t *cig_off /* hits+1 */, char *cigar,
+                    uint64_t hit_cap, uint64_t cig_cap, uint64_t needed[2]);
+/* Ref1 = 200 x 'N' ++ .ref ++ 200 x 'N' (src/worker_bwt.erl:54-55): copy [off, off+len) to out. */
+int bwt_ref1_read(const bwt_index *idx, uint64_t off, uint64_t len, uint8_t *out);
+
+/* ------------------------------------------------------------------ resident-batch interface
+ * The same pipeline split so that a caller can keep reads and hits in HBM (bench, multi-GPU
+ * gather): upload once, run stages on the index's HIP stream, fetch what is wanted. */
+typedef struct bwt_batch bwt_batch;
+enum { BWT_STAGE_SEARCH = 1, BWT_STAGE_CLUSTER = 2, BWT_STAGE_EXTEND = 4 };
+typedef struct {
+    uint64_t n_reads, n_tasks;       /* sub-reads enumerated by skip_Ns */
+    uint64_t lf_steps;               /* LF steps taken (two rank-block lookups each)        */
+    uint64_t sa_reads;               /* SA entries gathered                                  */
+    uint64_t n_clusters;             /* {S,D} candidates                                     */
+    uint64_t sw_cells;               /* Lq x W summed over candidates                        */
+    uint64_t n_hits, cigar_bytes;    /* alignments kept                                      */
+    uint64_t window_bytes;           /* reference-window bytes read by the extend stage      */
+    uint64_t n_float;                /* candidates that took the fp64 (N / 1.6) path         */
+} bwt_batch_counts;
+int bwt_batch_create(bwt_index *idx, bwt_batch **out);
+void bwt_batch_destroy(bwt_batch *b);
+int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n);
+/* runs the requested stages (a later stage implies the earlier ones) and waits for them */
+int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts);
+/* per-kernel device time of the runs since the last reset, from hipEvents recorded on the
+ * stream the kernels are launched on.  names: NUL-separated list; returns #kernels. */
+int bwt_batch_profile(bwt_batch *b, int enable);
+int bwt_batch_kernel_times(bwt_batch *b, char *names, uint32_t names_cap, double *ms, uint64_t *launches,
+                           uint32_t cap);
+/* device-to-device copy of the compact hit table {read:u32, score:i32, pos:i64} (16 B/hit)
+ * into caller-owned device memory (e.g. a torch tensor used for the RCCL gather) */
+int bwt_batch_hits_to_device(bwt_batch *b, void *dev_dst, uint64_t cap_hits);
+int bwt_batch_fetch_tasks(bwt_batch *b, int32_t *status, uint32_t *sp, uint32_t *ep, uint32_t *nmatch,
+                          uint32_t *task_read, uint32_t *task_end, uint64_t cap, uint64_t *needed);
+int bwt_batch_fetch_clusters(bwt_batch *b, uint64_t *clus_off, int64_t *S, int32_t *D, uint64_t cap,
+                             uint64_t *needed, int32_t *read_status);
+int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, int32_t *score,
+                         int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off,
+                         char *cigar, uint64_t hit_cap, uint64_t cig_cap, uint64_t needed[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
