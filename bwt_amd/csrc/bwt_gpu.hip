@@ -369,6 +369,13 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
     return 0;
 }
 
+// k_search is grid-stride: enough blocks to fill every CU 8 waves deep, no more
+static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n_tasks * 4, 256), (uint64_t)cus * 8));
+}
+
 static int fetch_counters(bwt_batch *b) {
     HIPCHK(hipMemcpyAsync(&b->hctr, b->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -386,7 +393,7 @@ static int stage_search(bwt_batch *b) {
     if (n == 0) return 0;
     KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), n, maxT,
             b->t_def.as<uint32_t>());
-    KLAUNCH(b, "fm_search", k_search, cdiv(T * 4, 256), 256, b->ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T,
+    KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, b->ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T,
             maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
             b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     HIPCHK(hipGetLastError());
@@ -667,7 +674,7 @@ extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const u
     HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
     if (T) {
         HIPCHK(hipMemcpyAsync(b->t_def.p, def.data(), T * 4, hipMemcpyHostToDevice, b->stream));
-        KLAUNCH(b, "fm_search", k_search, cdiv(T * 4, 256), 256, ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T, 1u,
+        KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T, 1u,
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     }

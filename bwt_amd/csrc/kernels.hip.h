@@ -173,42 +173,47 @@ __device__ __forceinline__ uint32_t count64(uint4 w, uint32_t pat, int t) {
     }
     return c;
 }
-// rows (blk*192, blk*192+m] of block blk: number whose L == code.  `$` is stored as code 0 and removed here.
-__device__ __forceinline__ uint32_t occ_block(const DevIndex &ix, uint4 w, int ql, uint32_t blk, uint32_t m,
-                                              uint32_t code, uint32_t pat) {
-    uint32_t part;
-    if (ql == 0) {
-        part = code == 0 ? w.x : code == 1 ? w.y : code == 2 ? w.z : w.w;
-    } else {
-        part = count64(w, pat, (int)m - 64 * (ql - 1));
-    }
-    uint32_t s = quad_sum(part);
-    uint32_t first = blk * BWT_BLOCK_ROWS;
-    if (code == 0 && ix.dollar > first && ix.dollar <= first + m) s -= 1;
-    return s;
+// broadcast lane 0 of each quad (DPP quad_perm [0,0,0,0])
+__device__ __forceinline__ uint32_t quad_bcast0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
 }
 
-// k_search: quad per task.  Closed form of se_down / se_up:
+// k_search: quad per task, grid-stride.  Closed form of se_down / se_up:
 //   found  <=>  occ(c,Ep-1) > occ(c,Sp-1);  Sp' = C0[c] + occ(c,Sp-1);  Ep' = C0[c] + occ(c,Ep) - 1
 // (I is the 0-based LF target but is used as a 1-based row by the reference -- kept as is).
+// occ(c,k) = cnt[k/192][c] + #{c among the first k%192 bases of block k/192}; the `$` row is stored
+// as code 0 and taken out again.  Per LF step a quad issues two 16-byte-per-lane loads (blocks of
+// Sp-1 and Ep-1); lane 0 holds the four counts, lanes 1..3 count matches in 64 bases each, and one
+// DPP quad reduction sums both partial counts and the L[Ep]==c bit at once.
 __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__restrict__ bases,
                                                  const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
                                                  const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                  uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
                                                  uint32_t *__restrict__ t_cnt, Counters *ctr) {
-    const uint64_t gtid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t task = gtid >> 2;
     const int ql = (int)(threadIdx.x & 3);
+    const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
     uint32_t steps = 0, live = 0;
-    if (task < n_tasks) {
+    for (uint64_t task = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; task < n_tasks; task += nquads) {
         const uint32_t def = t_def[task];
         const int e = (int)(def & 0xffffu);
         uint32_t status = TS_NONE, sp = 0, ep = 0, nm = 0;
         if (e > 0) {
-            live = 1;
+            live++;
             const uint32_t r = (uint32_t)(task / maxT);
-            const uint8_t *q = bases + off[r];
-            const uint32_t h = q[e - 1];
+            // the (at most) 15 bases a search consumes, [e-15, e), held as 5 aligned dwords
+            const uint64_t qabs = off[r];
+            int64_t a = (int64_t)qabs + e - 16;
+            if (a < 0) a = 0;
+            a &= ~3ll;
+            const uint32_t *wp = (const uint32_t *)(bases + a);
+            const uint32_t c0w = wp[0], c1w = wp[1], c2w = wp[2], c3w = wp[3], c4w = wp[4];
+            const uint32_t rel = (uint32_t)((int64_t)qabs - a);          // read-relative -> window-relative
+            auto getc = [&](int pos) -> uint32_t {
+                const uint32_t idx = rel + (uint32_t)pos;
+                const uint32_t d = idx < 4 ? c0w : idx < 8 ? c1w : idx < 12 ? c2w : idx < 16 ? c3w : c4w;
+                return (d >> ((idx & 3) * 8)) & 0xffu;
+            };
+            const uint32_t h = getc(e - 1);
             status = TS_SEEDS;
             switch (h) {                                          // bwa.erl:15-24
             case 'A': case 'N': sp = 1; ep = ix.Pc - 1; break;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__re
                 for (;;) {
                     if (n == BWT_MAX_LEN) break;                  // bwa.erl:31-32
                     if (k < 0) break;                             // bwa.erl:44-45
-                    const uint32_t c = q[k];
+                    const uint32_t c = getc(k);
                     if (c == 'N') break;                          // bwa.erl:33-34
                     const int code = base_code(c);
                     if (code < 0) { check = false; break; }       // never equals any L: not_found
@@ -233,13 +238,39 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__re
                     const uint4 w1 = ix.blocks[(uint64_t)b1 * 4 + ql];
                     const uint4 w2 = ix.blocks[(uint64_t)b2 * 4 + ql];
                     const uint32_t m1 = k1 - b1 * BWT_BLOCK_ROWS, m2 = k2 - b2 * BWT_BLOCK_ROWS;
-                    const uint32_t o1 = occ_block(ix, w1, ql, b1, m1, (uint32_t)code, pat);          // occ(c,Sp-1)
-                    const uint32_t o2i = occ_block(ix, w2, ql, b2, m2 + 1, (uint32_t)code, pat);     // occ(c,Ep)
-                    const uint32_t o2 = occ_block(ix, w2, ql, b2, m2, (uint32_t)code, pat);          // occ(c,Ep-1)
+                    uint32_t small = 0, cnt1 = 0, cnt2 = 0;
+                    if (ql == 0) {
+                        cnt1 = code == 0 ? w1.x : code == 1 ? w1.y : code == 2 ? w1.z : w1.w;
+                        cnt2 = code == 0 ? w2.x : code == 1 ? w2.y : code == 2 ? w2.z : w2.w;
+                    } else {
+                        const int lo = 64 * (ql - 1);
+                        const uint32_t p1 = count64(w1, pat, (int)m1 - lo);
+                        const uint32_t p2 = count64(w2, pat, (int)m2 - lo);
+                        // L[Ep] is base m2 of block b2
+                        const int bi = (int)m2 - lo;
+                        uint32_t bit = 0;
+                        if (bi >= 0 && bi < 64) {
+                            const uint32_t wd = bi < 16 ? w2.x : bi < 32 ? w2.y : bi < 48 ? w2.z : w2.w;
+                            bit = (((wd >> (2 * (bi & 15))) & 3u) == (uint32_t)code) ? 1u : 0u;
+                        }
+                        small = p1 | (p2 << 8) | (bit << 16);
+                    }
+                    const uint32_t S = quad_sum(small);
+                    cnt1 = quad_bcast0(cnt1);
+                    cnt2 = quad_bcast0(cnt2);
+                    uint32_t o1 = cnt1 + (S & 0xffu);             // occ(c,Sp-1)
+                    uint32_t o2 = cnt2 + ((S >> 8) & 0xffu);      // occ(c,Ep-1)
+                    uint32_t bit = (S >> 16) & 1u;                // L[Ep] == c
+                    if (code == 0) {                              // take the `$` row out again
+                        const uint32_t f1 = b1 * BWT_BLOCK_ROWS, f2 = b2 * BWT_BLOCK_ROWS;
+                        if (ix.dollar > f1 && ix.dollar <= k1) o1 -= 1;
+                        if (ix.dollar > f2 && ix.dollar <= k2) o2 -= 1;
+                        if (ix.dollar == ep) bit = 0;
+                    }
                     steps++;
                     if (!(o2 > o1)) { check = false; break; }     // se_down: not_found (bwa.erl:38)
                     sp = ix.c0[code] + o1;
-                    ep = ix.c0[code] + o2i - 1;
+                    ep = ix.c0[code] + o2 + bit - 1;              // C0 + occ(c,Ep) - 1
                     n++; k--;
                 }
                 nm = (uint32_t)n;
@@ -253,7 +284,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__re
             t_cnt[task] = status == TS_SEEDS ? ep - sp + 1 : 0;
         }
     }
-    // one atomic per wave for the work counters
+    // one atomic pair per wave (the grid is capped, so a few thousand per launch) for the work counters
     unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), l = wave_sum_u64(ql == 0 ? live : 0);
     if ((threadIdx.x & 63) == 0 && (s | l)) {
         atomicAdd(&ctr->lf_steps, s);
