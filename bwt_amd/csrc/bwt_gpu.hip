@@ -156,6 +156,26 @@ extern "C" int bwt_index_from_arrays(const uint8_t *L, const uint32_t *SA, uint3
     return index_build(fm, ref, ref_len, device, out);
 }
 
+extern "C" int bwt_fm_check(const char *fm_path, uint32_t out[5]) {
+    if (!fm_path || !out) return fail(BWT_EINVAL, "bwt_fm_check: null argument");
+    FmHost fm;
+    std::string err;
+    int rc = fm_read_etf(fm_path, fm, err);
+    if (rc) return fail(rc, err);
+    out[0] = fm.Pc; out[1] = fm.Pg; out[2] = fm.Pt; out[3] = fm.Last; out[4] = (uint32_t)fm.shift;
+    return 0;
+}
+
+extern "C" int bwt_fm_rewrite(const char *in_path, const char *out_path) {
+    if (!in_path || !out_path) return fail(BWT_EINVAL, "bwt_fm_rewrite: null argument");
+    FmHost fm;
+    std::string err;
+    int rc = fm_read_etf(in_path, fm, err);
+    if (rc) return fail(rc, err);
+    if ((rc = fm_write_etf(out_path, fm, err))) return fail(rc, err);
+    return 0;
+}
+
 extern "C" void bwt_index_close(bwt_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);

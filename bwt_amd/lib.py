@@ -15,7 +15,7 @@ EXPORTS = [
     "bwt_index_meta", "bwt_index_device_bytes", "bwt_find_seeds_batch", "bwt_sga_batch", "bwt_sw_batch",
     "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
-    "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits",
+    "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
 ]
 
 
@@ -75,6 +75,17 @@ def constants():
     c = Constants()
     load().bwt_constants(C.byref(c))
     return c
+
+
+def fm_check(fm_path):
+    """Parse a .fm on the host exactly as bwt_index_open does -> ((Pc,Pg,Pt,Last), Shift)."""
+    out = (C.c_uint32 * 5)()
+    _chk(load().bwt_fm_check(os.fsencode(fm_path), out))
+    return tuple(int(x) for x in out[:4]), C.c_int32(int(out[4])).value
+
+
+def fm_rewrite(in_path, out_path):
+    _chk(load().bwt_fm_rewrite(os.fsencode(in_path), os.fsencode(out_path)))
 
 
 def pack_reads(reads):

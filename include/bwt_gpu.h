@@ -61,6 +61,13 @@ int bwt_index_meta(const bwt_index *idx, uint32_t out[5]);
 /* bytes resident in HBM: {rank blocks, SA, ref1} */
 int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[3]);
 
+/* Host-only helpers on the on-disk format (no GPU needed):
+ * bwt_fm_check parses a .fm exactly as bwt_index_open does (all identities verified) and returns
+ * {Pc,Pg,Pt,Last,Shift}; bwt_fm_rewrite parses in_path and serialises it again the way
+ * term_to_binary/1 does (src/fm_index.erl:140) -- byte-identical for files written by OTP 17. */
+int bwt_fm_check(const char *fm_path, uint32_t out[5]);
+int bwt_fm_rewrite(const char *in_path, const char *out_path);
+
 /* ------------------------------------------------------------------ a-1..a-3
  * bwa:find_seeds/6 (src/bwa.erl:12-45, src/fmi.erl:25-39,89-100) on n sub-reads.
  * status[i]: 0 = seed list, 1 = no_seeds, 2 = too_many_seeds, -1 = the reference would crash

@@ -1,0 +1,68 @@
+"""world_size-2 gloo test of the multi-GPU path's host logic (bwt_amd/shard.py): slabs cover the
+read stream exactly once and rank 0 ends up with every hit record in global read order."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bwt_amd import shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.slab(n_total, world, rank)
+    # fake per-rank hits: read i yields (i % 3) hits; score/pos derived from the global id
+    g = torch.Generator().manual_seed(1234)
+    reads, scores, poss = [], [], []
+    for i in range(lo, hi):
+        for k in range(i % 3):
+            reads.append(i - lo); scores.append(100 + (i * 7 + k) % 101); poss.append(i * 1000 - k)
+    rec = shard.pack_records(torch.tensor(reads, dtype=torch.int64), torch.tensor(scores, dtype=torch.int64),
+                             torch.tensor(poss, dtype=torch.int64)) if reads else torch.zeros((0, 2), dtype=torch.int64)
+    rec = shard.globalize(rec, lo)
+    parts = shard.gather_hits(dist, rec, rank, world)
+    if rank == 0:
+        allrec = torch.cat(parts)
+        r, s, p = shard.unpack_records(allrec)
+        q.put((r.tolist(), s.tolist(), p.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slabs_partition():
+    for n in (0, 1, 7, 100, 1_000_003):
+        for w in (1, 2, 3, 8):
+            edges = [shard.slab(n, w, r) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+def test_gather_world2():
+    world, n_total = 2, 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp_r, exp_s, exp_p = [], [], []
+    for i in range(n_total):
+        for k in range(i % 3):
+            exp_r.append(i); exp_s.append(100 + (i * 7 + k) % 101); exp_p.append(i * 1000 - k)
+    assert got == (exp_r, exp_s, exp_p)
