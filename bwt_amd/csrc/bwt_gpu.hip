@@ -1,7 +1,7 @@
 // libbwtgpu: host side of the C ABI declared in include/bwt_gpu.h (HIP runtime only; no torch types).
+#include "common.h"
 #include "kernels.hip.h"
 #include "etf_fm.h"
-#include "../../include/bwt_gpu.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -12,18 +12,7 @@
 
 static thread_local std::string g_err;
 extern "C" const char *bwt_last_error(void) { return g_err.c_str(); }
-
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
-
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess) {                                                                   \
-            char _b[512];                                                                         \
-            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-            return fail(_e == hipErrorOutOfMemory ? BWT_ENOMEM : BWT_EHIP, _b);                   \
-        }                                                                                         \
-    } while (0)
+int bwt_fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 extern "C" void bwt_constants(bwt_constants_t *o) {
     o->tolerance = BWT_TOLERANCE; o->min_len = BWT_MIN_LEN; o->max_range = BWT_MAX_RANGE; o->max_len = BWT_MAX_LEN;
@@ -32,36 +21,6 @@ extern "C" void bwt_constants(bwt_constants_t *o) {
 }
 
 // ------------------------------------------------------------------------------------------------
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            e = hipMalloc(&p, bytes);
-            want = bytes;
-            if (e != hipSuccess) { p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
-        }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() const { return (T *)p; }
-};
-
-struct bwt_index {
-    int device = 0;
-    DevIndex d{};
-    DevBuf blocks, sa, ref1;
-    uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
-    int32_t shift = 0;
-    uint64_t ref1_len = 0;
-    hipStream_t stream = nullptr;
-};
-
 static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
     const uint32_t n = (uint32_t)fm.L.size();
     if (n < 8 || fm.Last != n) return fail(BWT_EINVAL, "index: Last must equal the number of rows");

@@ -1,0 +1,57 @@
+// Shared host-side declarations of libbwtgpu's translation units (bwt_gpu.hip, index_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include "kernels_index.h"
+#include "../../include/bwt_gpu.h"
+
+int bwt_fail(int code, const std::string &msg);     // records the thread-local error text, returns code
+static inline int fail(int code, const std::string &msg) { return bwt_fail(code, msg); }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return fail(_e == hipErrorOutOfMemory ? BWT_ENOMEM : BWT_EHIP, _b);                   \
+        }                                                                                         \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+            if (e != hipSuccess) { p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+        }
+        cap = want;
+        return 0;
+    }
+    int exact(size_t bytes) {           // no slack: for the big index arrays
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct bwt_index {
+    int device = 0;
+    DevIndex d{};
+    DevBuf blocks, sa, ref1;
+    uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
+    int32_t shift = 0;
+    uint64_t ref1_len = 0;
+    hipStream_t stream = nullptr;
+};

@@ -16,6 +16,7 @@ EXPORTS = [
     "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
+    "bwt_build_index", "bwt_index_save",
 ]
 
 
@@ -121,6 +122,22 @@ class Index:
         _chk(load().bwt_index_from_arrays(_p(L), _p(SA), C.c_uint32(len(L)), ptr, C.c_int32(int(shift)), _p(ref),
                                           C.c_uint64(len(ref)), int(device), C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def build(cls, ref, shift=1, rng_state=None, device=0):
+        """bwt_build_index: ref = the chunk's .ref bytes.  rng_state: list of 3 ints (AS183), updated in place."""
+        if not isinstance(ref, np.ndarray):
+            ref = np.frombuffer(bytes(ref), np.uint8)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        st = (C.c_uint32 * 3)(*(rng_state if rng_state is not None else (3172, 9814, 20125)))
+        h = C.c_void_p()
+        _chk(load().bwt_build_index(_p(ref), C.c_uint64(len(ref)), C.c_int32(int(shift)), st, int(device), C.byref(h)))
+        if rng_state is not None:
+            rng_state[:] = [int(x) for x in st]
+        return cls(h)
+
+    def save(self, fm_path, ref_path):
+        _chk(load().bwt_index_save(self.h, os.fsencode(fm_path), os.fsencode(ref_path)))
 
     def close(self):
         if self.h:

@@ -61,6 +61,17 @@ int bwt_index_meta(const bwt_index *idx, uint32_t out[5]);
 /* bytes resident in HBM: {rank blocks, SA, ref1} */
 int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[3]);
 
+/* ------------------------------------------------------------------ a-13 / 8f-1: index construction
+ * Replaces fm_index:make_index/4 (src/fm_index.erl:127-141) = IUPAC map + random:uniform(4) for N
+ * (AS183; rng_state in/out, NULL = the default process seed {3172,9814,20125}) + bwt:fm/1
+ * (src/bwt.erl:84-120, suffix array by src/dsa.erl with '$' smallest) + fmi:get_index_pointers/1.
+ * `ref` is the chunk as it goes into the .ref file (before substitution), `shift` the Meta value.
+ * The suffix array is built on the GPU (prefix doubling + radix sort); the index stays in HBM. */
+int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, uint32_t rng_state[3], int device,
+                    bwt_index **out);
+/* writes <fm_path> (ETF {Meta,FM}, byte-for-byte what term_to_binary/1 gives) and <ref_path> */
+int bwt_index_save(const bwt_index *idx, const char *fm_path, const char *ref_path);
+
 /* Host-only helpers on the on-disk format (no GPU needed):
  * bwt_fm_check parses a .fm exactly as bwt_index_open does (all identities verified) and returns
  * {Pc,Pg,Pt,Last,Shift}; bwt_fm_rewrite parses in_path and serialises it again the way

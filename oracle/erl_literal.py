@@ -541,3 +541,92 @@ def worker_pick(cigars):
     if len(cigars) == 1:
         return cigars[0]
     return lists_sort2(lambda a, b: a[0][0] > b[0][0], cigars)[0]
+
+
+# ---------------------------------------------------------------- offline index construction
+# src/fm_index.erl:93-141, src/bwt.erl:84-120, src/dsa.erl:15-48, src/fmi.erl:43-76
+class AS183:
+    """Erlang `random` (OTP 17 stdlib, not vendored): uniform/0,1 with the default seed."""
+
+    def __init__(self, state=(3172, 9814, 20125)):
+        self.a1, self.a2, self.a3 = state
+
+    def uniform(self, n=None):
+        self.a1 = (self.a1 * 171) % 30269
+        self.a2 = (self.a2 * 172) % 30307
+        self.a3 = (self.a3 * 170) % 30323
+        r = self.a1 / 30269 + self.a2 / 30307 + self.a3 / 30323
+        r = r - math.trunc(r)
+        return r if n is None else math.trunc(r * n) + 1
+
+
+_IUPAC_MAP = {ord("B"): "C", ord("D"): "G", ord("R"): "A", ord("Y"): "C", ord("K"): "T", ord("M"): "A",
+              ord("S"): "C", ord("W"): "A", ord("V"): "A", ord("A"): "A", ord("C"): "C", ord("G"): "G", ord("T"): "T"}
+
+
+def ref_seq_of_chunk(chunk, rng):
+    """fm_index.erl:131-137"""
+    out = bytearray()
+    for c in chunk:
+        if c == ord("N"):
+            out.append(b"ACGT"[rng.uniform(4) - 1])
+        elif c in _IUPAC_MAP:
+            out.append(ord(_IUPAC_MAP[c]))
+        else:
+            raise ErlCrash("error(%r)" % c)
+    return bytes(out)
+
+
+def fm_rows(ref_seq):
+    """bwt:fm(st:append($$, Ref_seq)) -> dict of columns F, L, I, SA (rows in tuple order) + pointers.
+    The suffix order is plain lexicographic with '$' smallest (dsa.erl:32-35: Vx < Vy on bytes,
+    '$' = 36 < 'A'); computed here by numpy prefix doubling, independent of the GPU builder."""
+    import numpy as np
+    t = np.frombuffer(ref_seq + b"$", np.uint8).astype(np.int64)
+    n = len(t)
+    rank = np.unique(t, return_inverse=True)[1].astype(np.int64)
+    h = 1
+    while True:
+        second = np.full(n, -1, np.int64)
+        second[: n - h] = rank[h:]
+        order = np.lexsort((second, rank))
+        key = rank[order] * (n + 1) + (second[order] + 1)
+        newr = np.concatenate([[0], np.cumsum(key[1:] != key[:-1])])
+        rank = np.empty(n, np.int64)
+        rank[order] = newr
+        if newr[-1] == n - 1:
+            break
+        h *= 2
+    sa = order
+    F = t[sa].astype(np.uint8)
+    L = t[sa - 1].astype(np.uint8)                     # SA = 0 -> t[-1] = '$'
+    # I (bwt.erl:105-112, fmi.erl:43-60): the K-th row (0-based) whose F is c is popped by the K-th row whose L is c
+    I = np.empty(n, np.int64)
+    for c in b"$ACGT":
+        I[L == c] = np.nonzero(F == c)[0]
+    cnt = {c: int((F == c).sum()) for c in b"ACGT"}
+    pc = 2 + cnt[ord("A")]; pg = pc + cnt[ord("C")]; pt = pg + cnt[ord("G")]
+    return dict(F=F, L=L, I=I, SA=sa.astype(np.int64), pointers=(pc, pg, pt, n))
+
+
+def ltrim_N(ls):
+    j = k = 0
+    while k < len(ls) and ls[k] in (ord("N"), 10, 13):
+        j += ls[k] == ord("N")
+        k += 1
+    return j, ls[k:]
+
+
+def make_index_chunks(chromo_bytes):
+    """build_fm/4,5 (fm_index.erl:93-124) for the raw bytes of one contig (between two FASTA headers):
+    -> [(J, Meta shift, chunk bytes)]"""
+    _, c1 = ltrim_N(chromo_bytes[::-1])
+    shift, c2 = ltrim_N(c1[::-1])
+    body = bytes(c for c in c2 if c not in (10, 13))
+    nbr = 1 + ((len(body) + 2) >> 24)
+    out = []
+    for j in range(1, nbr + 1):
+        chunk_size = (len(body) + nbr * 2) // nbr
+        start = 1 + (j - 1) * (chunk_size - 2)
+        out.append((j, shift + start, body[start - 1:start - 1 + chunk_size]))
+    return out

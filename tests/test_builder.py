@@ -1,0 +1,95 @@
+"""Index construction: the oracle's numpy suffix sort reproduces the bundled fixture's
+rows (CPU), and the GPU builder + ETF writer reproduce the bundled .fm byte for byte (GPU)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FM_PATH, GOLDEN, REF_PATH
+
+FASTA = os.path.join(GOLDEN, "bwt_files", "test_genome.fasta")
+
+
+def test_oracle_builder_reproduces_fixture(fm_dict, ref_bytes):
+    from oracle import erl_literal as E
+    rows = E.fm_rows(ref_bytes)                       # GL000193.1 holds no N: no random stream involved
+    assert rows["pointers"] == fm_dict["pointers"]
+    for k in ("F", "L", "I", "SA"):
+        assert (rows[k] == fm_dict[k]).all(), k
+
+
+def test_as183_stream():
+    from oracle import erl_literal as E
+    r = E.AS183()
+    # first values of random:uniform() from the default seed {3172,9814,20125} (OTP `random` docs' algorithm)
+    a1 = (3172 * 171) % 30269; a2 = (9814 * 172) % 30307; a3 = (20125 * 170) % 30323
+    v = a1 / 30269 + a2 / 30307 + a3 / 30323
+    assert r.uniform() == v - int(v)
+    assert all(1 <= r.uniform(4) <= 4 for _ in range(100))
+
+
+def test_chunking_rules():
+    from oracle import erl_literal as E
+    # contig "3" of the toy genome: 13 leading N, 15 trailing N
+    raw = b"NNNNNNNNNNNNNAAATACCTACACCACACACCACAGGGCACACACACACACACNNNNNNNNNNNNNNN\n"
+    ch = E.make_index_chunks(raw)
+    assert ch == [(1, 14, b"AAATACCTACACCACACACCACAGGGCACACACACACACAC")]
+    body = b"ACGT" * ((1 << 22) + 10)                 # 2^24 + 40 bases -> 2 chunks, 2-bp overlap
+    ch = E.make_index_chunks(body + b"\n")
+    assert len(ch) == 2
+    (j1, s1, c1), (j2, s2, c2) = ch
+    size = (len(body) + 4) // 2
+    assert (j1, s1, len(c1)) == (1, 1, size) and (j2, s2) == (2, 1 + size - 2)
+    assert c1[-2:] == c2[:2] and len(c1) - 2 + len(c2) == len(body)
+
+
+@pytest.mark.gpu
+def test_gpu_builder_reproduces_bundled_fm(tmp_path, ref_bytes):
+    from bwt_amd import lib
+    ix = lib.Index.build(ref_bytes, shift=1)
+    assert ix.meta() == ((53511, 94127, 134735, 189790), 1)
+    ix.save(str(tmp_path / "x.fm"), str(tmp_path / "x.ref"))
+    ix.close()
+    assert hashlib.sha256(open(tmp_path / "x.fm", "rb").read()).hexdigest() == \
+        "9a403b6340c1229ad33a2b632c541958566c8849a997210c9fc89268207425b9"
+    assert open(tmp_path / "x.ref", "rb").read() == ref_bytes
+
+
+@pytest.mark.gpu
+def test_gpu_make_indices_toy_genome(tmp_path):
+    """fm_index:t/0 builds contigs "2" and "4" of bwt_files/test_genome.fasta (src/fm_index.erl:15-17);
+    here every contig that holds all four bases, against the oracle's restatement (N -> AS183 stream)."""
+    from bwt_amd import fm_index, lib
+    from oracle import erl_literal as E, etf
+    names = ["2", "3", "4"]
+    try:
+        written = fm_index.make_indices(FASTA, names, out_dir=str(tmp_path))
+    finally:
+        fm_index._env.clear()
+    assert [os.path.basename(w) for w in written] == ["2_p1", "3_p1", "4_p1"]
+    rng = E.AS183()
+    raw = {n: r for n, r in fm_index._contigs(FASTA)}
+    for name in names:
+        (j, shift, chunk), = E.make_index_chunks(raw[name])
+        rows = E.fm_rows(E.ref_seq_of_chunk(chunk, rng))
+        d = etf.read_fm(str(tmp_path / (name + "_p1.fm")))
+        assert d["shift"] == shift and d["pointers"] == rows["pointers"]
+        for k in ("F", "L", "I", "SA"):
+            assert (d[k] == rows[k]).all(), (name, k)
+        assert open(tmp_path / (name + "_p1.ref"), "rb").read() == chunk
+
+
+@pytest.mark.gpu
+def test_gpu_built_index_searches_like_loaded_index(ref_bytes, orc_fm):
+    """An index built on the GPU answers exactly like the one parsed from the .fm."""
+    from bwt_amd import lib
+    from conftest import synth_reads
+    from oracle import orc
+    ix = lib.Index.build(ref_bytes, shift=1)
+    reads = synth_reads(ref_bytes, 200, 100, 99)
+    out = ix.sga_batch(*lib.pack_reads(reads))
+    for i, q in enumerate(reads):
+        a, b = int(out["clus_off"][i]), int(out["clus_off"][i + 1])
+        assert list(zip(out["S"][a:b].tolist(), out["D"][a:b].tolist())) == orc.sga(orc_fm, q)
+    ix.close()
