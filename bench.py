@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the FM-index seed search (+ clustering + SW extension) hot path.
+"""bench.py -- aligned reads/s of the FM-index seed search + clustering + SW extension hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload config2|config2-align] [--reads M]
+    python bench.py --gpus N --steps K --warmup W [--workload grch38|chr1|config2|config2-align]
 
 One process per GPU (torch.distributed / RCCL for N > 1; the driver launches the ranks).  A "step"
 is one pass of the hot path over one batch of synthetic reads that is already resident in HBM.
-Rank 0 prints ONE JSON line.  Weak scaling: every GPU gets its own slab of `--reads` reads, the index
-is replicated, and the only collective is the per-step gather of the 16-byte hit records to rank 0.
+Rank 0 prints ONE JSON line.  Weak scaling: every GPU gets its own slab of reads, the index is
+replicated, and the only collective is the per-step gather of the 16-byte hit records to rank 0.
 
 Workloads (BASELINE.json configs):
-  config2        configs[1]: bundled GL000193.1 index, 1 M exact-match 100 bp reads drawn from the
-                 contig (seed 2), FM backward-search stage only (sub-read enumeration + LF steps).
-  config2-align  same reads through the whole path (search + clustering + SW extension + CIGAR).
+  grch38 (default)  configs[3] at N GPUs: whole-GRCh38-SCALE FM index (3.1e9 rows) resident in HBM,
+                    100 M reads / 8 = 12.5 M 100-bp reads per GPU per step with 0/1/2 substitutions
+                    (p = 1/3 each), seed search + clustering + SW extension + CIGAR.  No GRCh38 FASTA
+                    exists offline, so the genome is a seeded i.i.d. ACGT contig (flagged synthetic);
+                    the index is built on the GPU by bwt_build_index at start-up (not timed).
+  chr1              configs[2]: 2.3e8-row index, 10 M reads, same path.
+  config2           configs[1]: bundled GL000193.1 index, 1 M exact reads, FM backward search only.
+  config2-align     the same reads through the whole path.
 """
 import argparse
 import json
@@ -24,52 +29,92 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured streaming
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured streaming copy
+VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lane-ops/ns: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
 
 
-def synth_exact_reads(ref, n, length, seed):
-    """exact `length`-mers of the .ref, uniform start."""
+def log(msg):
+    print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
+def synth_genome(n, seed):
     rng = np.random.default_rng(seed)
-    starts = rng.integers(0, len(ref) - length + 1, size=n, dtype=np.int64)
-    idx = starts[:, None] + np.arange(length, dtype=np.int64)[None, :]
-    bases = np.frombuffer(ref, np.uint8)[idx].reshape(-1)
+    return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)]
+
+
+def synth_reads(ref, n, length, seed, max_subs):
+    """uniform start, exactly k substitutions with k uniform in 0..max_subs (a substituted
+    base always differs from the original).  Generated in slices to bound host memory."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n * length, np.uint8)
+    code = np.zeros(256, np.uint8)
+    code[ord("C")] = 1; code[ord("G")] = 2; code[ord("T")] = 3
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    step = 1 << 20
+    for lo in range(0, n, step):
+        m = min(step, n - lo)
+        starts = rng.integers(0, len(ref) - length + 1, size=m, dtype=np.int64)
+        blk = ref[starts[:, None] + np.arange(length, dtype=np.int64)[None, :]]
+        if max_subs:
+            k = rng.integers(0, max_subs + 1, size=m)
+            for s in range(max_subs):
+                rows = np.nonzero(k > s)[0]
+                cols = rng.integers(0, length, size=len(rows))
+                old = code[blk[rows, cols]]
+                blk[rows, cols] = alpha[(old + rng.integers(1, 4, size=len(rows), dtype=np.uint8)) & 3]
+        out[lo * length:(lo + m) * length] = blk.reshape(-1)
     off = np.arange(0, (n + 1) * length, length, dtype=np.uint64)
-    return np.ascontiguousarray(bases), off
+    return out, off
 
 
-def cpu_baseline(workload, fm_path, ref, bases, off, length):
-    """The oracle's C restatement (literal linear-scan se_down/se_up, full-rectangle SW) timed on this
-    host's cores on a bounded sample of the same reads.  kind = "port": the reference is Erlang and
-    cannot run here."""
-    from oracle import etf, orc, erl_literal as E
-    d = etf.read_fm(fm_path)
-    ofm = orc.OrcFM.from_etf(d)
-    ref1 = E.make_ref1(ref)
+def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0):
+    """The oracle's C restatement (literal linear-scan se_down/se_up over the L and I columns,
+    full-rectangle SW with the per-row abort) timed on this host's cores on a bounded sample of the
+    same reads.  kind = "port": the reference is Erlang and cannot run here.  The index COLUMNS (L, SA)
+    are exported from the GPU-built index; the I column and every step of the timed path are the oracle's."""
+    from oracle import orc, erl_literal as E
+    t0 = time.perf_counter()
+    L, SA = ix.export()
+    ptr, shift = ix.meta()
+    ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+    ref1 = E.make_ref1(ref.tobytes() if isinstance(ref, np.ndarray) else ref)
+    log("cpu baseline: index columns on the host in %.1f s" % (time.perf_counter() - t0))
     cores = os.cpu_count() or 1
-    mode = 1 if workload.endswith("align") else 0
-    n = min(1_000_000, len(off) - 1)
-    b = bases[: n * length]
-    o = off[: n + 1].astype(np.uint32)
-    # bounded sample: repeat the same n reads until ~10 s of wall time have been spent
-    reps, dt, res = 0, 0.0, None
-    while dt < 10.0 and reps < 200:
+    nmax = len(off) - 1
+    n = min(nmax, 20000)
+    reps, dt, done, res = 0, 0.0, 0, None
+    while dt < budget_s and reps < 64:
         t0 = time.perf_counter()
-        res = orc.batch(ofm, ref1, b, o, mode, cores)
-        dt += time.perf_counter() - t0
-        reps += 1
-    return {"value": n * reps / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the bench batch x %d passes, %s, %d threads, %.1f s" %
-                      (n, reps, "sga (search+cluster)" if mode == 0 else "search+cluster+SW", cores, dt),
+        res = orc.batch(ofm, ref1, bases[: n * length], off[: n + 1].astype(np.uint32), mode, cores)
+        d = time.perf_counter() - t0
+        dt += d; done += n; reps += 1
+        if d < budget_s / 8 and n < nmax:            # grow the sample until one pass is a good part of the budget
+            n = min(nmax, n * 4)
+    return {"value": done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the bench batch (%d passes, %d reads in all), %s, %d threads, %.1f s" %
+                      (n, reps, done, "sga (search+cluster)" if mode == 0 else "search+cluster+SW", cores, dt),
             "checksum": int(res[3])}
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(workload)
+        except Exception:
+            return None
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config2-align"])
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="grch38", choices=["grch38", "chr1", "config2", "config2-align"])
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the workload's own)")
+    ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,33 +137,53 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from bwt_amd import lib
-    g = os.path.join(ROOT, "tests", "golden", "fm_indices", "GL000193.1_p1")
-    ref = open(g + ".ref", "rb").read()
-    ix = lib.Index.open(g + ".fm", g + ".ref", local_rank)
+    from bwt_amd import lib, shard
     length = 100
-    bases, off = synth_exact_reads(ref, args.reads, length, seed=2 + rank)
+    wl = args.workload
+    if wl.startswith("config2"):
+        g = os.path.join(ROOT, "tests", "golden", "fm_indices", "GL000193.1_p1")
+        ref = np.frombuffer(open(g + ".ref", "rb").read(), np.uint8)
+        ix = lib.Index.open(g + ".fm", g + ".ref", local_rank)
+        n_reads = args.reads or 1_000_000
+        bases, off = synth_reads(ref, n_reads, length, seed=2 + rank, max_subs=0)
+        stages = lib.STAGE_EXTEND if wl.endswith("align") else lib.STAGE_SEARCH
+        desc = ("BASELINE configs[1]: bundled GL000193.1_p1 index, %d exact-match 100 bp reads per GPU, %s"
+                % (n_reads, "whole path" if stages == lib.STAGE_EXTEND else "FM backward-search stage only"))
+    else:
+        glen = args.genome_len or (3_100_000_000 if wl == "grch38" else 230_000_000)
+        n_reads = args.reads or (12_500_000 if wl == "grch38" else 10_000_000)
+        t0 = time.perf_counter()
+        ref = synth_genome(glen, seed=5 if wl == "grch38" else 3)
+        log("rank %d: synthetic genome of %d bp in %.1f s" % (rank, glen, time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        ix = lib.Index.build(ref, shift=1, device=local_rank)
+        log("rank %d: FM index built on the GPU in %.1f s (%s)" % (rank, time.perf_counter() - t0, ix.device_bytes()))
+        t0 = time.perf_counter()
+        bases, off = synth_reads(ref, n_reads, length, seed=(5 if wl == "grch38" else 4) * 1000 + rank, max_subs=2)
+        log("rank %d: %d reads in %.1f s" % (rank, n_reads, time.perf_counter() - t0))
+        stages = lib.STAGE_EXTEND
+        desc = ("BASELINE configs[%d]: %s synthetic i.i.d. ACGT genome of %d bp (no GRCh38 FASTA offline), FM index "
+                "(%d rows) built on the GPU and resident in HBM, %d reads of 100 bp per GPU per step with 0/1/2 "
+                "substitutions (p=1/3 each), seed search + clustering + SW extension + CIGAR"
+                % (3 if wl == "grch38" else 2, "whole-GRCh38-scale" if wl == "grch38" else "chr1-scale", glen,
+                   glen + 1, n_reads))
+
     batch = lib.Batch(ix)
     batch.set_reads(bases, off)                         # resident in HBM before the timed region
-    stages = lib.STAGE_EXTEND if args.workload.endswith("align") else lib.STAGE_SEARCH
     gather = world > 1 and stages == lib.STAGE_EXTEND
-
+    lo, _ = shard.slab(n_reads * world, world, rank)
     hit_buf = None
 
     def step():
+        nonlocal hit_buf
         c = batch.run(stages)
         if gather:
-            # RCCL hit gather: counts, then max-padded 16-byte records to rank 0
-            nonlocal hit_buf
-            nh = torch.tensor([c["n_hits"]], dtype=torch.int64, device="cuda")
-            allc = [torch.zeros_like(nh) for _ in range(world)]
-            dist.all_gather(allc, nh)
-            mx = int(max(int(x.item()) for x in allc))
-            if hit_buf is None or hit_buf.numel() < mx * 2:
-                hit_buf = torch.zeros(max(mx, 1) * 2, dtype=torch.int64, device="cuda")
-            batch.hits_to_device(hit_buf.data_ptr(), hit_buf.numel() // 2)
-            out = [torch.empty_like(hit_buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(hit_buf, out, dst=0)
+            # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0
+            nh = c["n_hits"]
+            if hit_buf is None or hit_buf.shape[0] < nh:
+                hit_buf = torch.zeros((max(nh, 1) * 5 // 4, 2), dtype=torch.int64, device="cuda")
+            batch.hits_to_device(hit_buf.data_ptr(), hit_buf.shape[0])
+            shard.gather_hits(dist, shard.globalize(hit_buf[:nh], lo), rank, world)
         return c
 
     def sync():
@@ -129,7 +194,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    batch.profile(True)                                 # hipEvents around every kernel, on the library's stream
+    batch.profile(True)                                 # hipEvents around every kernel, on the library's own stream
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -143,37 +208,40 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        total_reads = args.reads * world * args.steps
-        value = total_reads / dt
-        # dominant kernel = fm_search.  Algorithmic bytes per launch (search terms only):
-        #   Lq per read in + 128 B per LF step (two 64-B rank blocks) + 16 B per sub-read result out
-        dom = "sw_extend" if stages == lib.STAGE_EXTEND and kt.get("sw_extend", {}).get("ms", 0) > kt["fm_search"]["ms"] \
-            else "fm_search"
-        fs = kt["fm_search"]
-        bytes_search = counts["n_reads"] * length + 128 * counts["lf_steps"] + 16 * counts["n_tasks"]
-        avg_s = fs["ms"] / fs["launches"] / 1e3
-        roof = {"kernel": "k_search", "bound": "hbm", "achieved": bytes_search / avg_s / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": bytes_search / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": bytes_search, "avg_launch_ms": avg_s * 1e3,
-                "note": "index (63 KB rank blocks) is L2-resident in this config: HBM is not the binding limit"}
+        value = n_reads * world * args.steps / dt
+        per = {k: v["ms"] / v["launches"] for k, v in kt.items()}           # avg ms per launch
+        dom = max(per, key=lambda k: kt[k]["ms"])
+        # k_search: algorithmic bytes per launch (search terms): Lq per read in, 128 B per LF step
+        # (two 64-B rank blocks), 16 B per sub-read result out
+        b_search = counts["n_reads"] * length + 128 * counts["lf_steps"] + 16 * counts["n_tasks"]
+        s_search = per["fm_search"] / 1e3
+        traffic = load_traffic(wl) or {}
+        roof = {"kernel": "k_search", "bound": "hbm", "achieved": b_search / s_search / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": b_search / s_search / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic.get("k_search"), "bytes_per_launch": b_search, "avg_launch_ms": per["fm_search"],
+                "share_of_step": kt["fm_search"]["ms"] / sum(v["ms"] for v in kt.values())}
         line = {
             "metric": "aligned reads/sec (100 bp, GRCh38 FM-index) at 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: GL000193.1_p1 index, %d exact-match 100 bp reads per GPU "
-                                   "(seed 2+rank), %s" % (args.reads, "FM backward-search stage only"
-                                                          if stages == lib.STAGE_SEARCH else
-                                                          "seed search + clustering + SW extension"),
-                       "reads_per_gpu": args.reads, "read_len": length, "index_rows": ix.meta()[0][3],
-                       "parallelism": "reads sharded x%d, index replicated" % world},
+            "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
+                       "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
+                       "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world},
             "roofline": roof,
             "dominant_kernel": dom,
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(kt.items())},
             "counts_per_step": counts,
         }
+        if "sw_extend" in per:
+            # extend stage: integer VALU bound (not HBM, not MFMA): cell updates/s and ~13 VALU lane-ops per cell
+            s_sw = per["sw_extend"] / 1e3
+            line["extend"] = {"kernel": "k_sw<false>", "bound": "valu-int", "cells_per_s": counts["sw_cells"] / s_sw,
+                              "avg_launch_ms": per["sw_extend"], "valu_lane_ops_per_cell": 13,
+                              "frac_of_valu_peak": counts["sw_cells"] * 13 / s_sw / (VALU_PEAK_GOPS * 1e9),
+                              "traffic": traffic.get("k_sw")}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.workload, g + ".fm", ref, bases, off, length)
+            line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1)
         print(json.dumps(line))
     batch.destroy()
     ix.close()

@@ -272,3 +272,20 @@ extern "C" int bwt_index_save(const bwt_index *ix, const char *fm_path, const ch
     if (w != ref.size()) return fail(BWT_EIO, "short write on .ref");
     return 0;
 }
+
+extern "C" int bwt_index_export(const bwt_index *ix, uint8_t *L, uint32_t *SA) {
+    if (!ix || !L || !SA) return fail(BWT_EINVAL, "bwt_index_export: null argument");
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t n = ix->Last;
+    HIPCHK(hipMemcpy(SA, ix->sa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> blk((size_t)ix->d.nblk * 16);
+    HIPCHK(hipMemcpy(blk.data(), ix->blocks.p, blk.size() * 4, hipMemcpyDeviceToHost));
+    static const char tb[4] = {'A', 'C', 'G', 'T'};
+    for (uint32_t r0 = 0; r0 < n; r0++) {
+        const uint32_t *w = &blk[(size_t)(r0 / BWT_BLOCK_ROWS) * 16];
+        const uint32_t i = r0 % BWT_BLOCK_ROWS;
+        L[r0] = (uint8_t)tb[(w[4 + i / 16] >> (2 * (i % 16))) & 3u];
+    }
+    L[ix->d.dollar - 1] = '$';
+    return 0;
+}

@@ -16,7 +16,7 @@ EXPORTS = [
     "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
-    "bwt_build_index", "bwt_index_save",
+    "bwt_build_index", "bwt_index_save", "bwt_index_export",
 ]
 
 
@@ -135,6 +135,13 @@ class Index:
         if rng_state is not None:
             rng_state[:] = [int(x) for x in st]
         return cls(h)
+
+    def export(self):
+        """-> (L u8[n_rows], SA u32[n_rows]) copied back from HBM."""
+        n = self.meta()[0][3]
+        L = np.empty(n, np.uint8); SA = np.empty(n, np.uint32)
+        _chk(load().bwt_index_export(self.h, _p(L), _p(SA)))
+        return L, SA
 
     def save(self, fm_path, ref_path):
         _chk(load().bwt_index_save(self.h, os.fsencode(fm_path), os.fsencode(ref_path)))

@@ -72,6 +72,9 @@ int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, uint32_t rng_
 /* writes <fm_path> (ETF {Meta,FM}, byte-for-byte what term_to_binary/1 gives) and <ref_path> */
 int bwt_index_save(const bwt_index *idx, const char *fm_path, const char *ref_path);
 
+/* copies the L column (n_rows bytes, '$' at its row) and the SA column back to the host */
+int bwt_index_export(const bwt_index *idx, uint8_t *L, uint32_t *SA);
+
 /* Host-only helpers on the on-disk format (no GPU needed):
  * bwt_fm_check parses a .fm exactly as bwt_index_open does (all identities verified) and returns
  * {Pc,Pg,Pt,Last,Shift}; bwt_fm_rewrite parses in_path and serialises it again the way

@@ -393,3 +393,16 @@ int orc_batch(const orc_fm *fm, const uint8_t *ref1, int64_t ref1_len, const uin
     free(th); free(jobs);
     return 0;
 }
+
+/* The I column from L: I[r] = C0[L[r]] + occ(L[r], r) - 1 with C0 = {$:0, A:1, C:Pc-1, G:Pg-1, T:Pt-1}
+ * (bwt.erl:105-112 + fmi.erl:43-60: the K-th row whose L is c pops the K-th 0-based row whose F is c). */
+int orc_make_I(const uint8_t *L, uint32_t n, uint32_t Pc, uint32_t Pg, uint32_t Pt, uint32_t *I) {
+    uint64_t occ[256] = {0}, c0[256] = {0};
+    c0['A'] = 1; c0['C'] = Pc - 1; c0['G'] = Pg - 1; c0['T'] = Pt - 1;
+    for (uint32_t r = 0; r < n; r++) {
+        uint8_t c = L[r];
+        I[r] = (uint32_t)(c0[c] + occ[c]);
+        occ[c]++;
+    }
+    return 0;
+}

@@ -46,6 +46,15 @@ class OrcFM:
                      *self.pointers, self.shift)
 
     @classmethod
+    def from_L_SA(cls, L, SA, pointers, shift):
+        """Index columns exported from anywhere: the I column is derived by the oracle itself."""
+        L = np.ascontiguousarray(L, np.uint8)
+        I = np.empty(len(L), np.uint32)
+        lib().orc_make_I(L.ctypes.data_as(C.c_void_p), C.c_uint32(len(L)), C.c_uint32(pointers[0]),
+                         C.c_uint32(pointers[1]), C.c_uint32(pointers[2]), I.ctypes.data_as(C.c_void_p))
+        return cls(L, I, SA, pointers, shift)
+
+    @classmethod
     def from_etf(cls, d):
         return cls(d["L"], d["I"], d["SA"], d["pointers"], d["shift"])
 
@@ -94,7 +103,7 @@ def align_read(fm, ref1, q, cap=256):
     woff = np.empty(cap, np.int64); wlen = np.empty(cap, np.int32)
     cigcap = 1 << 16
     cig = C.create_string_buffer(cigcap)
-    n = lib().orc_align_read(C.byref(fm.c), ref1, len(ref1), q, len(q),
+    n = lib().orc_align_read(C.byref(fm.c), ref1, C.c_int64(len(ref1)), q, len(q),
                              score.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
                              woff.ctypes.data_as(C.c_void_p), wlen.ctypes.data_as(C.c_void_p),
                              cig, cigcap, cap, None)
@@ -111,7 +120,7 @@ def batch(fm, ref1, bases, off, mode, nthreads):
     -> (reads_with_alignment, clusters_or_candidates, sw_cells, checksum)"""
     bases = np.ascontiguousarray(bases, np.uint8); off = np.ascontiguousarray(off, np.uint32)
     out = np.zeros(4, np.int64)
-    lib().orc_batch(C.byref(fm.c), ref1, len(ref1), bases.ctypes.data_as(C.c_void_p),
-                    off.ctypes.data_as(C.c_void_p), len(off) - 1, mode, nthreads,
+    lib().orc_batch(C.byref(fm.c), ref1, C.c_int64(len(ref1)), bases.ctypes.data_as(C.c_void_p),
+                    off.ctypes.data_as(C.c_void_p), C.c_uint32(len(off) - 1), mode, nthreads,
                     out.ctypes.data_as(C.c_void_p))
     return tuple(int(x) for x in out)
