@@ -133,9 +133,13 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_gather = os.environ.get("BWT_BENCH_FORCE_GATHER") == "1"    # rehearse the N>1 exchange step on one GPU
+    if world > 1 or force_gather:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from bwt_amd import lib, shard
     length = 100
@@ -170,7 +174,7 @@ def main():
 
     batch = lib.Batch(ix)
     batch.set_reads(bases, off)                         # resident in HBM before the timed region
-    gather = world > 1 and stages == lib.STAGE_EXTEND
+    gather = (world > 1 or force_gather) and stages == lib.STAGE_EXTEND
     lo, _ = shard.slab(n_reads * world, world, rank)
     hit_buf = None
 
@@ -183,7 +187,9 @@ def main():
             if hit_buf is None or hit_buf.shape[0] < nh:
                 hit_buf = torch.zeros((max(nh, 1) * 5 // 4, 2), dtype=torch.int64, device="cuda")
             batch.hits_to_device(hit_buf.data_ptr(), hit_buf.shape[0])
-            shard.gather_hits(dist, shard.globalize(hit_buf[:nh], lo), rank, world)
+            parts = shard.gather_hits(dist, shard.globalize(hit_buf[:nh], lo), rank, world)
+            if rank == 0:
+                c["gathered_hits"] = int(sum(p.shape[0] for p in parts))
         return c
 
     def sync():

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -185,7 +186,7 @@ struct bwt_batch {
     DevBuf c_read, c_S, c_D, c_qoff, c_qlen, c_woff, c_wlen, c_status, c_score, c_ciglen, cig, fpq;
     uint32_t cig_stride = 32;
     // sw slabs
-    DevBuf slab_bnd, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp;
+    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, tq;
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig;
@@ -289,7 +290,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -426,45 +427,67 @@ static int stage_cluster(bwt_batch *b) {
 }
 
 // runs the integer kernel over all candidates, then the fp64 kernel over those that need it
+// Extend stage: SW_SCORE over every candidate (boundary row in LDS, no direction matrix), then
+// SW_TRACE over the candidates whose alignment is not the plain diagonal (and those too wide for the
+// LDS pass), then SW_FP over the candidates that met a base outside ACGT.
 static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
                   uint32_t max_lq) {
     const uint64_t nc = b->n_cand;
     int rc;
     if ((rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) ||
-        (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)))
+        (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)) || (rc = b->tq.ensure(nc * 4 + 4)))
         return rc;
     if (nc == 0) return 0;
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, b->device);
-    {
-        if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
-        // per-wave slabs; cap the resident waves so that the slabs stay within ~6 GiB
-        const uint64_t per_wave = (uint64_t)maxW1 * 64 * 4 * (1 + strips);
-        uint64_t waves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * 16);
-        waves = std::max<uint64_t>(1, std::min<uint64_t>(waves, (6ull << 30) / std::max<uint64_t>(per_wave, 1)));
-        const uint32_t blocks = cdiv(waves, 4);
-        waves = (uint64_t)blocks * 4;
-        if ((rc = b->slab_bnd.ensure(waves * maxW1 * 64 * 4)) || (rc = b->slab_dir.ensure(waves * maxW1 * 64 * 4 * strips)))
-            return rc;
-        const uint64_t fwaves = std::max<uint64_t>(4, std::min<uint64_t>(waves, 1024) / 4 * 4);
-        if ((rc = b->slab_bnd_fp.ensure(fwaves * maxW1 * 64 * 4)) || (rc = b->slab_bndv.ensure(fwaves * maxW1 * 64 * 8)) ||
-            (rc = b->slab_dir_fp.ensure(fwaves * maxW1 * 64 * 4 * strips)))
-            return rc;
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 4, b->stream));
-        SwIO io;
-        io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
-        io.c_qoff = b->c_qoff.as<uint64_t>(); io.c_qlen = b->c_qlen.as<uint32_t>();
-        io.c_woff = b->c_woff.as<int64_t>(); io.c_wlen = b->c_wlen.as<uint32_t>();
-        io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
-        io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
-        io.fpq = b->fpq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
-        KLAUNCH(b, "sw_extend", k_sw<false>, blocks, 256, io, (uint32_t)nc, maxW1, strips, b->slab_bnd.as<uint32_t>(),
-                (double *)nullptr, b->slab_dir.as<uint32_t>());
-        KLAUNCH(b, "sw_extend_fp64", k_sw<true>, (uint32_t)(fwaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
-                b->slab_bnd_fp.as<uint32_t>(), b->slab_bndv.as<double>(), b->slab_dir_fp.as<uint32_t>());
-        HIPCHK(hipGetLastError());
+    if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
+    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 8, b->stream));      // fp_count, tq_count
+    SwIO io;
+    io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
+    io.c_qoff = b->c_qoff.as<uint64_t>(); io.c_qlen = b->c_qlen.as<uint32_t>();
+    io.c_woff = b->c_woff.as<int64_t>(); io.c_wlen = b->c_wlen.as<uint32_t>();
+    io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
+    io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
+    io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
+
+    // pass 1: 16-bit packed boundary row in LDS, [j][lane] per wave: 4 waves x maxW1 x 128 B per block
+    const bool fits16 = 4ull * (2ull * max_lq + max_w + 4) < 32000ull;
+    const uint64_t lds_bytes = (uint64_t)maxW1 * 512;
+    static const char *env_lds = getenv("BWT_SW_LDS");          // experiments: 0 forces the HBM boundary slab
+    static const char *env_wpc = getenv("BWT_SW_WAVES_PER_CU");
+    const uint32_t wpc = env_wpc ? (uint32_t)atoi(env_wpc) : 16;
+    if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
+        const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * per_cu);
+        if (lds_bytes > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)k_sw<SW_SCORE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+        ProfScope ps(b, "sw_extend");
+        hipLaunchKernelGGL((k_sw<SW_SCORE, true>), dim3(blocks), dim3(256), (size_t)lds_bytes, b->stream, io, (uint32_t)nc,
+                           maxW1, strips, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
+    } else {
+        uint64_t waves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * wpc);
+        waves = std::max<uint64_t>(4, std::min<uint64_t>(waves, (4ull << 30) / ((uint64_t)maxW1 * 256)) / 4 * 4);
+        if ((rc = b->slab_bnd.ensure(waves * maxW1 * 64 * 4))) return rc;
+        KLAUNCH(b, "sw_extend", (k_sw<SW_SCORE, false>), (uint32_t)(waves / 4), 256, io, (uint32_t)nc, maxW1, strips,
+                b->slab_bnd.as<uint32_t>(), (double *)nullptr, (uint32_t *)nullptr);
     }
+    // pass 2 / fp64: per-wave HBM slabs (boundary row + 2-bit directions); resident waves capped at ~4 GiB of slab
+    const uint64_t per_wave = (uint64_t)maxW1 * 64 * 4 * (1 + strips);
+    uint64_t twaves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * 8);
+    twaves = std::max<uint64_t>(4, std::min<uint64_t>(twaves, (4ull << 30) / std::max<uint64_t>(per_wave, 1)) / 4 * 4);
+    if ((rc = b->slab_bnd_t.ensure(twaves * maxW1 * 64 * 4)) || (rc = b->slab_dir.ensure(twaves * maxW1 * 64 * 4 * strips)))
+        return rc;
+    KLAUNCH(b, "sw_trace", (k_sw<SW_TRACE, false>), (uint32_t)(twaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
+            b->slab_bnd_t.as<uint32_t>(), (double *)nullptr, b->slab_dir.as<uint32_t>());
+    const uint64_t fwaves = std::max<uint64_t>(4, std::min<uint64_t>(twaves, 1024) / 4 * 4);
+    if ((rc = b->slab_bnd_fp.ensure(fwaves * maxW1 * 64 * 4)) || (rc = b->slab_bndv.ensure(fwaves * maxW1 * 64 * 8)) ||
+        (rc = b->slab_dir_fp.ensure(fwaves * maxW1 * 64 * 4 * strips)))
+        return rc;
+    KLAUNCH(b, "sw_extend_fp64", (k_sw<SW_FP, false>), (uint32_t)(fwaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
+            b->slab_bnd_fp.as<uint32_t>(), b->slab_bndv.as<double>(), b->slab_dir_fp.as<uint32_t>());
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -541,7 +564,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
         counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
-        counts->n_float = b->hctr.fp_count;
+        counts->n_float = b->hctr.fp_count; counts->n_traced = b->hctr.tq_count;
     }
     return 0;
 }

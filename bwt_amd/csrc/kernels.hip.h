@@ -6,7 +6,7 @@
 //   k_seed_list       fmi:get_seed_ends/4,5                                   src/fmi.erl:89-100
 //   k_cluster_*       sga:add_seeds/3 + sga:get_similar/2,7                   src/sga.erl:37-64
 //   k_candidates      window slice of worker_loop(running,..)                 src/worker_bwt.erl:86-90
-//   k_sw<FP>          sw:sw/3, build_tab, add_row2tab, sigma, get_CIGAR       src/sw.erl:47-202
+//   k_sw<MODE,LDSB>   sw:sw/3, build_tab, add_row2tab, sigma, get_CIGAR       src/sw.erl:47-202
 //   k_hits_*          the Cigars fold (order, Pos) of worker_loop             src/worker_bwt.erl:84-97
 #pragma once
 #include <hip/hip_runtime.h>
@@ -493,9 +493,9 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
 
 // ------------------------------------------------------------------------------------------------
 // Smith-Waterman (semi-global, direction-dependent gap cost) -- one LANE per alignment.
-// The query is cut into strips of SW_R rows held in registers; a strip sweeps all W columns;
-// the row between strips lives in a per-wave slab [j][lane]; 2-bit directions go to a per-wave
-// slab [strip][j][lane] (one dword per column per strip) for the traceback.
+// The query is cut into strips of SW_R rows held in registers; a strip sweeps all W columns; the
+// row between two strips is kept per wave as [j][lane] -- in LDS (16-bit packed cells) for the
+// common window widths, in an HBM slab otherwise.
 //
 // Cell (src/sw.erl:88-98):  {V,Dir} = lists:max([{Vul+sigma,up_left},{Lvalue,left},{Uvalue,up}])
 // Term order makes that a lexicographic max on (V, Dir) with left < up < up_left, so the integer
@@ -503,8 +503,18 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
 // Lvalue = Vleft + (Dleft==left ? -1 : -2), Uvalue = Vup + (Dup==up ? -1 : -2)  (sw.erl:103-107).
 // The per-row abort test (sw.erl:69) is equivalent to the test after the last row because
 // RowMax_{i+1} <= RowMax_i + 2, so only the last row's maximum is tracked.
+//
+// Three instantiations:
+//   SW_SCORE  integer, no direction matrix: finds the score and the start column, then checks whether
+//             the pure diagonal ending there already reaches the score.  If it does, every cell on
+//             that diagonal was stored as up_left (ties prefer up_left), so the reference's traceback
+//             walks it and the CIGAR is "<Lq>M"; the alignment is finished without any HBM traffic
+//             beyond its query and window.  Otherwise the candidate is queued for SW_TRACE.
+//   SW_TRACE  integer, 2-bit directions to a per-wave HBM slab [strip][j][lane], fused traceback.
+//   SW_FP     the same with IEEE doubles (any N / IUPAC: sigma may return 1.6), fused traceback.
 #define SW_R 16
 enum { DIR_LEFT = 0, DIR_UP = 1, DIR_UL = 2, DIR_UNDEF = 3 };
+enum { SW_SCORE = 0, SW_TRACE = 1, SW_FP = 2 };
 
 __device__ __forceinline__ double sigma_gen(uint32_t s, uint32_t r) {   // src/sw.erl:164-202
     if (s == 'N' && r == 'N') return 1.6;
@@ -536,25 +546,36 @@ struct SwIO {
     uint8_t *cig;              // n_cand x cig_stride, text right-aligned in its slot
     uint32_t cig_stride;
     uint32_t *fpq;             // queue of candidates for the fp64 kernel
+    uint32_t *tq;              // queue of candidates that need a real traceback
     Counters *ctr;
 };
 
-template <bool FP>
+// writes "<n><op>" right to left, returns the new write position
+__device__ __forceinline__ void cig_emit(uint8_t *slot, int &p, int &len, uint32_t n, char op) {
+    len++; if (--p >= 0) slot[p] = (uint8_t)op;
+    do { len++; if (--p >= 0) slot[p] = (uint8_t)('0' + n % 10); n /= 10; } while (n);
+}
+
+template <int MODE, bool LDSB>
 __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t maxW1, uint32_t max_strips,
                                             uint32_t *__restrict__ slab_bnd, double *__restrict__ slab_bndv,
                                             uint32_t *__restrict__ slab_dir) {
+    constexpr bool FP = MODE == SW_FP;
+    constexpr bool DIRS = MODE != SW_SCORE;
+    extern __shared__ uint16_t lds_bnd[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    uint32_t *bnd = slab_bnd + (uint64_t)wave * maxW1 * 64 + lane;                 // [j*64]
+    uint16_t *bl = LDSB ? lds_bnd + (uint64_t)(threadIdx.x >> 6) * maxW1 * 64 + lane : nullptr;   // [j*64]
+    uint32_t *bnd = LDSB ? nullptr : slab_bnd + (uint64_t)wave * maxW1 * 64 + lane;                // [j*64]
     double *bndv = FP ? slab_bndv + (uint64_t)wave * maxW1 * 64 + lane : nullptr;
-    uint32_t *dirs = slab_dir + (uint64_t)wave * max_strips * maxW1 * 64 + lane;   // [(s*maxW1+j)*64]
-    const uint32_t n_total = FP ? io.ctr->fp_count : n_items;
+    uint32_t *dirs = DIRS ? slab_dir + (uint64_t)wave * max_strips * maxW1 * 64 + lane : nullptr;  // [(s*maxW1+j)*64]
+    const uint32_t n_total = MODE == SW_FP ? io.ctr->fp_count : MODE == SW_TRACE ? io.ctr->tq_count : n_items;
 
     for (uint32_t g = wave; (uint64_t)g * 64 < n_total; g += nwaves) {
         const uint32_t item = g * 64 + lane;
         if (item >= n_total) continue;
-        const uint32_t c = FP ? io.fpq[item] : item;
+        const uint32_t c = MODE == SW_FP ? io.fpq[item] : MODE == SW_TRACE ? io.tq[item] : item;
         const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
         const int64_t wo = io.c_woff[c];
         if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
@@ -566,8 +587,10 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
         const uint32_t ns = (lq + SW_R - 1) / SW_R;
         bool needfp = false;
 
-        for (uint32_t j = 0; j <= w; j++) { bnd[j * 64] = DIR_UNDEF; if (FP) bndv[j * 64] = 0.0; }   // row 0: {0,undef}
-
+        for (uint32_t j = 0; j <= w; j++) {                 // row 0: {0,undef}
+            if (LDSB) bl[j * 64] = DIR_UNDEF; else bnd[j * 64] = DIR_UNDEF;
+            if (FP) bndv[j * 64] = 0.0;
+        }
         // leftmost maximum of the last row; starts at column 0: V(Lq,0) = -(Lq+1)
         int bestp = -(int)(lq + 1) * 4 + DIR_UP;
         double bestv = -(double)(lq + 1);
@@ -596,7 +619,8 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
             for (uint32_t j = 1; j <= w; j++) {
                 const uint32_t rc = rw[j - 1];
                 if (!FP && s == 0 && !is_acgt(rc)) { needfp = true; break; }
-                int d = dcar, u = bnd[j * 64];
+                int d = dcar, u;
+                if (LDSB) u = (int)(int16_t)bl[j * 64]; else u = (int)bnd[j * 64];
                 double dv = dcarv, uv = 0.0;
                 if (FP) uv = bndv[j * 64];
                 dcar = u; dcarv = uv;
@@ -621,13 +645,13 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
                         const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));       // {-7,-4,-9,-10}
                         int h = cd > cl ? cd : cl;
                         h = h > cu ? h : cu;
-                        dirw |= (uint32_t)(h & 3) << (2 * t);
+                        if (DIRS) dirw |= (uint32_t)(h & 3) << (2 * t);
                         d = old; u = h; H[t] = h;
                     }
                 }
-                bnd[j * 64] = (uint32_t)H[SW_R - 1];
+                if (LDSB) bl[j * 64] = (uint16_t)H[SW_R - 1]; else bnd[j * 64] = (uint32_t)H[SW_R - 1];
                 if (FP) bndv[j * 64] = Hv[SW_R - 1];
-                dirs[((uint64_t)s * maxW1 + j) * 64] = dirw;
+                if (DIRS) dirs[((uint64_t)s * maxW1 + j) * 64] = dirw;
                 if (last) {       // value of query row Lq in this column (register slot tl of the last strip)
                     int lastp = H[0]; double lastv = Hv[0];
 #pragma unroll
@@ -638,8 +662,10 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
             }
         }
         if (!FP && needfp) {
-            io.c_status[c] = CS_NEED_FP;
-            io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
+            if (MODE == SW_SCORE) {
+                io.c_status[c] = CS_NEED_FP;
+                io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
+            }
             continue;
         }
         // sw.erl:69 after the last row: no_match iff RowMax < -2*(Lq div 2) + 2*Lq
@@ -648,29 +674,41 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
         if (FP) { if (bestv < (double)thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; } score = (int)bestv; }
         else { score = bestp >> 2; if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; } }
 
-        // traceback (sw.erl:116-160): from the leftmost maximum of the last row up to row 0
         uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
         int p = (int)io.cig_stride, len = 0;
-        uint32_t i = lq, j = bestj;
-        int runop = -1; uint32_t runlen = 0;
-        for (;;) {
-            int code = -1;
-            if (i > 0) {
-                if (j == 0) code = DIR_UP;
-                else code = (int)((dirs[((uint64_t)((i - 1) / SW_R) * maxW1 + j) * 64] >> (2 * ((i - 1) % SW_R))) & 3u);
+        if (MODE == SW_SCORE) {
+            // does the pure diagonal ending at (Lq, bestj) reach the score?  then the CIGAR is "<Lq>M"
+            bool diag = bestj >= lq;
+            if (diag) {
+                int sum = 0;
+                const uint8_t *rd = rw + (bestj - lq);
+                for (uint32_t i = 0; i < lq; i++) sum += (q[i] == rd[i]) ? 2 : -1;
+                diag = sum == score;
             }
-            if (code == runop) { runlen++; }
-            else {
-                if (runop >= 0) {      // flush "<runlen><op>" written right to left
-                    const char opc = runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D';
-                    len++; if (--p >= 0) slot[p] = (uint8_t)opc;
-                    uint32_t v = runlen;
-                    do { len++; if (--p >= 0) slot[p] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
+            if (!diag) {
+                io.c_status[c] = CS_PENDING;
+                io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c;
+                continue;
+            }
+            cig_emit(slot, p, len, lq, 'M');
+        } else {
+            // traceback (sw.erl:116-160): from the leftmost maximum of the last row up to row 0
+            uint32_t i = lq, j = bestj;
+            int runop = -1; uint32_t runlen = 0;
+            for (;;) {
+                int code = -1;
+                if (i > 0) {
+                    if (j == 0) code = DIR_UP;
+                    else code = (int)((dirs[((uint64_t)((i - 1) / SW_R) * maxW1 + j) * 64] >> (2 * ((i - 1) % SW_R))) & 3u);
                 }
-                runop = code; runlen = 1;
+                if (code == runop) { runlen++; }
+                else {
+                    if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
+                    runop = code; runlen = 1;
+                }
+                if (code < 0) break;
+                if (code == DIR_UL) { i--; j--; } else if (code == DIR_UP) i--; else j--;
             }
-            if (code < 0) break;
-            if (code == DIR_UL) { i--; j--; } else if (code == DIR_UP) i--; else j--;
         }
         io.c_score[c] = score;
         io.c_ciglen[c] = (uint32_t)len;

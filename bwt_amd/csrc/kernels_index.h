@@ -26,6 +26,6 @@ struct DevIndex {
 
 struct Counters {          // device-side work counters (roofline accounting)
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags;
-    unsigned int max_w, max_lq, n_big, fp_count;
+    unsigned int max_w, max_lq, n_big, fp_count, tq_count, pad_;
 };
 

@@ -140,6 +140,7 @@ typedef struct {
     uint64_t n_hits, cigar_bytes;    /* alignments kept                                      */
     uint64_t window_bytes;           /* reference-window bytes read by the extend stage      */
     uint64_t n_float;                /* candidates that took the fp64 (N / 1.6) path         */
+    uint64_t n_traced;               /* candidates that needed a real traceback (not "<Lq>M") */
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);
 void bwt_batch_destroy(bwt_batch *b);

@@ -207,3 +207,22 @@ def test_counters_and_profile(gpu_index, ref_bytes):
     assert c["lf_steps"] > 2000 * 60 and c["n_hits"] > 500
     assert "fm_search" in kt and kt["fm_search"]["launches"] == 1 and kt["fm_search"]["ms"] > 0
     assert "sw_extend" in kt
+
+
+def test_bench_gather_path_single_rank():
+    """bench.py's N>1 exchange step (hits_to_device + RCCL gather of 16-byte records) rehearsed with a
+    world of one on the GPU: every hit of the step arrives on rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, BWT_BENCH_FORCE_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config2-align", "--reads", "20000",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    c = line["counts_per_step"]
+    assert c["gathered_hits"] == c["n_hits"] > 1000
+    assert line["n_gpus"] == 1 and line["roofline"]["frac"] > 0
