@@ -451,22 +451,26 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
 
-    // pass 1: 16-bit packed boundary row in LDS, [j][lane] per wave: 4 waves x maxW1 x 128 B per block
+    // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and
+    // non-diagonal alignments go on to the trace pass.  LDS per wave: planes + (wcap+1) x 128 B.
     const bool fits16 = 4ull * (2ull * max_lq + max_w + 4) < 32000ull;
-    const uint64_t lds_bytes = (uint64_t)maxW1 * 512;
     static const char *env_lds = getenv("BWT_SW_LDS");          // experiments: 0 forces the HBM boundary slab
-    static const char *env_wpc = getenv("BWT_SW_WAVES_PER_CU");
-    const uint32_t wpc = env_wpc ? (uint32_t)atoi(env_wpc) : 16;
+    const uint32_t wcap = std::min<uint32_t>(max_w, 254), lqcap = std::min<uint32_t>(max_lq, 254);
+    const uint32_t pwords = 2 * ((wcap + 31) / 32) + 2 * ((lqcap + 31) / 32);
+    const uint64_t lds_wave = ((uint64_t)pwords * 64 + ((uint64_t)(wcap + 1) * 64 + 1) / 2) * 4;
+    const uint64_t lds_bytes = lds_wave * 4;
     if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
-        const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
+        static const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");
+        uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
+        if (env_bpc) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(env_bpc));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * per_cu);
         if (lds_bytes > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)k_sw<SW_SCORE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)k_sw_score, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         ProfScope ps(b, "sw_extend");
-        hipLaunchKernelGGL((k_sw<SW_SCORE, true>), dim3(blocks), dim3(256), (size_t)lds_bytes, b->stream, io, (uint32_t)nc,
-                           maxW1, strips, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_sw_score, dim3(blocks), dim3(256), (size_t)lds_bytes, b->stream, io, (uint32_t)nc, wcap, lqcap);
     } else {
+        static const char *env_wpc = getenv("BWT_SW_WAVES_PER_CU");
+        const uint32_t wpc = env_wpc ? (uint32_t)atoi(env_wpc) : 8;
         uint64_t waves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * wpc);
         waves = std::max<uint64_t>(4, std::min<uint64_t>(waves, (4ull << 30) / ((uint64_t)maxW1 * 256)) / 4 * 4);
         if ((rc = b->slab_bnd.ensure(waves * maxW1 * 64 * 4))) return rc;

@@ -661,11 +661,9 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
                 }
             }
         }
-        if (!FP && needfp) {
-            if (MODE == SW_SCORE) {
-                io.c_status[c] = CS_NEED_FP;
-                io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
-            }
+        if (!FP && needfp) {          // a base outside ACGT: sigma may return 1.6 -> the fp64 kernel (runs last)
+            io.c_status[c] = CS_NEED_FP;
+            io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
             continue;
         }
         // sw.erl:69 after the last row: no_match iff RowMax < -2*(Lq div 2) + 2*Lq
@@ -710,6 +708,148 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
                 if (code == DIR_UL) { i--; j--; } else if (code == DIR_UP) i--; else j--;
             }
         }
+        io.c_score[c] = score;
+        io.c_ciglen[c] = (uint32_t)len;
+        io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sw_score: the fast path of the extend stage (integer, read and window all ACGT, W <= the LDS cap).
+// Same recurrence as k_sw<SW_SCORE>, but nothing is read from HBM inside the DP:
+//   * prologue, per group of 64 candidates: the wave loads each candidate's window and query with
+//     COALESCED 64-byte reads, turns them into two bit-planes per sequence with __ballot (bit b of the
+//     low/high plane = low/high bit of base b's 2-bit code) and parks the planes in LDS [word][lane];
+//   * strip: 16 query rows = 16 bits of each query plane; column: one bit of each window plane; the
+//     16 row-matches of a column are one xor/or/not (eq mask), each cell takes its bit;
+//   * the row between strips lives in LDS as 16-bit packed cells [j][lane].
+// A candidate that holds a base outside ACGT is handed to the fp64 kernel, one whose alignment is
+// not the plain diagonal (or whose window is wider than the cap) to the trace kernel.
+__global__ __launch_bounds__(256) void k_sw_score(SwIO io, uint32_t n_items, uint32_t wcap, uint32_t lqcap) {
+    extern __shared__ uint32_t lds_sw[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t PW = (wcap + 31) / 32, QW = (lqcap + 31) / 32;          // plane words
+    const uint32_t words_per_wave = (2 * PW + 2 * QW) * 64 + ((wcap + 1) * 64 + 1) / 2;
+    uint32_t *pl = lds_sw + (uint64_t)(threadIdx.x >> 6) * words_per_wave;  // planes [word*64 + lane]
+    uint32_t *const wlo = pl, *const whi = pl + PW * 64, *const qlo = pl + 2 * PW * 64, *const qhi = pl + (2 * PW + QW) * 64;
+    uint16_t *bl = (uint16_t *)(pl + (2 * PW + 2 * QW) * 64) + lane;        // boundary row [j*64]
+
+    for (uint32_t g = wave; (uint64_t)g * 64 < n_items; g += nwaves) {
+        const uint32_t c = g * 64 + lane;
+        uint32_t lq = 0, w = 0;
+        int64_t wo = 0;
+        uint64_t qo = 0;
+        int state = 0;       // 0 = run the DP here, 1 = idle lane, 2 = out of range, 3 = to the trace kernel (too wide)
+        if (c < n_items) {
+            lq = io.c_qlen[c]; w = io.c_wlen[c]; wo = io.c_woff[c]; qo = io.c_qoff[c];
+            if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) state = 2;
+            else if (w > wcap || lq > lqcap) state = 3;
+        } else state = 1;
+        // ---- prologue: bit-planes of every candidate's window and query into LDS
+        unsigned long long badmask = 0;
+        for (int k = 0; k < 64; k++) {
+            const uint32_t kw = __shfl(state == 0 ? w : 0u, k, 64);
+            if (kw == 0) continue;
+            const uint32_t klq = __shfl(lq, k, 64);
+            const uint64_t kro = (uint64_t)__shfl((long long)wo, k, 64), kqo = (uint64_t)__shfl((long long)qo, k, 64);
+            for (uint32_t c0 = 0; c0 < kw; c0 += 64) {
+                const uint32_t idx = c0 + lane;
+                const int code = idx < kw ? base_code(io.rbuf[kro + idx]) : 0;
+                const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2), bad = __ballot(code < 0);
+                if (bad) badmask |= 1ull << k;
+                if (lane == 0) {
+                    const uint32_t wd = 2 * (c0 >> 6);
+                    wlo[wd * 64 + k] = (uint32_t)lo; whi[wd * 64 + k] = (uint32_t)hi;
+                    if (wd + 1 < PW) { wlo[(wd + 1) * 64 + k] = (uint32_t)(lo >> 32); whi[(wd + 1) * 64 + k] = (uint32_t)(hi >> 32); }
+                }
+            }
+            for (uint32_t c0 = 0; c0 < klq; c0 += 64) {
+                const uint32_t idx = c0 + lane;
+                const int code = idx < klq ? base_code(io.qbuf[kqo + idx]) : 0;
+                const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2), bad = __ballot(code < 0);
+                if (bad) badmask |= 1ull << k;
+                if (lane == 0) {
+                    const uint32_t wd = 2 * (c0 >> 6);
+                    qlo[wd * 64 + k] = (uint32_t)lo; qhi[wd * 64 + k] = (uint32_t)hi;
+                    if (wd + 1 < QW) { qlo[(wd + 1) * 64 + k] = (uint32_t)(lo >> 32); qhi[(wd + 1) * 64 + k] = (uint32_t)(hi >> 32); }
+                }
+            }
+        }
+        if (state == 1) continue;
+        if (state == 2) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; continue; }
+        if (state == 3) { io.c_status[c] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c; continue; }
+        if ((badmask >> lane) & 1ull) {
+            io.c_status[c] = CS_NEED_FP;
+            io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
+            continue;
+        }
+        // ---- DP
+        const uint32_t ns = (lq + SW_R - 1) / SW_R;
+        for (uint32_t j = 0; j <= w; j++) bl[j * 64] = DIR_UNDEF;             // row 0: {0,undef}
+        int bestp = -(int)(lq + 1) * 4 + DIR_UP;                                // V(Lq,0) = -(Lq+1)
+        uint32_t bestj = 0;
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t i0 = s * SW_R;
+            const uint32_t q_lo = (qlo[(i0 >> 5) * 64 + lane] >> (i0 & 31)) & 0xffffu;
+            const uint32_t q_hi = (qhi[(i0 >> 5) * 64 + lane] >> (i0 & 31)) & 0xffffu;
+            int H[SW_R];
+#pragma unroll
+            for (int t = 0; t < SW_R; t++) H[t] = -(int)(i0 + t + 2) * 4 + DIR_UP;   // column 0 (sw.erl:73-77)
+            int dcar = s == 0 ? DIR_UNDEF : -(int)(i0 + 1) * 4 + DIR_UP;
+            const int tl = (int)(lq - 1 - i0);
+            const bool last = (s == ns - 1);
+            uint32_t r_lo = 0, r_hi = 0;
+            for (uint32_t j = 1; j <= w; j++) {
+                const uint32_t b = j - 1;
+                if ((b & 31) == 0) { r_lo = wlo[(b >> 5) * 64 + lane]; r_hi = whi[(b >> 5) * 64 + lane]; }
+                const uint32_t rl = 0u - ((r_lo >> (b & 31)) & 1u), rh = 0u - ((r_hi >> (b & 31)) & 1u);
+                const uint32_t eq = ~((q_lo ^ rl) | (q_hi ^ rh));                    // bit t: row t matches this column
+                int d = dcar, u = (int)(int16_t)bl[j * 64];
+                dcar = u;
+#pragma unroll
+                for (int t = 0; t < SW_R; t++) {
+                    const int old = H[t];
+                    const int sig = (int)((eq >> t) & 1u) * 12 - 5;                   // 4*sigma - 1: 7 / -5
+                    const int cd = (d | 3) + sig;
+                    const int cl = old + (int)(int8_t)(0xF5F6F7FCu >> ((old & 3) * 8));
+                    const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));
+                    int h = cd > cl ? cd : cl;
+                    h = h > cu ? h : cu;
+                    d = old; u = h; H[t] = h;
+                }
+                bl[j * 64] = (uint16_t)H[SW_R - 1];
+                if (last) {
+                    int lastp = H[0];
+#pragma unroll
+                    for (int t = 1; t < SW_R; t++) { if (t == tl) lastp = H[t]; }
+                    if ((lastp >> 2) > (bestp >> 2)) { bestp = lastp; bestj = j; }
+                }
+            }
+        }
+        const int thr = -2 * (int)(lq / 2) + 2 * (int)lq;                      // sw.erl:69 after the last row
+        const int score = bestp >> 2;
+        if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; }
+        // pure diagonal ending at (Lq, bestj)?  matches counted on the bit-planes
+        bool diag = bestj >= lq;
+        if (diag) {
+            const uint32_t sh = bestj - lq;           // window base of query base 0
+            int m = 0;
+            for (uint32_t i = 0; i < lq; i += 32) {
+                const uint32_t b = sh + i, wd = b >> 5, bo = b & 31;
+                uint32_t xlo = wlo[wd * 64 + lane] >> bo, xhi = whi[wd * 64 + lane] >> bo;
+                if (bo && wd + 1 < PW) { xlo |= wlo[(wd + 1) * 64 + lane] << (32 - bo); xhi |= whi[(wd + 1) * 64 + lane] << (32 - bo); }
+                uint32_t e = ~((qlo[(i >> 5) * 64 + lane] ^ xlo) | (qhi[(i >> 5) * 64 + lane] ^ xhi));
+                if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                m += __popc(e);
+            }
+            diag = (3 * m - (int)lq) == score;        // 2m - (Lq - m)
+        }
+        if (!diag) { io.c_status[c] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c; continue; }
+        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+        int p = (int)io.cig_stride, len = 0;
+        cig_emit(slot, p, len, lq, 'M');
         io.c_score[c] = score;
         io.c_ciglen[c] = (uint32_t)len;
         io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
