@@ -459,7 +459,20 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     const uint32_t pwords = 2 * ((wcap + 31) / 32) + 2 * ((lqcap + 31) / 32);
     const uint64_t lds_wave = ((uint64_t)pwords * 64 + ((uint64_t)(wcap + 1) * 64 + 1) / 2) * 4;
     const uint64_t lds_bytes = lds_wave * 4;
-    if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
+    static const char *env_pk = getenv("BWT_SW_PK");            // experiments: 0 disables the packed-i16 kernels
+    const bool pk_ok = (max_lq == 100 || max_lq == 150) && !(env_pk && env_pk[0] == '0') && !(env_lds && env_lds[0] == '0');
+    if (pk_ok) {
+        // two alignments per lane, whole query column in registers; LDS holds only the bit-planes
+        const uint32_t qw = (max_lq + 31) / 32;
+        const uint64_t lds_pk = (uint64_t)(2 * ((wcap + 31) / 32) + 2 * qw) * 64 * 4 * 2 * 4;     // 2 sets x 4 waves
+        const uint32_t per_cu = 2;                                                             // VGPR-limited (181 / 247 VGPRs)
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * per_cu);
+        ProfScope ps(b, "sw_extend");
+        if (max_lq == 100)
+            hipLaunchKernelGGL(k_sw_score_pk<100>, dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap);
+        else
+            hipLaunchKernelGGL(k_sw_score_pk<150>, dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap);
+    } else if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
         static const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
         if (env_bpc) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(env_bpc));

@@ -857,6 +857,196 @@ __global__ __launch_bounds__(256) void k_sw_score(SwIO io, uint32_t n_items, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sw_score_pk<LQ>: the extend stage's workhorse for the common read lengths.  The extend stage is
+// integer-VALU bound (SQ counters: VALU active ~95 % of the kernel at 4 cycles per wave64 op), so this
+// version halves the instruction count per cell:
+//   * TWO alignments per lane, cells packed as 2 x i16 (4V+code each) -> v_pk_add/mad/max/min_i16
+//     update both at once (|4V| < 2^15 for every read length this is instantiated for);
+//   * the WHOLE query column (LQ rows) lives in registers: no strips, no boundary row, no padding rows;
+//     the last query row is register LQ-1 at compile time;
+//   * per column the row-match bits of both alignments for 16 rows come from one xor/xor/bitop on
+//     pre-interleaved query bit-planes; per cell the 4*sigma+2 term is (bit * 12 - 2) as one pk_mad.
+// Cell algebra here: h = 8V + code with ONE-HOT codes left 1, up 2, up_left 4 (same order as the term
+// order left < up < up_left, so a packed max still is lists:max); row 0 is stored as (V=0, left), which
+// gives the same Uvalue as `undef` does in the reference (-2).  base = h & ~7:
+//   up_left candidate = base(diag) + 8*sigma + 4                 = base + (bit*24 - 4)
+//   left    candidate = base(left) + 8*(-2 + [code==left]) + 1   = base + 8*(h&1) - 15
+//   up      candidate = base(up)   + 8*(-2 + [code==up])   + 2   = base + 4*(h&2) - 14
+typedef short bwt_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(bwt_s16x2, a) + __builtin_bit_cast(bwt_s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(bwt_s16x2, a), __builtin_bit_cast(bwt_s16x2, b)));
+}
+// a*b+c on both halves in ONE op (hipcc splits power-of-two multipliers into shift + add otherwise)
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int LQ>
+__global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, uint32_t wcap) {
+    constexpr int QW = (LQ + 31) / 32, NG = (LQ + 15) / 16;
+    extern __shared__ uint32_t lds_sw[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t PW = (wcap + 31) / 32;
+    const uint32_t set_words = (2 * PW + 2 * QW) * 64;                      // one set = 64 candidates
+    uint32_t *pl = lds_sw + (uint64_t)(threadIdx.x >> 6) * 2 * set_words;
+
+    for (uint32_t g = wave; (uint64_t)g * 128 < n_items; g += nwaves) {
+        uint32_t cc[2], lq[2], w[2];
+        int64_t wo[2];
+        uint64_t qo[2];
+        int state[2];     // 0 run, 1 idle, 2 out of range, 3 to the trace kernel, 4 to the fp64 kernel
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            cc[h] = g * 128 + h * 64 + lane;
+            lq[h] = 0; w[h] = 0; wo[h] = 0; qo[h] = 0; state[h] = 1;
+            if (cc[h] < n_items) {
+                lq[h] = io.c_qlen[cc[h]]; w[h] = io.c_wlen[cc[h]]; wo[h] = io.c_woff[cc[h]]; qo[h] = io.c_qoff[cc[h]];
+                if (wo[h] < 0 || (uint64_t)wo[h] + w[h] > io.rbuf_len || w[h] == 0 || lq[h] == 0) state[h] = 2;
+                else if (w[h] > wcap || lq[h] != (uint32_t)LQ) state[h] = 3;
+                else state[h] = 0;
+            }
+        }
+        // ---- prologue: coalesced loads -> ballot bit-planes -> LDS, for both sets of 64 candidates
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint32_t *const wlo = pl + h * set_words, *const whi = wlo + PW * 64, *const qlo = wlo + 2 * PW * 64,
+                           *const qhi = wlo + (2 * PW + QW) * 64;
+            unsigned long long badmask = 0;
+            for (int k = 0; k < 64; k++) {
+                const uint32_t kw = __shfl(state[h] == 0 ? w[h] : 0u, k, 64);
+                if (kw == 0) continue;
+                const uint64_t kro = (uint64_t)__shfl((long long)wo[h], k, 64), kqo = (uint64_t)__shfl((long long)qo[h], k, 64);
+                for (uint32_t c0 = 0; c0 < kw; c0 += 64) {
+                    const uint32_t idx = c0 + lane;
+                    const int code = idx < kw ? base_code(io.rbuf[kro + idx]) : 0;
+                    const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2), bad = __ballot(code < 0);
+                    if (bad) badmask |= 1ull << k;
+                    if (lane == 0) {
+                        const uint32_t wd = 2 * (c0 >> 6);
+                        wlo[wd * 64 + k] = (uint32_t)lo; whi[wd * 64 + k] = (uint32_t)hi;
+                        if (wd + 1 < PW) { wlo[(wd + 1) * 64 + k] = (uint32_t)(lo >> 32); whi[(wd + 1) * 64 + k] = (uint32_t)(hi >> 32); }
+                    }
+                }
+#pragma unroll
+                for (uint32_t c0 = 0; c0 < (uint32_t)LQ; c0 += 64) {
+                    const uint32_t idx = c0 + lane;
+                    const int code = idx < (uint32_t)LQ ? base_code(io.qbuf[kqo + idx]) : 0;
+                    const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2), bad = __ballot(code < 0);
+                    if (bad) badmask |= 1ull << k;
+                    if (lane == 0) {
+                        const uint32_t wd = 2 * (c0 >> 6);
+                        qlo[wd * 64 + k] = (uint32_t)lo; qhi[wd * 64 + k] = (uint32_t)hi;
+                        if (wd + 1 < (uint32_t)QW) { qlo[(wd + 1) * 64 + k] = (uint32_t)(lo >> 32); qhi[(wd + 1) * 64 + k] = (uint32_t)(hi >> 32); }
+                    }
+                }
+            }
+            if (state[h] == 0 && ((badmask >> lane) & 1ull)) state[h] = 4;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (state[h] == 2) { io.c_status[cc[h]] = CS_WINDOW_OOR; io.c_ciglen[cc[h]] = 0; }
+            else if (state[h] == 3) { io.c_status[cc[h]] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = cc[h]; }
+            else if (state[h] == 4) { io.c_status[cc[h]] = CS_NEED_FP; io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = cc[h]; }
+        }
+        const bool runA = state[0] == 0, runB = state[1] == 0;
+        if (!runA && !runB) continue;
+        const uint32_t *const wloA = pl, *const whiA = pl + PW * 64, *const qloA = pl + 2 * PW * 64, *const qhiA = pl + (2 * PW + QW) * 64;
+        const uint32_t *const wloB = wloA + set_words, *const whiB = whiA + set_words, *const qloB = qloA + set_words,
+                       *const qhiB = qhiA + set_words;
+        // query planes, rows 16m..16m+15 of A in the low half, of B in the high half
+        uint32_t q2lo[NG], q2hi[NG];
+#pragma unroll
+        for (int m = 0; m < NG; m++) {
+            const int wd = m >> 1, sh = (m & 1) * 16;
+            q2lo[m] = ((qloA[wd * 64 + lane] >> sh) & 0xffffu) | ((qloB[wd * 64 + lane] >> sh) << 16);
+            q2hi[m] = ((qhiA[wd * 64 + lane] >> sh) & 0xffffu) | ((qhiB[wd * 64 + lane] >> sh) << 16);
+        }
+        uint32_t H[LQ];
+#pragma unroll
+        for (int t = 0; t < LQ; t++) {                      // column 0: V(i,0) = -(i+1), dir up (sw.erl:73-77)
+            const uint32_t v = (uint32_t)(-(t + 2) * 8 + 2) & 0xffffu;
+            H[t] = v | (v << 16);
+        }
+        int bestA = -(LQ + 1), bestB = -(LQ + 1);           // V(Lq,0)
+        uint32_t bestjA = 0, bestjB = 0;
+        const uint32_t wA = runA ? w[0] : 0, wB = runB ? w[1] : 0, wmax = wA > wB ? wA : wB;
+        uint32_t rloA = 0, rhiA = 0, rloB = 0, rhiB = 0;
+        const uint32_t K8 = 0x00080008u, K4 = 0x00040004u, K24 = 0x00180018u, KM4 = 0xFFFCFFFCu, KM15 = 0xFFF1FFF1u,
+                       KM14 = 0xFFF2FFF2u;
+        for (uint32_t j = 1; j <= wmax; j++) {
+            const uint32_t b = j - 1;
+            if ((b & 31) == 0) {
+                const uint32_t wd = (b >> 5) * 64 + lane;
+                rloA = wloA[wd]; rhiA = whiA[wd]; rloB = wloB[wd]; rhiB = whiB[wd];
+            }
+            const uint32_t sh = b & 31;
+            const uint32_t rl2 = (0u - ((rloA >> sh) & 1u)) >> 16 | (0u - ((rloB >> sh) & 1u)) << 16;
+            const uint32_t rh2 = (0u - ((rhiA >> sh) & 1u)) >> 16 | (0u - ((rhiB >> sh) & 1u)) << 16;
+            uint32_t e2[NG];
+#pragma unroll
+            for (int m = 0; m < NG; m++) e2[m] = ~((q2lo[m] ^ rl2) | (q2hi[m] ^ rh2));   // bit: row matches this column
+            uint32_t dbase = 0;                              // row 0, column j-1: V = 0
+            uint32_t cu = KM14;                              // row 0 as the up source: 8*(-2) + 2
+#pragma unroll
+            for (int t = 0; t < LQ; t++) {
+                const uint32_t old = H[t];
+                const uint32_t base_o = old & 0xFFF8FFF8u;
+                const uint32_t cl = pk_add(pk_mad(old & 0x00010001u, K8, base_o), KM15);
+                const uint32_t x = (e2[t >> 4] >> (t & 15)) & 0x00010001u;
+                const uint32_t cd = pk_add(dbase, pk_mad(x, K24, KM4));
+                const uint32_t h = pk_max(pk_max(cd, cl), cu);
+                H[t] = h;
+                dbase = base_o;
+                cu = pk_add(pk_mad(h & 0x00020002u, K4, h & 0xFFF8FFF8u), KM14);
+            }
+            const uint32_t lastp = H[LQ - 1];
+            const int vA = (int)(int16_t)(lastp & 0xffffu) >> 3, vB = (int)lastp >> 19;
+            if (j <= wA && vA > bestA) { bestA = vA; bestjA = j; }
+            if (j <= wB && vB > bestB) { bestB = vB; bestjB = j; }
+        }
+        const int thr = -2 * (LQ / 2) + 2 * LQ;             // sw.erl:69 after the last row
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (state[h] != 0) continue;
+            const uint32_t c = cc[h];
+            const int score = h ? bestB : bestA;
+            const uint32_t bestj = h ? bestjB : bestjA;
+            if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; }
+            const uint32_t *wlo = h ? wloB : wloA, *whi = h ? whiB : whiA, *qlo = h ? qloB : qloA, *qhi = h ? qhiB : qhiA;
+            bool diag = bestj >= (uint32_t)LQ;
+            if (diag) {                                      // pure diagonal ending at (Lq, bestj)?
+                const uint32_t shd = bestj - LQ;
+                int m = 0;
+#pragma unroll
+                for (int i = 0; i < LQ; i += 32) {
+                    const uint32_t bb = shd + i, wd = bb >> 5, bo = bb & 31;
+                    uint32_t xlo = wlo[wd * 64 + lane] >> bo, xhi = whi[wd * 64 + lane] >> bo;
+                    if (bo && wd + 1 < PW) { xlo |= wlo[(wd + 1) * 64 + lane] << (32 - bo); xhi |= whi[(wd + 1) * 64 + lane] << (32 - bo); }
+                    uint32_t e = ~((qlo[(i >> 5) * 64 + lane] ^ xlo) | (qhi[(i >> 5) * 64 + lane] ^ xhi));
+                    if (LQ - i < 32) e &= (1u << (LQ - i)) - 1u;
+                    m += __popc(e);
+                }
+                diag = (3 * m - LQ) == score;
+            }
+            if (!diag) { io.c_status[c] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c; continue; }
+            uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+            int p = (int)io.cig_stride, len = 0;
+            cig_emit(slot, p, len, LQ, 'M');
+            io.c_score[c] = score;
+            io.c_ciglen[c] = (uint32_t)len;
+            io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // hits: the reference keeps, per read, the non-no_match results, prepending while it walks the
 // clusters (descending position) => final list order is ascending position (worker_bwt.erl:84-97).
 __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *__restrict__ clus_off,
