@@ -34,13 +34,13 @@ static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, i
     if (device < 0 || device >= ndev) return fail(BWT_EINVAL, "index: no such HIP device");
     HIPCHK(hipSetDevice(device));
 
-    // 64-byte rank blocks: 4 x u32 cumulative counts (rows <= blk*192) + 192 bases x 2 bit
+    // 64-byte rank blocks (layout: kernels_index.h)
     const uint32_t nblk = n / BWT_BLOCK_ROWS + 1;
     std::vector<uint32_t> blk((size_t)nblk * 16, 0);
     uint32_t cnt[4] = {0, 0, 0, 0}, dollar = 0;
     for (uint32_t b = 0; b < nblk; b++) {
         uint32_t *w = &blk[(size_t)b * 16];
-        w[0] = cnt[0]; w[1] = cnt[1]; w[2] = cnt[2]; w[3] = cnt[3];
+        w[0] = cnt[0]; w[4] = cnt[1]; w[8] = cnt[2]; w[12] = cnt[3];
         for (uint32_t i = 0; i < BWT_BLOCK_ROWS; i++) {
             const uint64_t row0 = (uint64_t)b * BWT_BLOCK_ROWS + i;     // 0-based row
             if (row0 >= n) break;
@@ -57,7 +57,7 @@ static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, i
             default: return fail(BWT_EINVAL, "index: L outside $ACGT");
             }
             if (c != '$') cnt[code]++;
-            w[4 + i / 16] |= code << (2 * (i % 16));
+            blk_set_code(w, i, code);
         }
     }
     if (!dollar) return fail(BWT_EINVAL, "index: no $ in L");
@@ -175,7 +175,8 @@ struct bwt_batch {
     // inputs
     uint32_t n = 0, maxT = 0, max_lq = 0;
     uint64_t total_bases = 0;
-    DevBuf bases, off;
+    DevBuf bases, off, rplanes;
+    uint64_t pw = 0;                 // words per read bit-plane
     // tasks
     DevBuf t_def, t_sp, t_ep, t_info, t_cnt;
     // reads
@@ -286,7 +287,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
     (void)hipStreamSynchronize(b->stream);
     prof_collect(b);
     for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
-    DevBuf *all[] = {&b->bases, &b->off, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
+    DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
@@ -356,6 +357,21 @@ static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n_tasks * 4, 256), (uint64_t)cus * 8));
 }
 
+// reads -> bit-planes over the concatenated byte stream (k_read_planes); part of every search pass
+static int read_planes(bwt_batch *b) {
+    b->pw = ((b->total_bases + 63) / 64) * 2 + 8;
+    int rc = b->rplanes.ensure(b->pw * 4 * 4);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(b->rplanes.p, 0, b->pw * 4 * 4, b->stream));
+    if (b->total_bases) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(b->total_bases, 256), (uint64_t)cus * 8));
+        KLAUNCH(b, "read_planes", k_read_planes, grid, 256, b->bases.as<uint8_t>(), b->total_bases, b->rplanes.as<uint32_t>(), b->pw);
+    }
+    return 0;
+}
+
 static int fetch_counters(bwt_batch *b) {
     HIPCHK(hipMemcpyAsync(&b->hctr, b->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -371,9 +387,10 @@ static int stage_search(bwt_batch *b) {
         return rc;
     HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
     if (n == 0) return 0;
-    KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), n, maxT,
+    if ((rc = read_planes(b))) return rc;
+    KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT,
             b->t_def.as<uint32_t>());
-    KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, b->ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T,
+    KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, b->ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T,
             maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
             b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     HIPCHK(hipGetLastError());
@@ -693,7 +710,8 @@ extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const u
     HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
     if (T) {
         HIPCHK(hipMemcpyAsync(b->t_def.p, def.data(), T * 4, hipMemcpyHostToDevice, b->stream));
-        KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, ix->d, b->bases.as<uint8_t>(), b->off.as<uint64_t>(), T, 1u,
+        if ((rc = read_planes(b))) return rc;
+        KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, 1u,
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     }

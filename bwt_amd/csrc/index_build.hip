@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void kb_scatter_rank(const uint32_t *__restric
     if (j < N) rank[sa[j]] = head[j];
 }
 
-// one thread per 64-byte rank block: packs 192 L codes, counts them; the `$` row is reported
+// one thread per 64-byte rank block: bit-planes of 192 L codes + their counts; the `$` row is reported
 __global__ __launch_bounds__(256) void kb_pack_blocks(const uint32_t *__restrict__ sa, const uint8_t *__restrict__ sym,
                                                        uint64_t N, uint32_t nblk, uint32_t *__restrict__ blocks,
                                                        uint32_t *__restrict__ cntA, uint32_t *__restrict__ cntC,
@@ -91,20 +91,28 @@ __global__ __launch_bounds__(256) void kb_pack_blocks(const uint32_t *__restrict
                                                        uint32_t *dollar) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
-    uint32_t w[12] = {0}, c[4] = {0, 0, 0, 0};
-    for (uint32_t i = 0; i < BWT_BLOCK_ROWS; i++) {
-        const uint64_t row0 = (uint64_t)b * BWT_BLOCK_ROWS + i;
-        if (row0 >= N) break;
-        const uint32_t p = sa[row0];
-        uint32_t code = 0;
-        if (p == 0) *dollar = (uint32_t)row0 + 1;            // L = '$' (bwt.erl: the preceding char of suffix 0)
-        else { code = sym[p - 1] - 1u; c[code]++; }
-        w[i / 16] |= code << (2 * (i % 16));
-    }
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     uint32_t *o = blocks + (uint64_t)b * 16;
-#pragma unroll
-    for (int k = 0; k < 12; k++) o[4 + k] = w[k];
-    cntA[b] = c[0]; cntC[b] = c[1]; cntG[b] = c[2]; cntT[b] = c[3];
+    for (uint32_t q = 0; q < 4; q++) {
+        unsigned long long lo = 0, hi = 0;
+        for (uint32_t r = 0; r < 48; r++) {
+            const uint64_t row0 = (uint64_t)b * BWT_BLOCK_ROWS + q * 48 + r;
+            if (row0 >= N) break;
+            const uint32_t p = sa[row0];
+            uint32_t code = 0;
+            if (p == 0) *dollar = (uint32_t)row0 + 1;        // L = '$' (the preceding char of suffix 0)
+            else {
+                code = sym[p - 1] - 1u;
+                c0 += code == 0; c1 += code == 1; c2 += code == 2; c3 += code == 3;
+            }
+            lo |= (unsigned long long)(code & 1u) << r;
+            hi |= (unsigned long long)(code >> 1) << r;
+        }
+        o[4 * q + 1] = (uint32_t)lo;
+        o[4 * q + 2] = (uint32_t)hi;
+        o[4 * q + 3] = (uint32_t)(lo >> 32) | ((uint32_t)(hi >> 32) << 16);
+    }
+    cntA[b] = c0; cntC[b] = c1; cntG[b] = c2; cntT[b] = c3;
 }
 
 __global__ __launch_bounds__(256) void kb_block_counts(uint32_t nblk, uint32_t *__restrict__ blocks,
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void kb_block_counts(uint32_t nblk, uint32_t *
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
     uint32_t *o = blocks + (uint64_t)b * 16;
-    o[0] = sA[b]; o[1] = sC[b]; o[2] = sG[b]; o[3] = sT[b];
+    o[0] = sA[b]; o[4] = sC[b]; o[8] = sG[b]; o[12] = sT[b];
 }
 
 static inline uint32_t cdiv_u(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -256,7 +264,7 @@ extern "C" int bwt_index_save(const bwt_index *ix, const char *fm_path, const ch
     for (uint32_t r0 = 0; r0 < n; r0++) {
         const uint32_t *w = &blk[(size_t)(r0 / BWT_BLOCK_ROWS) * 16];
         const uint32_t i = r0 % BWT_BLOCK_ROWS;
-        fm.L[r0] = (uint8_t)tb[(w[4 + i / 16] >> (2 * (i % 16))) & 3u];
+        fm.L[r0] = (uint8_t)tb[blk_get_code(w, i)];
     }
     fm.L[ix->d.dollar - 1] = '$';
     std::string err;
@@ -284,7 +292,7 @@ extern "C" int bwt_index_export(const bwt_index *ix, uint8_t *L, uint32_t *SA) {
     for (uint32_t r0 = 0; r0 < n; r0++) {
         const uint32_t *w = &blk[(size_t)(r0 / BWT_BLOCK_ROWS) * 16];
         const uint32_t i = r0 % BWT_BLOCK_ROWS;
-        L[r0] = (uint8_t)tb[(w[4 + i / 16] >> (2 * (i % 16))) & 3u];
+        L[r0] = (uint8_t)tb[blk_get_code(w, i)];
     }
     L[ix->d.dollar - 1] = '$';
     return 0;

@@ -26,13 +26,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
     return v;
 }
-// sum over the 4 lanes of a quad (DPP quad_perm, no LDS traffic)
-__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-    return v;
-}
-
 __device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anything else -> -1
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
 }
@@ -101,72 +94,112 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(uint64_t *__restrict__ out
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_read_planes: the concatenated read bases as four bit-planes over the byte stream (bit i of a plane
+// = property of base i): low / high bit of the 2-bit code (A C G T = 0..3), is-N, is-other (neither
+// ACGT nor N).  One coalesced 64-byte read and four ballots per wave iteration; everything downstream
+// (sub-read enumeration, LF steps) works on 16..32-bit windows of these planes instead of bytes.
+#define RP_LO 0
+#define RP_HI 1
+#define RP_N 2
+#define RP_O 3
+__global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
+                                                      uint32_t *__restrict__ planes, uint64_t pw) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t nchunks = (total + 63) >> 6;
+    for (uint64_t ci = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ci < nchunks; ci += nwaves) {
+        const uint64_t pos = ci * 64 + lane;
+        const uint32_t c = pos < total ? bases[pos] : 'A';
+        const int code = base_code(c);
+        const unsigned long long lo = __ballot(code == 1 || code == 3), hi = __ballot(code >= 2),
+                                 nn = __ballot(c == 'N'), oo = __ballot(code < 0 && c != 'N');
+        if (lane < 8) {
+            const unsigned long long m = (lane >> 1) == 0 ? lo : (lane >> 1) == 1 ? hi : (lane >> 1) == 2 ? nn : oo;
+            planes[(uint64_t)(lane >> 1) * pw + 2 * ci + (lane & 1)] = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+        }
+    }
+}
+// 32 bits of a plane starting at absolute bit position pos
+__device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plane, uint64_t pos) {
+    const uint64_t w = pos >> 5;
+    return __builtin_amdgcn_alignbit(plane[w + 1], plane[w], (uint32_t)pos & 31u);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_subreads: one lane per read.  Enumerates the sub-reads sga:sga/9 will search:
 //   {Skip,Qseq1} = skip_Ns(Qseq); search Qseq1; Qseq <- first (len(Qseq1)-8) bases; Shift += 8+Skip.
+// skip_Ns (sga.erl:69-76) scans from the right with J counting since (and including) the last N and
+// stops at J = 8: the sub-read ends at e = len, or right after an N, such that the 7 bases left of its
+// last base hold no N.  On the is-N plane that is: while the 7-bit window [e-8, e-2] is non-zero, move e to
+// just past its highest set bit.
 // task word = end (exclusive, = len(Qseq1)) | (Shift+Skip) << 16 ; 0 = no task.
-__global__ __launch_bounds__(256) void k_subreads(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
-                                                   uint32_t n, uint32_t maxT, uint32_t *__restrict__ t_def) {
+__global__ __launch_bounds__(256) void k_subreads(const uint32_t *__restrict__ planes, uint64_t pw,
+                                                   const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
+                                                   uint32_t *__restrict__ t_def) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const uint8_t *q = bases + off[r];
-    int len = (int)(off[r + 1] - off[r]);
+    const uint32_t *np = planes + RP_N * pw;
+    const uint64_t P = off[r];
+    int len = (int)(off[r + 1] - P);
     uint32_t shift = 0, t = 0;
     uint32_t *td = t_def + (uint64_t)r * maxT;
     for (;;) {
         if (len < BWT_MIN_LEN) break;                       // sga.erl:69
-        int j = 0, skipped = 0, k = len - 1;
-        bool ok = false;
+        int e = len;
+        bool ok = true;
         for (;;) {
-            if (j == BWT_MIN_LEN) { ok = true; break; }     // sga.erl:72-73: tested before the list
-            if (k < 0) break;                               // sga.erl:76
-            if (q[k] == 'N') { skipped += j; j = 1; } else j++;
-            k--;
+            if (e < BWT_MIN_LEN) { ok = false; break; }     // list exhausted before J reached 8 (sga.erl:76)
+            const uint32_t w7 = plane_bits(np, P + (uint64_t)(e - 8)) & 0x7fu;
+            if (!w7) break;
+            e = e - 7 + (31 - __clz((int)w7));              // the sub-read now ends in that N
         }
         if (!ok) break;
-        int l1 = len - skipped;
-        td[t++] = (uint32_t)l1 | ((shift + (uint32_t)skipped) << 16);
-        len = l1 - BWT_MIN_LEN;
+        const int skipped = len - e;
+        td[t++] = (uint32_t)e | ((shift + (uint32_t)skipped) << 16);
+        len = e - BWT_MIN_LEN;
         shift += BWT_MIN_LEN + (uint32_t)skipped;
     }
     for (; t < maxT; t++) td[t] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Occ lookups on the rank-sampled BWT.  A quad (4 lanes) owns one task; lane q of the quad loads
-// bytes [16q,16q+16) of the 64-byte block, so one wave instruction fetches 16 whole blocks with
-// every 64-byte line requested exactly once.
-// count of bases == code among the first t (0..64) of the 64 bases in w
-__device__ __forceinline__ uint32_t count64(uint4 w, uint32_t pat, int t) {
-    uint32_t c = 0;
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t x = ww[k] ^ pat;
-        uint32_t y = ~(x | (x >> 1)) & 0x55555555u;
-        int tk = t - 16 * k;
-        uint32_t m = tk >= 16 ? 0xffffffffu : tk <= 0 ? 0u : ((1u << (2 * tk)) - 1u);
-        c += __popc(y & m);
-    }
-    return c;
+// Occ lookups on the rank-sampled BWT (block layout: kernels_index.h).  A quad (4 lanes) owns one task;
+// lane q of the quad loads quarter q (16 B) of the 64-byte block, so one wave instruction fetches 16
+// whole blocks with every 64-byte line requested exactly once, and all four lanes do the same work.
+// sum over the 4 lanes of a quad (DPP quad_perm, no LDS traffic)
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    return v;
 }
-// broadcast lane 0 of each quad (DPP quad_perm [0,0,0,0])
-__device__ __forceinline__ uint32_t quad_bcast0(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
+// match bits of this quarter's 48 rows against a code given as plane masks (nl = ~(-(c&1)), nh = ~(-(c>>1)))
+__device__ __forceinline__ void quarter_match(uint4 v, uint32_t nl, uint32_t nh, uint32_t n16, uint32_t &y0, uint32_t &y1) {
+    y0 = (v.y ^ nl) & (v.z ^ nh);
+    const uint32_t x = v.w ^ n16;
+    y1 = x & (x >> 16) & 0xffffu;
+}
+// matches among the first t (clamped to 0..48) rows of the quarter
+__device__ __forceinline__ uint32_t quarter_prefix(uint32_t y0, uint32_t y1, int t) {
+    const int tc = t < 0 ? 0 : (t > 48 ? 48 : t);
+    const uint32_t mlo = tc >= 32 ? 0xffffffffu : ((1u << tc) - 1u);
+    const int th = tc > 32 ? tc - 32 : 0;
+    const uint32_t mhi = (1u << th) - 1u;
+    return __popc(y0 & mlo) + __popc(y1 & mhi);
 }
 
 // k_search: quad per task, grid-stride.  Closed form of se_down / se_up:
 //   found  <=>  occ(c,Ep-1) > occ(c,Sp-1);  Sp' = C0[c] + occ(c,Sp-1);  Ep' = C0[c] + occ(c,Ep) - 1
 // (I is the 0-based LF target but is used as a 1-based row by the reference -- kept as is).
-// occ(c,k) = cnt[k/192][c] + #{c among the first k%192 bases of block k/192}; the `$` row is stored
+// occ(c,k) = cnt[k/192][c] + #{c among the first k%192 rows of block k/192}; the `$` row is stored
 // as code 0 and taken out again.  Per LF step a quad issues two 16-byte-per-lane loads (blocks of
-// Sp-1 and Ep-1); lane 0 holds the four counts, lanes 1..3 count matches in 64 bases each, and one
-// DPP quad reduction sums both partial counts and the L[Ep]==c bit at once.
-__global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__restrict__ bases,
+// Sp-1 and Ep-1) and three DPP quad reductions (occ(c,Sp-1), occ(c,Ep-1), the L[Ep]==c bit).
+__global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
                                                  const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
                                                  const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                  uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
                                                  uint32_t *__restrict__ t_cnt, Counters *ctr) {
     const int ql = (int)(threadIdx.x & 3);
+    const int row0 = 48 * ql;                                    // first row of this lane's quarter
     const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
     uint32_t steps = 0, live = 0;
     for (uint64_t task = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; task < n_tasks; task += nquads) {
@@ -176,27 +209,25 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__re
         if (e > 0) {
             live++;
             const uint32_t r = (uint32_t)(task / maxT);
-            // the (at most) 15 bases a search consumes, [e-15, e), held as 5 aligned dwords
-            const uint64_t qabs = off[r];
-            int64_t a = (int64_t)qabs + e - 16;
-            if (a < 0) a = 0;
-            a &= ~3ll;
-            const uint32_t *wp = (const uint32_t *)(bases + a);
-            const uint32_t c0w = wp[0], c1w = wp[1], c2w = wp[2], c3w = wp[3], c4w = wp[4];
-            const uint32_t rel = (uint32_t)((int64_t)qabs - a);          // read-relative -> window-relative
-            auto getc = [&](int pos) -> uint32_t {
-                const uint32_t idx = rel + (uint32_t)pos;
-                const uint32_t d = idx < 4 ? c0w : idx < 8 ? c1w : idx < 12 ? c2w : idx < 16 ? c3w : c4w;
-                return (d >> ((idx & 3) * 8)) & 0xffu;
-            };
-            const uint32_t h = getc(e - 1);
+            // the (at most) 15 bases a search consumes, [e-15, e): bit 15 of each 16-bit plane window = base e-1
+            const uint64_t endp = off[r] + (uint64_t)e;
+            uint32_t lo16, hi16, n16b, o16;
+            if (endp >= 16) {
+                lo16 = plane_bits(planes + RP_LO * pw, endp - 16); hi16 = plane_bits(planes + RP_HI * pw, endp - 16);
+                n16b = plane_bits(planes + RP_N * pw, endp - 16); o16 = plane_bits(planes + RP_O * pw, endp - 16);
+            } else {                                             // only the very first read of a batch
+                const uint32_t sh = 16 - (uint32_t)endp;
+                lo16 = planes[RP_LO * pw] << sh; hi16 = planes[RP_HI * pw] << sh;
+                n16b = planes[RP_N * pw] << sh; o16 = planes[RP_O * pw] << sh;
+            }
             status = TS_SEEDS;
-            switch (h) {                                          // bwa.erl:15-24
-            case 'A': case 'N': sp = 1; ep = ix.Pc - 1; break;
-            case 'C': sp = ix.Pc; ep = ix.Pg - 1; break;
-            case 'G': sp = ix.Pg; ep = ix.Pt - 1; break;
-            case 'T': sp = ix.Pt; ep = ix.Last; break;
-            default: status = TS_CRASH; break;
+            {                                                     // bwa.erl:15-24: range of the last base
+                const uint32_t hc = ((lo16 >> 15) & 1u) | (((hi16 >> 15) & 1u) << 1);
+                if ((o16 >> 15) & 1u) status = TS_CRASH;
+                else if (((n16b >> 15) & 1u) || hc == 0) { sp = 1; ep = ix.Pc - 1; }        // N is searched as A
+                else if (hc == 1) { sp = ix.Pc; ep = ix.Pg - 1; }
+                else if (hc == 2) { sp = ix.Pg; ep = ix.Pt - 1; }
+                else { sp = ix.Pt; ep = ix.Last; }
             }
             if (status != TS_CRASH) {
                 int n = 1, k = e - 2;
@@ -204,39 +235,28 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__re
                 for (;;) {
                     if (n == BWT_MAX_LEN) break;                  // bwa.erl:31-32
                     if (k < 0) break;                             // bwa.erl:44-45
-                    const uint32_t c = getc(k);
-                    if (c == 'N') break;                          // bwa.erl:33-34
-                    const int code = base_code(c);
-                    if (code < 0) { check = false; break; }       // never equals any L: not_found
-                    const uint32_t pat = (uint32_t)code * 0x55555555u;
+                    const uint32_t bi = 15u - (uint32_t)n;        // plane bit of base k
+                    if ((n16b >> bi) & 1u) break;                 // bwa.erl:33-34
+                    if ((o16 >> bi) & 1u) { check = false; break; }   // never equals any L: not_found
+                    const uint32_t cl = (lo16 >> bi) & 1u, ch = (hi16 >> bi) & 1u;
+                    const int code = (int)(cl | (ch << 1));
+                    const uint32_t nl = cl - 1u, nh = ch - 1u;     // ~(-bit): all ones when the wanted bit is 0
+                    const uint32_t n16 = (nl & 0xffffu) | (nh << 16);
                     const uint32_t k1 = sp - 1, k2 = ep - 1;
                     const uint32_t b1 = k1 / BWT_BLOCK_ROWS, b2 = k2 / BWT_BLOCK_ROWS;
-                    const uint4 w1 = ix.blocks[(uint64_t)b1 * 4 + ql];
-                    const uint4 w2 = ix.blocks[(uint64_t)b2 * 4 + ql];
-                    const uint32_t m1 = k1 - b1 * BWT_BLOCK_ROWS, m2 = k2 - b2 * BWT_BLOCK_ROWS;
-                    uint32_t small = 0, cnt1 = 0, cnt2 = 0;
-                    if (ql == 0) {
-                        cnt1 = code == 0 ? w1.x : code == 1 ? w1.y : code == 2 ? w1.z : w1.w;
-                        cnt2 = code == 0 ? w2.x : code == 1 ? w2.y : code == 2 ? w2.z : w2.w;
-                    } else {
-                        const int lo = 64 * (ql - 1);
-                        const uint32_t p1 = count64(w1, pat, (int)m1 - lo);
-                        const uint32_t p2 = count64(w2, pat, (int)m2 - lo);
-                        // L[Ep] is base m2 of block b2
-                        const int bi = (int)m2 - lo;
-                        uint32_t bit = 0;
-                        if (bi >= 0 && bi < 64) {
-                            const uint32_t wd = bi < 16 ? w2.x : bi < 32 ? w2.y : bi < 48 ? w2.z : w2.w;
-                            bit = (((wd >> (2 * (bi & 15))) & 3u) == (uint32_t)code) ? 1u : 0u;
-                        }
-                        small = p1 | (p2 << 8) | (bit << 16);
-                    }
-                    const uint32_t S = quad_sum(small);
-                    cnt1 = quad_bcast0(cnt1);
-                    cnt2 = quad_bcast0(cnt2);
-                    uint32_t o1 = cnt1 + (S & 0xffu);             // occ(c,Sp-1)
-                    uint32_t o2 = cnt2 + ((S >> 8) & 0xffu);      // occ(c,Ep-1)
-                    uint32_t bit = (S >> 16) & 1u;                // L[Ep] == c
+                    const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql];
+                    const uint4 v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+                    const int m1 = (int)(k1 - b1 * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2 * BWT_BLOCK_ROWS);
+                    uint32_t ya0, ya1, yb0, yb1;
+                    quarter_match(v1, nl, nh, n16, ya0, ya1);
+                    quarter_match(v2, nl, nh, n16, yb0, yb1);
+                    const bool mine = ql == code;                 // this lane's count word is the wanted one
+                    uint32_t o1 = quad_sum(quarter_prefix(ya0, ya1, m1 - row0) + (mine ? v1.x : 0u));   // occ(c,Sp-1)
+                    uint32_t o2 = quad_sum(quarter_prefix(yb0, yb1, m2 - row0) + (mine ? v2.x : 0u));   // occ(c,Ep-1)
+                    const int pos = m2 - row0;                    // L[Ep] is row m2 of block b2
+                    uint32_t bit = 0;
+                    if (pos >= 0 && pos < 48) bit = pos < 32 ? (yb0 >> pos) & 1u : (yb1 >> (pos - 32)) & 1u;
+                    bit = quad_sum(bit);                          // L[Ep] == c
                     if (code == 0) {                              // take the `$` row out again
                         const uint32_t f1 = b1 * BWT_BLOCK_ROWS, f2 = b2 * BWT_BLOCK_ROWS;
                         if (ix.dollar > f1 && ix.dollar <= k1) o1 -= 1;
@@ -245,8 +265,10 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint8_t *__re
                     }
                     steps++;
                     if (!(o2 > o1)) { check = false; break; }     // se_down: not_found (bwa.erl:38)
-                    sp = ix.c0[code] + o1;
-                    ep = ix.c0[code] + o2 + bit - 1;              // C0 + occ(c,Ep) - 1
+                    // C0 by selects: indexing the kernel-argument array with a per-lane code sends it through scratch
+                    const uint32_t c0 = code == 0 ? 1u : code == 1 ? ix.Pc - 1 : code == 2 ? ix.Pg - 1 : ix.Pt - 1;
+                    sp = c0 + o1;
+                    ep = c0 + o2 + bit - 1;                       // C0 + occ(c,Ep) - 1
                     n++; k--;
                 }
                 nm = (uint32_t)n;
