@@ -67,7 +67,26 @@ def synth_reads(ref, n, length, seed, max_subs):
     return out, off
 
 
-def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0):
+def parity_sample(batch, ofm, ref1, bases, off, length, n=2000):
+    """Hits of the LAST timed step for the first n reads, compared one by one with the CPU oracle."""
+    from oracle import orc
+    out = batch.fetch_hits()
+    bad = 0
+    for i in range(min(n, len(off) - 1)):
+        q = bases[i * length:(i + 1) * length].tobytes()
+        a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+        got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+                int(out["pos"][h])) for h in range(a, b)]
+        try:
+            exp = orc.align_read(ofm, ref1, q)
+        except RuntimeError:
+            exp = None
+        want = [] if exp is None else [(s, c, p) for (s, c, p, _, _) in exp]
+        bad += got != want
+    return {"reads": min(n, len(off) - 1), "mismatching_reads": bad}
+
+
+def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
     """The oracle's C restatement (literal linear-scan se_down/se_up over the L and I columns,
     full-rectangle SW with the per-row abort) timed on this host's cores on a bounded sample of the
     same reads.  kind = "port": the reference is Erlang and cannot run here.  The index COLUMNS (L, SA)
@@ -90,10 +109,13 @@ def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0):
         dt += d; done += n; reps += 1
         if d < budget_s / 8 and n < nmax:            # grow the sample until one pass is a good part of the budget
             n = min(nmax, n * 4)
-    return {"value": done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the bench batch (%d passes, %d reads in all), %s, %d threads, %.1f s" %
-                      (n, reps, done, "sga (search+cluster)" if mode == 0 else "search+cluster+SW", cores, dt),
-            "checksum": int(res[3])}
+    out = {"value": done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+           "sample": "first %d reads of the bench batch (%d passes, %d reads in all), %s, %d threads, %.1f s" %
+                     (n, reps, done, "sga (search+cluster)" if mode == 0 else "search+cluster+SW", cores, dt),
+           "checksum": int(res[3])}
+    if batch is not None and mode == 1:
+        out["parity_sample"] = parity_sample(batch, ofm, ref1, bases, off, length)
+    return out
 
 
 def load_traffic(workload):
@@ -247,7 +269,8 @@ def main():
                               "frac_of_valu_peak": counts["sw_cells"] * 13 / s_sw / (VALU_PEAK_GOPS * 1e9),
                               "traffic": traffic.get("k_sw")}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1)
+            line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1,
+                                                batch=batch)
         print(json.dumps(line))
     batch.destroy()
     ix.close()

@@ -405,7 +405,7 @@ static int stage_cluster(bwt_batch *b) {
         (rc = b->seed_off.ensure(((size_t)n + 1) * 8)) || (rc = b->clus_off.ensure(((size_t)n + 1) * 8)))
         return rc;
     if (n == 0) { b->n_cand = 0; return fetch_counters(b); }
-    KLAUNCH(b, "read_counts", k_read_counts, cdiv(n, 256), 256, n, maxT, b->t_info.as<uint32_t>(),
+    KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
             b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
             b->ctr.as<Counters>());
     if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
@@ -435,7 +435,7 @@ static int stage_cluster(bwt_batch *b) {
         (rc = b->c_qoff.ensure(nc * 8)) || (rc = b->c_qlen.ensure(nc * 4)) || (rc = b->c_woff.ensure(nc * 8)) ||
         (rc = b->c_wlen.ensure(nc * 4)))
         return rc;
-    KLAUNCH(b, "candidates", k_candidates, cdiv(n, 256), 256, n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
+    KLAUNCH(b, "candidates", k_candidates, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
             b->seed_off.as<uint64_t>(), b->clus_off.as<uint64_t>(), b->pos.as<uint32_t>(), b->c_read.as<uint32_t>(),
             b->c_S.as<uint32_t>(), b->c_D.as<uint32_t>(), b->c_qoff.as<uint64_t>(), b->c_qlen.as<uint32_t>(),
             b->c_woff.as<int64_t>(), b->c_wlen.as<uint32_t>(), b->ctr.as<Counters>());

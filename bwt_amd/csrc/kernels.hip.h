@@ -313,9 +313,10 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
                                                       const uint32_t *__restrict__ t_cnt, uint32_t *__restrict__ r_P,
                                                       uint32_t *__restrict__ r_qty, uint32_t *__restrict__ bigq,
                                                       Counters *ctr) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long P = 0;
-    if (r < n) {
+    // grid-stride (capped grid): one counter atomic per wave for the whole launch, not per 64 reads
+    unsigned long long Psum = 0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        unsigned long long P = 0;
         uint32_t qty = 0, crash = 0;
         for (uint32_t k = 0; k < maxT; k++) {
             uint32_t st = t_info[(uint64_t)r * maxT + k] & 0xff;
@@ -327,8 +328,9 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
         r_P[r] = (uint32_t)P;
         r_qty[r] = qty | (crash << 31);
         if (P > 64 || (P > 0 && maxT > 64)) bigq[atomicAdd(&ctr->n_big, 1u)] = r;
+        Psum += P;
     }
-    unsigned long long s = wave_sum_u64(P);
+    unsigned long long s = wave_sum_u64(Psum);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&ctr->sa_reads, s);
 }
 
@@ -366,8 +368,12 @@ __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, 
     uint32_t p = 0xffffffffu;
     {
         uint32_t msp = 0, madd = 0, midx = 0;
-        for (uint32_t k = 0; k < maxT; k++) {
-            uint32_t e = __shfl(excl, k, 64), c = __shfl(cnt, k, 64), s = __shfl(sp, k, 64), a = __shfl(nadd, k, 64);
+        for (uint32_t k = 0; k < maxT; k++) {          // k is wave-uniform: v_readlane, no LDS round trip
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k);
+            if (!c) continue;
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)k);
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)sp, (int)k);
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)nadd, (int)k);
             if (lane >= e && lane < e + c) { msp = s; madd = a; midx = lane - e; }
         }
         if (lane < P) p = ix.sa[msp - 1 + midx] + madd;
@@ -483,10 +489,9 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
                                                      uint64_t *__restrict__ c_qoff, uint32_t *__restrict__ c_qlen,
                                                      int64_t *__restrict__ c_woff, uint32_t *__restrict__ c_wlen,
                                                      Counters *ctr) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long cells = 0, wbytes = 0;
     uint32_t maxw = 0, maxlq = 0;
-    if (r < n) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {   // grid-stride, capped grid
         const uint32_t K = r_K[r];
         if (K) {
             const uint64_t qo = off[r];
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
                 cells += (unsigned long long)lq * wl; wbytes += wl;
                 maxw = wl > maxw ? wl : maxw;
             }
-            maxlq = lq;
+            maxlq = lq > maxlq ? lq : maxlq;
         }
     }
     cells = wave_sum_u64(cells); wbytes = wave_sum_u64(wbytes);

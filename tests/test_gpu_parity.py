@@ -226,3 +226,62 @@ def test_bench_gather_path_single_rank():
     c = line["counts_per_step"]
     assert c["gathered_hits"] == c["n_hits"] > 1000
     assert line["n_gpus"] == 1 and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("length", [100, 150])
+def test_align_uniform_length_fast_path(gpu_index, orc_fm, ref_bytes, length):
+    """Batches of one read length take the packed-i16 extend kernel (k_sw_score_pk<100|150>): substitutions
+    stay on it (diagonal shortcut), indels go through the trace pass, N goes to the fp64 pass."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = (synth_reads(ref_bytes, 1500, length, 61 + length, max_subs=3) +
+             synth_reads(ref_bytes, 700, length, 62 + length, indel_frac=1.0) +
+             synth_reads(ref_bytes, 200, length, 63 + length, n_frac=1.0))
+    bases, off = lib.pack_reads(reads)
+    b = lib.Batch(gpu_index)
+    b.set_reads(bases, off)
+    counts = b.run(lib.STAGE_EXTEND)
+    out = b.fetch_hits()
+    b.destroy()
+    assert counts["n_traced"] > 50 and counts["n_float"] > 20 and counts["n_hits"] > 1000
+    for i, q in enumerate(reads):
+        a, bb = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+        exp = orc.align_read(orc_fm, ref1, q)
+        if exp is None:
+            assert out["read_status"][i] == 1 and a == bb
+            continue
+        got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+                int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, bb)]
+        assert got == exp, (i, q)
+
+
+def test_parity_on_gpu_built_synthetic_index():
+    """A 6 M-row i.i.d. index built by the GPU builder (the bench's kind of index): search, clustering and
+    extension against the oracle run on the exported columns."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(17)
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 6_000_000, dtype=np.uint8)].tobytes()
+    ix = lib.Index.build(ref, shift=7)
+    L, SA = ix.export()
+    ptr, shift = ix.meta()
+    assert shift == 7
+    ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+    ref1 = E.make_ref1(ref)
+    reads = synth_reads(ref, 1500, 100, 71, max_subs=2) + synth_reads(ref, 300, 100, 72, indel_frac=0.7, n_frac=0.2)
+    bases, off = lib.pack_reads(reads)
+    out = ix.align_batch(bases, off)
+    nh = 0
+    for i, q in enumerate(reads):
+        a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+        exp = orc.align_read(ofm, ref1, q)
+        if exp is None:
+            assert out["read_status"][i] == 1 and a == b
+            continue
+        got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+                int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
+        assert got == exp, (i, q)
+        nh += len(got)
+    assert nh > 1000
+    ix.close()
