@@ -268,6 +268,13 @@ def main():
                               "avg_launch_ms": per["sw_extend"], "valu_lane_ops_per_cell": 13,
                               "frac_of_valu_peak": counts["sw_cells"] * 13 / s_sw / (VALU_PEAK_GOPS * 1e9),
                               "traffic": traffic.get("k_sw")}
+        # PCIe-inclusive rate (never `value`): host buffers in, host hit tables out, one untimed-extra pass
+        t0 = time.perf_counter()
+        batch.set_reads(bases, off)
+        batch.run(stages)
+        if stages == lib.STAGE_EXTEND:
+            batch.fetch_hits()
+        line["pcie_inclusive_reads_per_s"] = n_reads / (time.perf_counter() - t0)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1,
                                                 batch=batch)
