@@ -22,6 +22,21 @@ extern "C" void bwt_constants(bwt_constants_t *o) {
 }
 
 // ------------------------------------------------------------------------------------------------
+int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream) {
+    const uint64_t pw = ((ix->ref1_len + 63) / 64) * 2 + 8;
+    int rc = ix->refplanes.exact(pw * 4 * 4);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ix->refplanes.p, 0, pw * 4 * 4, stream));
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((ix->ref1_len + 255) / 256, 2048));
+    hipLaunchKernelGGL(k_read_planes, dim3(grid), dim3(256), 0, stream, ix->ref1.as<uint8_t>(), ix->ref1_len,
+                       ix->refplanes.as<uint32_t>(), pw);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    ix->d.rplanes = ix->refplanes.as<uint32_t>();
+    ix->d.rpw = pw;
+    return 0;
+}
+
 static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
     const uint32_t n = (uint32_t)fm.L.size();
     if (n < 8 || fm.Last != n) return fail(BWT_EINVAL, "index: Last must equal the number of rows");
@@ -85,6 +100,7 @@ static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, i
     ix->d.ref1_len = ix->ref1_len;
     ix->d.Pc = fm.Pc; ix->d.Pg = fm.Pg; ix->d.Pt = fm.Pt; ix->d.Last = fm.Last; ix->d.dollar = dollar; ix->d.nblk = nblk;
     ix->d.c0[0] = 1; ix->d.c0[1] = fm.Pc - 1; ix->d.c0[2] = fm.Pg - 1; ix->d.c0[3] = fm.Pt - 1;
+    if ((rc = bwt_index_make_refplanes(ix, ix->stream))) { bwt_index_close(ix); return rc; }
     *out = ix;
     return 0;
 }
@@ -140,7 +156,7 @@ extern "C" void bwt_index_close(bwt_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    ix->blocks.release(); ix->sa.release(); ix->ref1.release();
+    ix->blocks.release(); ix->sa.release(); ix->ref1.release(); ix->refplanes.release();
     delete ix;
 }
 
@@ -152,7 +168,7 @@ extern "C" int bwt_index_meta(const bwt_index *ix, uint32_t out[5]) {
 
 extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[3]) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_device_bytes: null argument");
-    out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len;
+    out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len + ix->d.rpw * 16;
     return 0;
 }
 
@@ -187,7 +203,7 @@ struct bwt_batch {
     DevBuf c_read, c_S, c_D, c_qoff, c_qlen, c_woff, c_wlen, c_status, c_score, c_ciglen, cig, fpq;
     uint32_t cig_stride = 32;
     // sw slabs
-    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, tq;
+    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, tq, dq;
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig;
@@ -291,7 +307,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -448,18 +464,19 @@ static int stage_cluster(bwt_batch *b) {
 // SW_TRACE over the candidates whose alignment is not the plain diagonal (and those too wide for the
 // LDS pass), then SW_FP over the candidates that met a base outside ACGT.
 static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
-                  uint32_t max_lq) {
+                  uint32_t max_lq, const uint32_t *qplanes, uint64_t qpw, const uint32_t *wplanes, uint64_t wpw) {
     const uint64_t nc = b->n_cand;
     int rc;
     if ((rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) ||
-        (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)) || (rc = b->tq.ensure(nc * 4 + 4)))
+        (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)) || (rc = b->tq.ensure(nc * 4 + 4)) ||
+        (rc = b->dq.ensure(nc * 4 + 4)))
         return rc;
     if (nc == 0) return 0;
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, b->device);
     if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
-    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 8, b->stream));      // fp_count, tq_count
+    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 12, b->stream));     // fp_count, tq_count, dq_count
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
     io.c_qoff = b->c_qoff.as<uint64_t>(); io.c_qlen = b->c_qlen.as<uint32_t>();
@@ -467,6 +484,12 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
+    io.dq = nullptr; io.qplanes = qplanes; io.wplanes = wplanes; io.qpw = qpw; io.wpw = wpw;
+    static const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
+    if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
+        io.dq = b->dq.as<uint32_t>();
+        KLAUNCH(b, "sw_prefilter", k_sw_prefilter, std::min<uint32_t>(cdiv(nc, 256), 2048), 256, io, (uint32_t)nc);
+    }
 
     // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and
     // non-diagonal alignments go on to the trace pass.  LDS per wave: planes + (wcap+1) x 128 B.
@@ -560,9 +583,10 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
 }
 
 static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
-                        uint32_t max_lq, int32_t shift) {
+                        uint32_t max_lq, int32_t shift, const uint32_t *qplanes = nullptr, uint64_t qpw = 0,
+                        const uint32_t *wplanes = nullptr, uint64_t wpw = 0) {
     for (int attempt = 0; attempt < 8; attempt++) {
-        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq);
+        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq, qplanes, qpw, wplanes, wpw);
         if (rc) return rc;
         // clear the sticky CIGAR-overflow flag before counting
         Counters *dc = b->ctr.as<Counters>();
@@ -589,7 +613,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     }
     if (stages & BWT_STAGE_EXTEND) {
         if ((rc = stage_extend(b, b->bases.as<uint8_t>(), b->ix->d.ref1, b->ix->d.ref1_len, b->hctr.max_w, b->hctr.max_lq,
-                               b->ix->shift)))
+                               b->ix->shift, b->rplanes.as<uint32_t>(), b->pw, b->ix->d.rplanes, b->ix->d.rpw)))
             return rc;
         b->done |= BWT_STAGE_EXTEND;
     }

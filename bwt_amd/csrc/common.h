@@ -49,9 +49,12 @@ struct DevBuf {
 struct bwt_index {
     int device = 0;
     DevIndex d{};
-    DevBuf blocks, sa, ref1;
+    DevBuf blocks, sa, ref1, refplanes;
     uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
     int32_t shift = 0;
     uint64_t ref1_len = 0;
     hipStream_t stream = nullptr;
 };
+
+// builds the Ref1 bit-planes of an index whose ref1 buffer is resident (used by both constructors)
+int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream);

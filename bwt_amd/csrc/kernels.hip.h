@@ -26,9 +26,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
     return v;
 }
-__device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anything else -> -1
-    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
-}
 __device__ __forceinline__ bool is_acgt(uint32_t c) {
     uint32_t i = c - 'A';   // A=0 C=2 G=6 T=19
     return i < 20u && ((0x80045u >> i) & 1u);
@@ -91,38 +88,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(uint64_t *__restrict__ out
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] += add;
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_read_planes: the concatenated read bases as four bit-planes over the byte stream (bit i of a plane
-// = property of base i): low / high bit of the 2-bit code (A C G T = 0..3), is-N, is-other (neither
-// ACGT nor N).  One coalesced 64-byte read and four ballots per wave iteration; everything downstream
-// (sub-read enumeration, LF steps) works on 16..32-bit windows of these planes instead of bytes.
-#define RP_LO 0
-#define RP_HI 1
-#define RP_N 2
-#define RP_O 3
-__global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
-                                                      uint32_t *__restrict__ planes, uint64_t pw) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t nchunks = (total + 63) >> 6;
-    for (uint64_t ci = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ci < nchunks; ci += nwaves) {
-        const uint64_t pos = ci * 64 + lane;
-        const uint32_t c = pos < total ? bases[pos] : 'A';
-        const int code = base_code(c);
-        const unsigned long long lo = __ballot(code == 1 || code == 3), hi = __ballot(code >= 2),
-                                 nn = __ballot(c == 'N'), oo = __ballot(code < 0 && c != 'N');
-        if (lane < 8) {
-            const unsigned long long m = (lane >> 1) == 0 ? lo : (lane >> 1) == 1 ? hi : (lane >> 1) == 2 ? nn : oo;
-            planes[(uint64_t)(lane >> 1) * pw + 2 * ci + (lane & 1)] = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
-        }
-    }
-}
-// 32 bits of a plane starting at absolute bit position pos
-__device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plane, uint64_t pos) {
-    const uint64_t w = pos >> 5;
-    return __builtin_amdgcn_alignbit(plane[w + 1], plane[w], (uint32_t)pos & 31u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,6 +539,9 @@ struct SwIO {
     uint32_t cig_stride;
     uint32_t *fpq;             // queue of candidates for the fp64 kernel
     uint32_t *tq;              // queue of candidates that need a real traceback
+    uint32_t *dq;              // queue of candidates that need the DP at all (filled by k_sw_prefilter)
+    const uint32_t *qplanes, *wplanes;   // bit-planes over qbuf / rbuf (k_read_planes layout)
+    uint64_t qpw, wpw;
     Counters *ctr;
 };
 
@@ -597,12 +565,12 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
     uint32_t *bnd = LDSB ? nullptr : slab_bnd + (uint64_t)wave * maxW1 * 64 + lane;                // [j*64]
     double *bndv = FP ? slab_bndv + (uint64_t)wave * maxW1 * 64 + lane : nullptr;
     uint32_t *dirs = DIRS ? slab_dir + (uint64_t)wave * max_strips * maxW1 * 64 + lane : nullptr;  // [(s*maxW1+j)*64]
-    const uint32_t n_total = MODE == SW_FP ? io.ctr->fp_count : MODE == SW_TRACE ? io.ctr->tq_count : n_items;
+    const uint32_t n_total = MODE == SW_FP ? io.ctr->fp_count : MODE == SW_TRACE ? io.ctr->tq_count : io.dq ? io.ctr->dq_count : n_items;
 
     for (uint32_t g = wave; (uint64_t)g * 64 < n_total; g += nwaves) {
         const uint32_t item = g * 64 + lane;
         if (item >= n_total) continue;
-        const uint32_t c = MODE == SW_FP ? io.fpq[item] : MODE == SW_TRACE ? io.tq[item] : item;
+        const uint32_t c = MODE == SW_FP ? io.fpq[item] : MODE == SW_TRACE ? io.tq[item] : io.dq ? io.dq[item] : item;
         const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
         const int64_t wo = io.c_woff[c];
         if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
@@ -742,6 +710,70 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sw_prefilter: lane per candidate, on the bit-planes of reads and Ref1 only.
+//   * a base outside ACGT in the read or the window  -> fp64 queue (sigma may return 1.6);
+//   * the read matches the window exactly on some diagonal -> done: 2*Lq is the largest score any
+//     alignment of Lq bases can have (sigma <= 2, gaps cost), only a gap-free all-match diagonal reaches
+//     it, so the leftmost such diagonal IS the leftmost maximum of the last row and its cells all chose
+//     up_left: {2*Lq, "<Lq>M"} without running the DP;
+//   * everything else -> DP queue (dense, so the DP kernels' lanes stay full).
+__global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
+    const uint32_t *qlo = io.qplanes + RP_LO * io.qpw, *qhi = io.qplanes + RP_HI * io.qpw;
+    const uint32_t *qn = io.qplanes + RP_N * io.qpw, *qx = io.qplanes + RP_O * io.qpw;
+    const uint32_t *wlo = io.wplanes + RP_LO * io.wpw, *whi = io.wplanes + RP_HI * io.wpw;
+    const uint32_t *wn = io.wplanes + RP_N * io.wpw, *wx = io.wplanes + RP_O * io.wpw;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_items; c += gridDim.x * blockDim.x) {
+        const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
+        const int64_t wo = io.c_woff[c];
+        const uint64_t qo = io.c_qoff[c];
+        if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
+            io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
+            continue;
+        }
+        uint32_t bad = 0;
+        for (uint32_t i = 0; i < lq; i += 32) {
+            uint32_t m = plane_bits(qn, qo + i) | plane_bits(qx, qo + i);
+            if (lq - i < 32) m &= (1u << (lq - i)) - 1u;
+            bad |= m;
+        }
+        for (uint32_t i = 0; i < w; i += 32) {
+            uint32_t m = plane_bits(wn, (uint64_t)wo + i) | plane_bits(wx, (uint64_t)wo + i);
+            if (w - i < 32) m &= (1u << (w - i)) - 1u;
+            bad |= m;
+        }
+        if (bad) {
+            io.c_status[c] = CS_NEED_FP;
+            io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
+            continue;
+        }
+        bool done = false;
+        if (w >= lq && w - lq <= 64) {
+            for (uint32_t d = 0; d + lq <= w && !done; d++) {
+                bool all = true;
+                for (uint32_t i = 0; i < lq && all; i += 32) {
+                    uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + d + i)) |
+                                 (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + d + i));
+                    if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                    all = e == 0;
+                }
+                done = all;
+            }
+        }
+        if (!done) {
+            io.c_status[c] = CS_PENDING;
+            io.dq[atomicAdd(&io.ctr->dq_count, 1u)] = c;
+            continue;
+        }
+        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+        int p = (int)io.cig_stride, len = 0;
+        cig_emit(slot, p, len, lq, 'M');
+        io.c_score[c] = 2 * (int)lq;
+        io.c_ciglen[c] = (uint32_t)len;
+        io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_sw_score: the fast path of the extend stage (integer, read and window all ACGT, W <= the LDS cap).
 // Same recurrence as k_sw<SW_SCORE>, but nothing is read from HBM inside the DP:
 //   * prologue, per group of 64 candidates: the wave loads each candidate's window and query with
@@ -763,13 +795,15 @@ __global__ __launch_bounds__(256) void k_sw_score(SwIO io, uint32_t n_items, uin
     uint32_t *const wlo = pl, *const whi = pl + PW * 64, *const qlo = pl + 2 * PW * 64, *const qhi = pl + (2 * PW + QW) * 64;
     uint16_t *bl = (uint16_t *)(pl + (2 * PW + 2 * QW) * 64) + lane;        // boundary row [j*64]
 
+    if (io.dq) n_items = io.ctr->dq_count;
     for (uint32_t g = wave; (uint64_t)g * 64 < n_items; g += nwaves) {
-        const uint32_t c = g * 64 + lane;
+        const uint32_t item = g * 64 + lane;
+        const uint32_t c = item < n_items ? (io.dq ? io.dq[item] : item) : 0;
         uint32_t lq = 0, w = 0;
         int64_t wo = 0;
         uint64_t qo = 0;
         int state = 0;       // 0 = run the DP here, 1 = idle lane, 2 = out of range, 3 = to the trace kernel (too wide)
-        if (c < n_items) {
+        if (item < n_items) {
             lq = io.c_qlen[c]; w = io.c_wlen[c]; wo = io.c_woff[c]; qo = io.c_qoff[c];
             if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) state = 2;
             else if (w > wcap || lq > lqcap) state = 3;
@@ -924,6 +958,7 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
     const uint32_t set_words = (2 * PW + 2 * QW) * 64;                      // one set = 64 candidates
     uint32_t *pl = lds_sw + (uint64_t)(threadIdx.x >> 6) * 2 * set_words;
 
+    if (io.dq) n_items = io.ctr->dq_count;
     for (uint32_t g = wave; (uint64_t)g * 128 < n_items; g += nwaves) {
         uint32_t cc[2], lq[2], w[2];
         int64_t wo[2];
@@ -931,9 +966,11 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
         int state[2];     // 0 run, 1 idle, 2 out of range, 3 to the trace kernel, 4 to the fp64 kernel
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            cc[h] = g * 128 + h * 64 + lane;
+            const uint32_t item = g * 128 + h * 64 + lane;
+            cc[h] = 0;
             lq[h] = 0; w[h] = 0; wo[h] = 0; qo[h] = 0; state[h] = 1;
-            if (cc[h] < n_items) {
+            if (item < n_items) {
+                cc[h] = io.dq ? io.dq[item] : item;
                 lq[h] = io.c_qlen[cc[h]]; w[h] = io.c_wlen[cc[h]]; wo[h] = io.c_woff[cc[h]]; qo[h] = io.c_qoff[cc[h]];
                 if (wo[h] < 0 || (uint64_t)wo[h] + w[h] > io.rbuf_len || w[h] == 0 || lq[h] == 0) state[h] = 2;
                 else if (w[h] > wcap || lq[h] != (uint32_t)LQ) state[h] = 3;

@@ -40,12 +40,52 @@ struct DevIndex {
     const uint32_t *sa;    // SA[row] at sa[row-1]
     const uint8_t *ref1;   // 200 x 'N' ++ .ref ++ 200 x 'N'
     uint64_t ref1_len;
+    const uint32_t *rplanes;  // bit-planes over Ref1 (k_read_planes layout), rpw words per plane
+    uint64_t rpw;
     uint32_t Pc, Pg, Pt, Last, dollar, nblk;
     uint32_t c0[4];        // {1, Pc-1, Pg-1, Pt-1}: 0-based first row of each F block (src/bwt.erl:105-112)
 };
 
+// byte-stream bit-planes (reads, Ref1) ---------------------------------------------------------------
+__device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anything else -> -1
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_read_planes: the concatenated read bases as four bit-planes over the byte stream (bit i of a plane
+// = property of base i): low / high bit of the 2-bit code (A C G T = 0..3), is-N, is-other (neither
+// ACGT nor N).  One coalesced 64-byte read and four ballots per wave iteration; everything downstream
+// (sub-read enumeration, LF steps) works on 16..32-bit windows of these planes instead of bytes.
+#define RP_LO 0
+#define RP_HI 1
+#define RP_N 2
+#define RP_O 3
+static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
+                                                      uint32_t *__restrict__ planes, uint64_t pw) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t nchunks = (total + 63) >> 6;
+    for (uint64_t ci = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ci < nchunks; ci += nwaves) {
+        const uint64_t pos = ci * 64 + lane;
+        const uint32_t c = pos < total ? bases[pos] : 'A';
+        const int code = base_code(c);
+        const unsigned long long lo = __ballot(code == 1 || code == 3), hi = __ballot(code >= 2),
+                                 nn = __ballot(c == 'N'), oo = __ballot(code < 0 && c != 'N');
+        if (lane < 8) {
+            const unsigned long long m = (lane >> 1) == 0 ? lo : (lane >> 1) == 1 ? hi : (lane >> 1) == 2 ? nn : oo;
+            planes[(uint64_t)(lane >> 1) * pw + 2 * ci + (lane & 1)] = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+        }
+    }
+}
+// 32 bits of a plane starting at absolute bit position pos
+__device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plane, uint64_t pos) {
+    const uint64_t w = pos >> 5;
+    return __builtin_amdgcn_alignbit(plane[w + 1], plane[w], (uint32_t)pos & 31u);
+}
+
+
 struct Counters {          // device-side work counters (roofline accounting)
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags;
-    unsigned int max_w, max_lq, n_big, fp_count, tq_count, pad_;
+    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count;
 };
 

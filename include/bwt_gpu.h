@@ -58,7 +58,7 @@ int bwt_index_from_arrays(const uint8_t *L, const uint32_t *SA, uint32_t n_rows,
 void bwt_index_close(bwt_index *idx);
 /* out = {Pc, Pg, Pt, Last, Shift}  (proplists pointers / shift of the Meta term) */
 int bwt_index_meta(const bwt_index *idx, uint32_t out[5]);
-/* bytes resident in HBM: {rank blocks, SA, ref1} */
+/* bytes resident in HBM: {rank blocks, SA, ref1 + its bit-planes} */
 int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[3]);
 
 /* ------------------------------------------------------------------ a-13 / 8f-1: index construction
