@@ -16,7 +16,7 @@ EXPORTS = [
     "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
-    "bwt_build_index", "bwt_index_save", "bwt_index_export",
+    "bwt_build_index", "bwt_index_save", "bwt_index_export", "bwt_fastq_open", "bwt_fastq_close", "bwt_fastq_read_seqs",
 ]
 
 
@@ -56,6 +56,7 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.bwt_last_error.restype = C.c_char_p
     lib.bwt_index_close.restype = None
+    lib.bwt_fastq_close.restype = None
     lib.bwt_batch_destroy.restype = None
     lib.bwt_constants.restype = None
     _lib = lib

@@ -126,6 +126,19 @@ int bwt_align_batch(bwt_index *idx, const uint8_t *bases, const uint64_t *off, u
 /* Ref1 = 200 x 'N' ++ .ref ++ 200 x 'N' (src/worker_bwt.erl:54-55): copy [off, off+len) to out. */
 int bwt_ref1_read(const bwt_index *idx, uint64_t off, uint64_t len, uint8_t *out);
 
+/* ------------------------------------------------------------------ 8f-2: FASTQ ingest
+ * fastq:read_seqs/2 (src/fastq.erl:5-40) on a memory-mapped file, straight into the packed batch layout:
+ * up to n records in the reference's list order (records are prepended => reverse file order);
+ * Name = header line minus '@' and minus its last character, Seq = next line minus its last character.
+ * *state: 0 = {ok,Acc}, 1 = eof (no record), 2 = {eof,Acc} (file exhausted before n records).
+ * BWT_ENOSPC leaves the file position untouched and reports needed = {bases, name bytes}. */
+typedef struct bwt_fastq bwt_fastq;
+int bwt_fastq_open(const char *path, bwt_fastq **out);
+void bwt_fastq_close(bwt_fastq *f);
+int bwt_fastq_read_seqs(bwt_fastq *f, uint32_t n, uint8_t *bases, uint64_t bases_cap, uint64_t *off /* n+1 */,
+                        char *names, uint64_t names_cap, uint64_t *name_off /* n+1 */, uint32_t *n_out,
+                        int *state, uint64_t needed[2]);
+
 /* ------------------------------------------------------------------ resident-batch interface
  * The same pipeline split so that a caller can keep reads and hits in HBM (bench, multi-GPU
  * gather): upload once, run stages on the index's HIP stream, fetch what is wanted. */

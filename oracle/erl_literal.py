@@ -630,3 +630,69 @@ def make_index_chunks(chromo_bytes):
         start = 1 + (j - 1) * (chunk_size - 2)
         out.append((j, shift + start, body[start - 1:start - 1 + chunk_size]))
     return out
+
+
+# ---------------------------------------------------------------- src/fastq.erl:5-40, src/master.erl:149-178
+class LineDev:
+    """file:open(Path, []) + file:read_line/1 on a byte string: lines keep their newline."""
+
+    def __init__(self, data):
+        self.data, self.pos = data, 0
+
+    def read_line(self):
+        if self.pos >= len(self.data):
+            return None
+        e = self.data.find(b"\n", self.pos)
+        e = len(self.data) if e < 0 else e + 1
+        line = self.data[self.pos:e]
+        self.pos = e
+        return line
+
+
+def fastq_read_seq(dev):
+    while True:
+        line = dev.read_line()
+        if line is None:
+            return None                                        # eof
+        if line[:1] == b"@":
+            seq = dev.read_line()
+            if seq is None:
+                raise ErlCrash("badmatch {ok,SeqData} = eof")
+            dev.read_line(); dev.read_line()                   # _Delimiter, _Quality
+            return line[1:][:-1], seq[:-1]                     # lists:droplast/1 on both
+
+
+def fastq_read_seqs(dev, n):
+    acc = []
+    while n > 0:
+        r = fastq_read_seq(dev)
+        if r is None:
+            return "eof" if not acc else ("eof", acc)
+        acc.insert(0, r)
+        n -= 1
+    return "ok", acc
+
+
+def master_produce_workload(n, dev, state, workload_size=200):
+    """master.erl:162-178; state = dict(fastq_eof=bool, stopping=bool)."""
+    acc = []
+    while n > 0:
+        if state["fastq_eof"]:
+            if not acc:
+                state["stopping"] = True
+                return "stop"
+            raise ErlCrash("function_clause produce_workload")
+        r = fastq_read_seqs(dev, workload_size)
+        if r == "eof":
+            state["fastq_eof"] = True
+            return acc
+        acc.insert(0, r[1])
+        n -= 1
+    return acc
+
+
+def master_cigar_line(name, chromosome, pos, cigar_value, cigar_rate, refseq):
+    """master.erl:149-153: dropped under 265, else the io:format line."""
+    if cigar_rate < 265:
+        return None
+    return "\n%s      %s      %d      %s      %d      %s\n" % (name, chromosome, pos, cigar_value, cigar_rate, refseq)

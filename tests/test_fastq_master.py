@@ -1,0 +1,75 @@
+"""FASTQ ingest and result sink (8f-3): the native parser / host mirror against the literal
+restatement of fastq.erl and master.erl -- record boundaries, droplast quirk, reverse batch order,
+workload production, the 265 filter and the printed line.  CPU only (no compute calls)."""
+import io
+
+import pytest
+
+from oracle import erl_literal as E
+
+
+def make_fastq(n, with_junk=True, final_newline=True, seed=0):
+    import random
+    rng = random.Random(seed)
+    out = []
+    if with_junk:
+        out.append("junk line before the first record\n")
+    for i in range(n):
+        seq = "".join(rng.choice("ACGTN") for _ in range(rng.randrange(20, 120)))
+        qual = "".join(rng.choice("@IJ#+") for _ in seq)      # quality lines may start with '@'
+        out.append("@read.%d extra words\n%s\n+\n%s\n" % (i, seq, qual))
+    text = "".join(out)
+    if not final_newline:
+        text = text[:-1]
+    return text.encode()
+
+
+@pytest.mark.parametrize("n,final_newline", [(0, True), (1, True), (7, True), (450, True), (5, False)])
+def test_read_seqs_matches_literal(tmp_path, n, final_newline):
+    from bwt_amd import fastq
+    data = make_fastq(n, final_newline=final_newline, seed=n)
+    p = tmp_path / "x.fastq"
+    p.write_bytes(data)
+    dev = fastq.Dev(str(p))
+    lit = E.LineDev(data)
+    for want in (200, 200, 3, 200, 1):
+        assert fastq.read_seqs(dev, want) == E.fastq_read_seqs(lit, want)
+    dev.close()
+
+
+def test_header_without_sequence_is_reported(tmp_path):
+    from bwt_amd import fastq, lib
+    p = tmp_path / "bad.fastq"
+    p.write_bytes(b"@only a header\n")
+    dev = fastq.Dev(str(p))
+    with pytest.raises(lib.BwtError):          # {ok,SeqData} = eof: the reference badmatches here
+        fastq.read_seqs(dev, 10)
+    dev.close()
+
+
+def test_produce_workload_matches_literal(tmp_path):
+    from bwt_amd import fastq, master
+    data = make_fastq(1234, seed=5)
+    p = tmp_path / "y.fastq"
+    p.write_bytes(data)
+    s = master.State(fastq.Dev(str(p)), "GL000193.1")
+    lit, lst = E.LineDev(data), dict(fastq_eof=False, stopping=False)
+    total = 0
+    for _ in range(5):
+        a = master.get_workload(3, s)
+        b = E.master_produce_workload(3, lit, lst)
+        assert a == b
+        if a == "stop":
+            break
+        total += sum(len(x) for x in a)
+    assert total == 1234 == s.stat_workload_amount and s.stopping and lst["stopping"]
+    s.fastq.close()
+
+
+def test_cigar_sink_filter_and_format():
+    from bwt_amd import master
+    cast = ("cigar", "r1", (266, "150M"), 117832, b"ACGT")
+    assert master.cigar_line(cast, "GL000193.1") == E.master_cigar_line("r1", "GL000193.1", 117832, "150M", 266, "ACGT")
+    assert master.cigar_line(("cigar", "r1", (200, "100M"), 5, b"AC"), "21") is None      # master.erl:149: 100 bp reads never pass
+    assert master.cigar_line(("cigar", "r1", (200, "100M"), 5, b"AC"), "21", threshold=100) == \
+        "\nr1      21      5      100M      200      AC\n"

@@ -58,3 +58,44 @@ def test_worker_running_clause(fm, lit_fm, ref_bytes):
         exp.append("no_cigar" if top == "no_cigar" else ("cigar", name, top[0], top[1], top[2]))
     assert casts == exp
     assert sum(1 for c in casts if c != "no_cigar") > 10
+
+
+def test_master_run_end_to_end(tmp_path, lit_fm, ref_bytes):
+    """FASTQ file -> workloads -> GPU worker -> result sink, against the literal restatement of
+    fastq.erl + worker_bwt.erl + master.erl (150 bp reads: scores above the 265 filter exist)."""
+    import io
+    from bwt_amd import fm_index, master
+    from oracle import erl_literal as E
+    reads = synth_reads(ref_bytes, 450, 150, 91, max_subs=1)
+    text = "".join("@synth.%d\n%s\n+\n%s\n" % (i, q.decode(), "I" * len(q)) for i, q in enumerate(reads)).encode()
+    p = tmp_path / "reads.fastq"
+    p.write_bytes(text)
+    fm_index.set_env("fm_indices", GOLDEN + "/fm_indices")
+    try:
+        out = io.StringIO()
+        n, lines, _ = master.run(str(p), "GL000193.1", out=out)
+    finally:
+        fm_index._env.clear()
+    assert n == 450
+    # literal pipeline
+    ref1 = E.make_ref1(ref_bytes)
+    lit, st = E.LineDev(text), dict(fastq_eof=False, stopping=False)
+    exp = []
+    while True:
+        wl = E.master_produce_workload(10, lit, st)
+        if wl == "stop":
+            break
+        for qlist in wl:
+            for name, q in reversed(qlist):                      # worker answers in reverse batch order
+                cand = E.worker_candidates(lit_fm, ref1, q)
+                if cand is None:
+                    continue
+                top = E.worker_pick(cand)
+                if top == "no_cigar":
+                    continue
+                line = E.master_cigar_line(name.decode(), "GL000193.1", top[1], top[0][1], top[0][0], top[2].decode())
+                if line is not None:
+                    exp.append(line)
+    got = out.getvalue().split("\n\nReads:")[0]
+    assert got == "".join(exp)
+    assert lines == len(exp) > 20
