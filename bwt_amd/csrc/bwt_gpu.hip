@@ -843,7 +843,22 @@ extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, 
     HIPCHK(hipStreamSynchronize(b->stream));
     // one "read" per pair, one candidate each
     b->n = n; b->n_cand = n;
-    if ((rc = stage_extend(b, dq.as<uint8_t>(), dr.as<uint8_t>(), rtot, max_w, max_lq, 0))) return rc;
+    // bit-planes of both byte streams so that the prefilter applies here as well
+    DevBuf pq, pr;
+    struct G3 { DevBuf &a, &b; ~G3() { a.release(); b.release(); } } g3{pq, pr};
+    const uint64_t qpw = ((qtot + 63) / 64) * 2 + 8, rpw = ((rtot + 63) / 64) * 2 + 8;
+    if ((rc = pq.ensure(qpw * 16)) || (rc = pr.ensure(rpw * 16))) return rc;
+    HIPCHK(hipMemsetAsync(pq.p, 0, qpw * 16, b->stream));
+    HIPCHK(hipMemsetAsync(pr.p, 0, rpw * 16, b->stream));
+    if (n) {
+        KLAUNCH(b, "read_planes", k_read_planes, std::min<uint32_t>(cdiv(qtot, 256), 2048), 256, dq.as<uint8_t>(), qtot,
+                pq.as<uint32_t>(), qpw);
+        KLAUNCH(b, "read_planes", k_read_planes, std::min<uint32_t>(cdiv(rtot, 256), 2048), 256, dr.as<uint8_t>(), rtot,
+                pr.as<uint32_t>(), rpw);
+    }
+    if ((rc = stage_extend(b, dq.as<uint8_t>(), dr.as<uint8_t>(), rtot, max_w, max_lq, 0, pq.as<uint32_t>(), qpw,
+                           pr.as<uint32_t>(), rpw)))
+        return rc;
     if (cig_needed) *cig_needed = b->cig_bytes;
     std::vector<int32_t> cst(n), csc(n);
     std::vector<uint32_t> cl(n);

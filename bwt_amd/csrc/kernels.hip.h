@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
                     const uint32_t k1 = sp - 1, k2 = ep - 1;
                     const uint32_t b1 = k1 / BWT_BLOCK_ROWS, b2 = k2 / BWT_BLOCK_ROWS;
                     const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql];
-                    const uint4 v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+                    uint4 v2 = v1;                                // late steps: Sp-1 and Ep-1 share a block
+                    if (b2 != b1) v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
                     const int m1 = (int)(k1 - b1 * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2 * BWT_BLOCK_ROWS);
                     uint32_t ya0, ya1, yb0, yb1;
                     quarter_match(v1, nl, nh, n16, ya0, ya1);
@@ -716,6 +717,9 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 //     alignment of Lq bases can have (sigma <= 2, gaps cost), only a gap-free all-match diagonal reaches
 //     it, so the leftmost such diagonal IS the leftmost maximum of the last row and its cells all chose
 //     up_left: {2*Lq, "<Lq>M"} without running the DP;
+//   * square window (W = Lq, i.e. D = 0) and at most one mismatch on its only full diagonal -> done as
+//     well: every other path into the last row contains an insertion (loss >= 4 > 3), so the diagonal is
+//     the unique optimum, every cell on it ties or wins as up_left, and no column left of Lq reaches it;
 //   * everything else -> DP queue (dense, so the DP kernels' lanes stay full).
 __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
     const uint32_t *qlo = io.qplanes + RP_LO * io.qpw, *qhi = io.qplanes + RP_HI * io.qpw;
@@ -747,7 +751,20 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
             continue;
         }
         bool done = false;
-        if (w >= lq && w - lq <= 64) {
+        int score = 2 * (int)lq;
+        if (w == lq) {
+            // square window: one full diagonal.  With <= 1 mismatch on it (loss <= 3) it is the unique optimum:
+            // any other path into the last row needs an insertion (gap -2 and a lost match -2: loss >= 4).
+            uint32_t mism = 0;
+            for (uint32_t i = 0; i < lq && mism <= 1; i += 32) {
+                uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
+                             (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + i));
+                if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                mism += __popc(e);
+            }
+            done = mism <= 1 && lq >= 8;
+            score -= 3 * (int)mism;
+        } else if (w > lq && w - lq <= 64) {
             for (uint32_t d = 0; d + lq <= w && !done; d++) {
                 bool all = true;
                 for (uint32_t i = 0; i < lq && all; i += 32) {
@@ -767,7 +784,7 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
         uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
         int p = (int)io.cig_stride, len = 0;
         cig_emit(slot, p, len, lq, 'M');
-        io.c_score[c] = 2 * (int)lq;
+        io.c_score[c] = score;
         io.c_ciglen[c] = (uint32_t)len;
         io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
     }

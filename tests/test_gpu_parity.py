@@ -285,3 +285,44 @@ def test_parity_on_gpu_built_synthetic_index():
         nh += len(got)
     assert nh > 400
     ix.close()
+
+
+def test_prefilter_shortcuts_on_low_complexity_pairs():
+    """The extend stage skips the DP when (a) the read matches a window diagonal exactly, or (b) the window
+    is square (W = Lq) and its diagonal has at most one mismatch.  Adversarial inputs for both claims:
+    homopolymers, short tandem repeats, shifted repeats, and 0/1/2 mismatches at every kind of position."""
+    from bwt_amd import lib
+    from oracle import orc
+    rng = np.random.default_rng(123)
+    qs, rs = [], []
+    units = [b"A", b"AC", b"ACG", b"AAC", b"ACGT", b"AACCGGTT", b"ATATATGC"]
+    for lq in (8, 9, 31, 32, 33, 64, 100, 150):
+        for u in units:
+            base = (u * (lq // len(u) + 3))
+            for shift in (0, 1, len(u)):
+                for nm in (0, 1, 2):
+                    q = bytearray(base[shift:shift + lq])
+                    r = bytearray(base[:lq])                       # square window
+                    for _ in range(nm):
+                        p = int(rng.integers(0, lq))
+                        q[p] = b"ACGT"[(b"ACGT".index(q[p]) + 1 + int(rng.integers(0, 3))) & 3]
+                    qs.append(bytes(q)); rs.append(bytes(r))
+                    r2 = bytearray(base[:lq + int(rng.integers(1, 12))])   # wider window (D > 0)
+                    qs.append(bytes(q)); rs.append(bytes(r2))
+        for _ in range(40):                                       # random sequences, mismatch at the ends
+            r = bytes(rng.choice(list(b"ACGT"), lq).tolist())
+            q = bytearray(r)
+            for p in {0: [], 1: [0], 2: [lq - 1], 3: [0, lq - 1]}[int(rng.integers(0, 4))]:
+                q[p] = b"ACGT"[(b"ACGT".index(q[p]) + 1) & 3]
+            qs.append(bytes(q)); rs.append(r)
+    out = lib.sw_batch(*lib.pack_reads(qs), *lib.pack_reads(rs))
+    nshort = 0
+    for i in range(len(qs)):
+        exp = orc.sw(qs[i], rs[i])
+        if exp == "no_match":
+            assert out["status"][i] == 1, (qs[i], rs[i])
+        else:
+            cig = out["cigar"][int(out["cig_off"][i]):int(out["cig_off"][i + 1])].decode()
+            assert (out["status"][i], int(out["score"][i]), cig) == (0, exp[0], exp[1]), (qs[i], rs[i])
+            nshort += cig == "%dM" % len(qs[i])
+    assert nshort > 200
