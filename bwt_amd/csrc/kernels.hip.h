@@ -210,8 +210,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
                     const uint32_t k1 = sp - 1, k2 = ep - 1;
                     const uint32_t b1 = k1 / BWT_BLOCK_ROWS, b2 = k2 / BWT_BLOCK_ROWS;
                     const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql];
-                    uint4 v2 = v1;                                // late steps: Sp-1 and Ep-1 share a block
-                    if (b2 != b1) v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+                    const uint4 v2 = ix.blocks[(uint64_t)b2 * 4 + ql];   // (skipping this load when b2 == b1 measured 16 % slower)
                     const int m1 = (int)(k1 - b1 * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2 * BWT_BLOCK_ROWS);
                     uint32_t ya0, ya1, yb0, yb1;
                     quarter_match(v1, nl, nh, n16, ya0, ya1);
