@@ -366,11 +366,14 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
     return 0;
 }
 
-// k_search is grid-stride: enough blocks to fill every CU 8 waves deep, no more
-static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks) {
-    int cus = 256;
+// k_search is grid-stride: exactly as many blocks as are resident at once (a larger grid leaves a tail)
+static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks, bool u2 = true) {
+    int cus = 256, per_cu = 8;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n_tasks * 4, 256), (uint64_t)cus * 8));
+    if (u2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<2>, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<1>, 256, 0);
+    per_cu = std::max(1, std::min(per_cu, 8));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n_tasks * 4, 256), (uint64_t)cus * per_cu));
 }
 
 // reads -> bit-planes over the concatenated byte stream (k_read_planes); part of every search pass
@@ -406,7 +409,9 @@ static int stage_search(bwt_batch *b) {
     if ((rc = read_planes(b))) return rc;
     KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT,
             b->t_def.as<uint32_t>());
-    KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, b->ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T,
+    static const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
+    const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
+    KLAUNCH(b, "fm_search", (u2 ? k_search<2> : k_search<1>), search_grid(b, T, u2), 256, b->ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T,
             maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
             b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     HIPCHK(hipGetLastError());
@@ -735,7 +740,7 @@ extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const u
     if (T) {
         HIPCHK(hipMemcpyAsync(b->t_def.p, def.data(), T * 4, hipMemcpyHostToDevice, b->stream));
         if ((rc = read_planes(b))) return rc;
-        KLAUNCH(b, "fm_search", k_search, search_grid(b, T), 256, ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, 1u,
+        KLAUNCH(b, "fm_search", k_search<1>, search_grid(b, T, false), 256, ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, 1u,
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     }

@@ -158,6 +158,19 @@ __device__ __forceinline__ uint32_t quarter_prefix(uint32_t y0, uint32_t y1, int
 // occ(c,k) = cnt[k/192][c] + #{c among the first k%192 rows of block k/192}; the `$` row is stored
 // as code 0 and taken out again.  Per LF step a quad issues two 16-byte-per-lane loads (blocks of
 // Sp-1 and Ep-1) and three DPP quad reductions (occ(c,Sp-1), occ(c,Ep-1), the L[Ep]==c bit).
+// U independent tasks per quad are advanced in lock step (their block loads are issued together), which
+// doubles the bytes each wave keeps in flight: the step is a dependent chain of random 64-byte reads.
+// The clause order of bwa:find_seeds/5 (bwa.erl:31-45) is folded into a per-task step limit:
+//   n stops at MAX_LEN, at the start of the read, or at the first N (all three: range check applies),
+//   or at the first base that is neither ACGT nor N (never equals any L: not_found, no range check).
+struct LfTask {
+    uint64_t task;
+    uint32_t sp, ep, lo16, hi16, status;
+    int n, nlim;
+    bool check_at_limit, check, active;
+};
+
+template <int U>
 __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
                                                  const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
                                                  const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
@@ -167,84 +180,112 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
     const int row0 = 48 * ql;                                    // first row of this lane's quarter
     const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
     uint32_t steps = 0, live = 0;
-    for (uint64_t task = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; task < n_tasks; task += nquads) {
-        const uint32_t def = t_def[task];
-        const int e = (int)(def & 0xffffu);
-        uint32_t status = TS_NONE, sp = 0, ep = 0, nm = 0;
-        if (e > 0) {
+    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; base < n_tasks; base += (uint64_t)U * nquads) {
+        LfTask T[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            LfTask &t = T[u];
+            t.task = base + (uint64_t)u * nquads;
+            t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
+            t.check_at_limit = true; t.check = true; t.active = false;
+            if (t.task >= n_tasks) continue;
+            const int e = (int)(t_def[t.task] & 0xffffu);
+            if (e <= 0) continue;
             live++;
-            const uint32_t r = (uint32_t)(task / maxT);
+            const uint32_t r = (uint32_t)(t.task / maxT);
             // the (at most) 15 bases a search consumes, [e-15, e): bit 15 of each 16-bit plane window = base e-1
             const uint64_t endp = off[r] + (uint64_t)e;
-            uint32_t lo16, hi16, n16b, o16;
+            uint32_t n16b, o16;
             if (endp >= 16) {
-                lo16 = plane_bits(planes + RP_LO * pw, endp - 16); hi16 = plane_bits(planes + RP_HI * pw, endp - 16);
+                t.lo16 = plane_bits(planes + RP_LO * pw, endp - 16); t.hi16 = plane_bits(planes + RP_HI * pw, endp - 16);
                 n16b = plane_bits(planes + RP_N * pw, endp - 16); o16 = plane_bits(planes + RP_O * pw, endp - 16);
             } else {                                             // only the very first read of a batch
                 const uint32_t sh = 16 - (uint32_t)endp;
-                lo16 = planes[RP_LO * pw] << sh; hi16 = planes[RP_HI * pw] << sh;
+                t.lo16 = planes[RP_LO * pw] << sh; t.hi16 = planes[RP_HI * pw] << sh;
                 n16b = planes[RP_N * pw] << sh; o16 = planes[RP_O * pw] << sh;
             }
-            status = TS_SEEDS;
-            {                                                     // bwa.erl:15-24: range of the last base
-                const uint32_t hc = ((lo16 >> 15) & 1u) | (((hi16 >> 15) & 1u) << 1);
-                if ((o16 >> 15) & 1u) status = TS_CRASH;
-                else if (((n16b >> 15) & 1u) || hc == 0) { sp = 1; ep = ix.Pc - 1; }        // N is searched as A
-                else if (hc == 1) { sp = ix.Pc; ep = ix.Pg - 1; }
-                else if (hc == 2) { sp = ix.Pg; ep = ix.Pt - 1; }
-                else { sp = ix.Pt; ep = ix.Last; }
+            t.status = TS_SEEDS;
+            t.n = 1;
+            const uint32_t hc = ((t.lo16 >> 15) & 1u) | (((t.hi16 >> 15) & 1u) << 1);       // bwa.erl:15-24
+            if ((o16 >> 15) & 1u) { t.status = TS_CRASH; continue; }
+            else if (((n16b >> 15) & 1u) || hc == 0) { t.sp = 1; t.ep = ix.Pc - 1; }        // N is searched as A
+            else if (hc == 1) { t.sp = ix.Pc; t.ep = ix.Pg - 1; }
+            else if (hc == 2) { t.sp = ix.Pg; t.ep = ix.Pt - 1; }
+            else { t.sp = ix.Pt; t.ep = ix.Last; }
+            t.nlim = e < BWT_MAX_LEN ? e : BWT_MAX_LEN;          // n == MAX_LEN (bwa.erl:31-32) or read exhausted (:44-45)
+            const uint32_t sm = (n16b | o16) & 0x7fffu;           // base k of step n sits at plane bit 15-n
+            if (sm) {
+                const int hb = 31 - __clz((int)sm);
+                const int nstop = 15 - hb;
+                if (nstop < t.nlim) { t.nlim = nstop; t.check_at_limit = ((o16 >> hb) & 1u) == 0; }   // N: :33-34
             }
-            if (status != TS_CRASH) {
-                int n = 1, k = e - 2;
-                bool check = true;
-                for (;;) {
-                    if (n == BWT_MAX_LEN) break;                  // bwa.erl:31-32
-                    if (k < 0) break;                             // bwa.erl:44-45
-                    const uint32_t bi = 15u - (uint32_t)n;        // plane bit of base k
-                    if ((n16b >> bi) & 1u) break;                 // bwa.erl:33-34
-                    if ((o16 >> bi) & 1u) { check = false; break; }   // never equals any L: not_found
-                    const uint32_t cl = (lo16 >> bi) & 1u, ch = (hi16 >> bi) & 1u;
-                    const int code = (int)(cl | (ch << 1));
-                    const uint32_t nl = cl - 1u, nh = ch - 1u;     // ~(-bit): all ones when the wanted bit is 0
-                    const uint32_t n16 = (nl & 0xffffu) | (nh << 16);
-                    const uint32_t k1 = sp - 1, k2 = ep - 1;
-                    const uint32_t b1 = k1 / BWT_BLOCK_ROWS, b2 = k2 / BWT_BLOCK_ROWS;
-                    const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql];
-                    const uint4 v2 = ix.blocks[(uint64_t)b2 * 4 + ql];   // (skipping this load when b2 == b1 measured 16 % slower)
-                    const int m1 = (int)(k1 - b1 * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2 * BWT_BLOCK_ROWS);
-                    uint32_t ya0, ya1, yb0, yb1;
-                    quarter_match(v1, nl, nh, n16, ya0, ya1);
-                    quarter_match(v2, nl, nh, n16, yb0, yb1);
-                    const bool mine = ql == code;                 // this lane's count word is the wanted one
-                    uint32_t o1 = quad_sum(quarter_prefix(ya0, ya1, m1 - row0) + (mine ? v1.x : 0u));   // occ(c,Sp-1)
-                    uint32_t o2 = quad_sum(quarter_prefix(yb0, yb1, m2 - row0) + (mine ? v2.x : 0u));   // occ(c,Ep-1)
-                    const int pos = m2 - row0;                    // L[Ep] is row m2 of block b2
-                    uint32_t bit = 0;
-                    if (pos >= 0 && pos < 48) bit = pos < 32 ? (yb0 >> pos) & 1u : (yb1 >> (pos - 32)) & 1u;
-                    bit = quad_sum(bit);                          // L[Ep] == c
-                    if (code == 0) {                              // take the `$` row out again
-                        const uint32_t f1 = b1 * BWT_BLOCK_ROWS, f2 = b2 * BWT_BLOCK_ROWS;
-                        if (ix.dollar > f1 && ix.dollar <= k1) o1 -= 1;
-                        if (ix.dollar > f2 && ix.dollar <= k2) o2 -= 1;
-                        if (ix.dollar == ep) bit = 0;
-                    }
-                    steps++;
-                    if (!(o2 > o1)) { check = false; break; }     // se_down: not_found (bwa.erl:38)
-                    // C0 by selects: indexing the kernel-argument array with a per-lane code sends it through scratch
-                    const uint32_t c0 = code == 0 ? 1u : code == 1 ? ix.Pc - 1 : code == 2 ? ix.Pg - 1 : ix.Pt - 1;
-                    sp = c0 + o1;
-                    ep = c0 + o2 + bit - 1;                       // C0 + occ(c,Ep) - 1
-                    n++; k--;
+            t.active = t.n < t.nlim;
+        }
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) any |= T[u].active;
+            if (!any) break;
+            uint4 v1[U], v2[U];
+            uint32_t b1[U], b2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {                        // issue every task's two block loads first
+                if (!T[u].active) continue;
+                b1[u] = (T[u].sp - 1) / BWT_BLOCK_ROWS; b2[u] = (T[u].ep - 1) / BWT_BLOCK_ROWS;
+                v1[u] = ix.blocks[(uint64_t)b1[u] * 4 + ql];
+                v2[u] = ix.blocks[(uint64_t)b2[u] * 4 + ql];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                LfTask &t = T[u];
+                if (!t.active) continue;
+                const uint32_t bi = 15u - (uint32_t)t.n;          // plane bit of the base this step consumes
+                const uint32_t cl = (t.lo16 >> bi) & 1u, ch = (t.hi16 >> bi) & 1u;
+                const int code = (int)(cl | (ch << 1));
+                const uint32_t nl = cl - 1u, nh = ch - 1u;        // ~(-bit): all ones when the wanted bit is 0
+                const uint32_t n16 = (nl & 0xffffu) | (nh << 16);
+                const uint32_t k1 = t.sp - 1, k2 = t.ep - 1;
+                const int m1 = (int)(k1 - b1[u] * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2[u] * BWT_BLOCK_ROWS);
+                uint32_t ya0, ya1, yb0, yb1;
+                quarter_match(v1[u], nl, nh, n16, ya0, ya1);
+                quarter_match(v2[u], nl, nh, n16, yb0, yb1);
+                const bool mine = ql == code;                     // this lane's count word is the wanted one
+                uint32_t o1 = quad_sum(quarter_prefix(ya0, ya1, m1 - row0) + (mine ? v1[u].x : 0u));   // occ(c,Sp-1)
+                uint32_t o2 = quad_sum(quarter_prefix(yb0, yb1, m2 - row0) + (mine ? v2[u].x : 0u));   // occ(c,Ep-1)
+                const int pos = m2 - row0;                        // L[Ep] is row m2 of block b2
+                const uint32_t sel = pos < 32 ? yb0 >> (pos & 31) : yb1 >> ((pos - 32) & 31);
+                uint32_t bit = quad_sum((pos >= 0 && pos < 48) ? sel & 1u : 0u);                     // L[Ep] == c
+                if (code == 0) {                                  // take the `$` row out again
+                    const uint32_t f1 = b1[u] * BWT_BLOCK_ROWS, f2 = b2[u] * BWT_BLOCK_ROWS;
+                    if (ix.dollar > f1 && ix.dollar <= k1) o1 -= 1;
+                    if (ix.dollar > f2 && ix.dollar <= k2) o2 -= 1;
+                    if (ix.dollar == t.ep) bit = 0;
                 }
-                nm = (uint32_t)n;
-                if (check && ep - sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
-                else if (n < BWT_MIN_LEN) status = TS_NO_SEEDS;   // fmi.erl:89
+                steps++;
+                if (!(o2 > o1)) { t.check = false; t.active = false; continue; }   // se_down: not_found (bwa.erl:38)
+                // C0 by selects: indexing the kernel-argument array with a per-lane code sends it through scratch
+                const uint32_t c0 = code == 0 ? 1u : code == 1 ? ix.Pc - 1 : code == 2 ? ix.Pg - 1 : ix.Pt - 1;
+                t.sp = c0 + o1;
+                t.ep = c0 + o2 + bit - 1;                         // C0 + occ(c,Ep) - 1
+                t.n++;
+                if (t.n >= t.nlim) { t.check = t.check_at_limit; t.active = false; }
             }
         }
-        if (ql == 0) {
-            t_sp[task] = sp; t_ep[task] = ep;
-            t_info[task] = status | (nm << 8);
-            t_cnt[task] = status == TS_SEEDS ? ep - sp + 1 : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            LfTask &t = T[u];
+            if (t.task >= n_tasks) continue;
+            uint32_t status = t.status;
+            if (status == TS_SEEDS) {
+                if (t.n >= t.nlim && t.check) t.check = t.check_at_limit;          // tasks that never stepped
+                if (t.check && t.ep - t.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
+                else if (t.n < BWT_MIN_LEN) status = TS_NO_SEEDS;                  // fmi.erl:89
+            }
+            if (ql == 0) {
+                t_sp[t.task] = t.sp; t_ep[t.task] = t.ep;
+                t_info[t.task] = status | ((uint32_t)t.n << 8);
+                t_cnt[t.task] = status == TS_SEEDS ? t.ep - t.sp + 1 : 0;
+            }
         }
     }
     // one atomic pair per wave (the grid is capped, so a few thousand per launch) for the work counters
