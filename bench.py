@@ -30,7 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured streaming copy
-VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lane-ops/ns: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
 
 
 def log(msg):
@@ -262,11 +261,16 @@ def main():
             "counts_per_step": counts,
         }
         if "sw_extend" in per:
-            # extend stage: integer VALU bound (not HBM, not MFMA): cell updates/s and ~13 VALU lane-ops per cell
+            # extend stage: integer-VALU bound (not HBM, not MFMA).  wave64 integer ops issue at 4 cycles per op on
+            # gfx950's SIMDs (SQ counters), i.e. 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 3.9e13 lane-ops/s;
+            # the packed kernel spends 7.4 VALU ops per cell on the candidates the prefilter could not settle.
             s_sw = per["sw_extend"] / 1e3
-            line["extend"] = {"kernel": "k_sw<false>", "bound": "valu-int", "cells_per_s": counts["sw_cells"] / s_sw,
-                              "avg_launch_ms": per["sw_extend"], "valu_lane_ops_per_cell": 13,
-                              "frac_of_valu_peak": counts["sw_cells"] * 13 / s_sw / (VALU_PEAK_GOPS * 1e9),
+            dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
+            line["extend"] = {"kernel": "k_sw_score_pk", "bound": "valu-int", "candidates": counts["n_clusters"],
+                              "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"],
+                              "dp_candidates": counts["n_dp"], "dp_cells_per_s": dp_cells / s_sw,
+                              "avg_launch_ms": per["sw_extend"], "valu_lane_ops_per_cell": 7.4,
+                              "frac_of_valu_peak": dp_cells * 7.4 / s_sw / (256 * 4 * 16 * 2.4e9),
                               "traffic": traffic.get("k_sw")}
         # PCIe-inclusive rate (never `value`): host buffers in, host hit tables out, one untimed-extra pass
         t0 = time.perf_counter()

@@ -627,7 +627,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
         counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
-        counts->n_float = b->hctr.fp_count; counts->n_traced = b->hctr.tq_count;
+        counts->n_float = b->hctr.fp_count; counts->n_traced = b->hctr.tq_count; counts->n_dp = b->hctr.dq_count;
     }
     return 0;
 }

@@ -154,6 +154,7 @@ typedef struct {
     uint64_t window_bytes;           /* reference-window bytes read by the extend stage      */
     uint64_t n_float;                /* candidates that took the fp64 (N / 1.6) path         */
     uint64_t n_traced;               /* candidates that needed a real traceback (not "<Lq>M") */
+    uint64_t n_dp;                   /* candidates the prefilter could not settle (ran the DP)  */
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);
 void bwt_batch_destroy(bwt_batch *b);
