@@ -326,3 +326,28 @@ def test_prefilter_shortcuts_on_low_complexity_pairs():
             assert (out["status"][i], int(out["score"][i]), cig) == (0, exp[0], exp[1]), (qs[i], rs[i])
             nshort += cig == "%dM" % len(qs[i])
     assert nshort > 200
+
+
+def test_edge_batches(gpu_index, orc_fm, ref_bytes):
+    """Empty batch, reads shorter than MIN_LEN, a single read, and 600 bp reads (more than 64 sub-reads:
+    the workgroup clustering path and the generic strip kernels)."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    out = gpu_index.align_batch(*lib.pack_reads([]))
+    assert len(out["hit_off"]) == 1 and len(out["score"]) == 0
+    out = gpu_index.sga_batch(*lib.pack_reads([b"ACGTAC", b"", b"ACGTACG"]))
+    assert out["clus_off"].tolist() == [0, 0, 0, 0]
+    long_reads = synth_reads(ref_bytes, 40, 600, 301, max_subs=4) + synth_reads(ref_bytes, 10, 600, 302, indel_frac=1.0)
+    for reads in ([ref_bytes[5000:5100]], long_reads):
+        bases, off = lib.pack_reads(reads)
+        out = gpu_index.align_batch(bases, off)
+        for i, q in enumerate(reads):
+            a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+            exp = orc.align_read(orc_fm, ref1, q)
+            if exp is None:
+                assert out["read_status"][i] == 1 and a == b
+                continue
+            got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+                    int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
+            assert got == exp, (i, len(q))
