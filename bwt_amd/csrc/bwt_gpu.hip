@@ -425,7 +425,11 @@ static int stage_cluster(bwt_batch *b) {
         (rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->bigq.ensure((size_t)n * 4 + 4)) ||
         (rc = b->seed_off.ensure(((size_t)n + 1) * 8)) || (rc = b->clus_off.ensure(((size_t)n + 1) * 8)))
         return rc;
-    if (n == 0) { b->n_cand = 0; return fetch_counters(b); }
+    if (n == 0) {
+        b->n_cand = 0;
+        HIPCHK(hipMemsetAsync(b->clus_off.p, 0, 8, b->stream));
+        return fetch_counters(b);
+    }
     KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
             b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
             b->ctr.as<Counters>());
@@ -560,7 +564,16 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
         (rc = b->r_status.ensure((size_t)n * 4 + 4)) || (rc = b->hit_off.ensure(((size_t)n + 1) * 8)) ||
         (rc = b->cigb_off.ensure(((size_t)n + 1) * 8)))
         return rc;
-    if (n == 0) { b->n_hits = 0; b->cig_bytes = 0; return 0; }
+    if (n == 0) {                                   // empty batch: empty, but well-formed, hit tables
+        b->n_hits = 0; b->cig_bytes = 0;
+        if ((rc = b->h_rec.ensure(16)) || (rc = b->h_woff.ensure(8)) || (rc = b->h_wlen.ensure(4)) ||
+            (rc = b->h_cigoff.ensure(8)) || (rc = b->h_cig.ensure(16)))
+            return rc;
+        HIPCHK(hipMemsetAsync(b->hit_off.p, 0, 8, b->stream));
+        HIPCHK(hipMemsetAsync(b->h_cigoff.p, 0, 8, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return 0;
+    }
     KLAUNCH(b, "hits_count", k_hits_count, cdiv(n, 256), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
             b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_cigb.as<uint32_t>(),
             b->r_status.as<int32_t>(), b->ctr.as<Counters>());
