@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
             for (int u = 0; u < U; u++) {                        // issue every task's two block loads first
                 if (!T[u].active) continue;
                 b1[u] = (T[u].sp - 1) / BWT_BLOCK_ROWS; b2[u] = (T[u].ep - 1) / BWT_BLOCK_ROWS;
+                // (non-temporal loads for the deep, touched-once steps measured slower: 38.6-42 ms vs 36.2 ms)
                 v1[u] = ix.blocks[(uint64_t)b1[u] * 4 + ql];
                 v2[u] = ix.blocks[(uint64_t)b2[u] * 4 + ql];
             }
