@@ -198,20 +198,29 @@ def main():
     gather = (world > 1 or force_gather) and stages == lib.STAGE_EXTEND
     lo, _ = shard.slab(n_reads * world, world, rank)
     hit_buf = None
+    gatherer = shard.HitGatherer(dist, rank, world, torch.device("cuda", local_rank)) if gather else None
+    gathered = [0]
 
     def step():
         nonlocal hit_buf
         c = batch.run(stages)
         if gather:
-            # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0
+            # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0, double-buffered so that the
+            # gather of this step overlaps the next step's kernels
             nh = c["n_hits"]
             if hit_buf is None or hit_buf.shape[0] < nh:
                 hit_buf = torch.zeros((max(nh, 1) * 5 // 4, 2), dtype=torch.int64, device="cuda")
             batch.hits_to_device(hit_buf.data_ptr(), hit_buf.shape[0])
-            parts = shard.gather_hits(dist, shard.globalize(hit_buf[:nh], lo), rank, world)
-            if rank == 0:
-                c["gathered_hits"] = int(sum(p.shape[0] for p in parts))
+            parts = gatherer.submit(shard.globalize(hit_buf[:nh], lo))
+            if rank == 0 and parts is not None:
+                gathered[0] = int(sum(p.shape[0] for p in parts))
         return c
+
+    def drain():
+        if gather:
+            parts = gatherer.wait()
+            if rank == 0 and parts is not None:
+                gathered[0] = int(sum(p.shape[0] for p in parts))
 
     def sync():
         torch.cuda.synchronize()
@@ -221,13 +230,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     batch.profile(True)                                 # hipEvents around every kernel, on the library's own stream
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counts = step()
+    drain()                                             # the last gather is inside the timed region
     sync()
     dt = time.perf_counter() - t0
+    if gather and rank == 0:
+        counts["gathered_hits"] = gathered[0]
     kt = batch.kernel_times()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")

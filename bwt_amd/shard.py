@@ -52,3 +52,68 @@ def gather_hits(dist, rec, rank, world, dst=0):
     if rank != dst:
         return None
     return [out[r][: counts[r]] for r in range(world)]
+
+
+class HitGatherer:
+    """Asynchronous, double-buffered form of gather_hits for a steady stream of batches: the gather of
+    batch b runs on the collective's own stream while batch b+1 is being computed.  All ranks agree once on a
+    padded capacity (all_reduce MAX of the first batch's hit count, +25 %); a batch that outgrows it falls
+    back to the synchronous path."""
+
+    def __init__(self, dist, rank, world, device, dst=0):
+        self.dist, self.rank, self.world, self.device, self.dst = dist, rank, world, device, dst
+        self.cap = 0
+        self.send = [None, None]
+        self.recv = [None, None]
+        self.cnt_in = [None, None]
+        self.cnt_out = [None, None]
+        self.pending = None          # (slot, [work handles])
+        self.k = 0
+
+    def _agree_capacity(self, n):
+        t = torch.tensor([n], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.cap = max(int(t.item()) * 5 // 4, 1)
+        for s in (0, 1):
+            self.send[s] = torch.zeros((self.cap, 2), dtype=torch.int64, device=self.device)
+            self.cnt_in[s] = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.cnt_out[s] = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+            if self.rank == self.dst:
+                self.recv[s] = [torch.empty((self.cap, 2), dtype=torch.int64, device=self.device) for _ in range(self.world)]
+
+    def submit(self, rec):
+        """Start gathering `rec` ([k,2] int64, global read ids).  Returns the result of the PREVIOUS submit
+        (list of per-rank tensors on dst, None elsewhere, None for the very first call)."""
+        n = rec.shape[0]
+        if self.cap == 0:
+            self._agree_capacity(n)
+        prev = self.wait()
+        over = torch.tensor([1 if n > self.cap else 0], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(over, op=self.dist.ReduceOp.MAX)          # every rank takes the same path
+        if int(over.item()):
+            self.sync_result = gather_hits(self.dist, rec, self.rank, self.world, self.dst)
+            self.pending = ("sync", None)
+            return prev
+        s = self.k & 1
+        self.k += 1
+        self.send[s][:n] = rec
+        self.cnt_in[s][0] = n
+        w1 = self.dist.all_gather(self.cnt_out[s], self.cnt_in[s], async_op=True)
+        w2 = self.dist.gather(self.send[s], self.recv[s] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        self.pending = (s, [w1, w2])
+        return prev
+
+    def wait(self):
+        """Finish the outstanding gather, if any, and return its result."""
+        if self.pending is None:
+            return None
+        s, works = self.pending
+        self.pending = None
+        if s == "sync":
+            return self.sync_result
+        for w in works:
+            w.wait()
+        if self.rank != self.dst:
+            return None
+        counts = [int(c.item()) for c in self.cnt_out[s]]
+        return [self.recv[s][r][: counts[r]] for r in range(self.world)]

@@ -66,3 +66,45 @@ def test_gather_world2():
         for k in range(i % 3):
             exp_r.append(i); exp_s.append(100 + (i * 7 + k) % 101); exp_p.append(i * 1000 - k)
     assert got == (exp_r, exp_s, exp_p)
+
+
+def _worker_async(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = shard.HitGatherer(dist, rank, world, torch.device("cpu"))
+    results = []
+    for step in range(4):                      # batch sizes change; step 3 outgrows the agreed capacity
+        n = [5, 3, 6, 40][step] + rank
+        rec = torch.stack([torch.arange(n, dtype=torch.int64) + 1000 * rank + 100000 * step,
+                           torch.full((n,), step, dtype=torch.int64)], dim=1)
+        prev = g.submit(rec)
+        if prev is not None and rank == 0:
+            results.append(torch.cat(prev).tolist())
+    last = g.wait()
+    if rank == 0:
+        results.append(torch.cat(last).tolist())
+        q.put(results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_double_buffered_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == 4
+    for step, res in enumerate(got):
+        exp = []
+        for rank in range(world):
+            n = [5, 3, 6, 40][step] + rank
+            exp += [[i + 1000 * rank + 100000 * step, step] for i in range(n)]
+        assert res == exp
