@@ -369,21 +369,26 @@ __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, 
         nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);   // N + Shift + Skip (sga.erl:32,37-39)
     }
     uint32_t incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+    for (uint32_t o = 1; o < maxT; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
     const uint32_t excl = incl - cnt;
+    // seed i of the read belongs to the sub-read whose slice [excl, excl+cnt) holds i: the sub-read lanes drop their
+    // id at their slice start in a wave-private LDS row, a ballot + clz finds every lane's slice start, and three
+    // ds_bpermutes fetch that sub-read's {Sp, N+Shift+Skip}
+    __shared__ uint32_t mark[4][64];
+    uint32_t *mk = mark[threadIdx.x >> 6];
+    mk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < maxT && cnt) mk[excl] = lane + 1;           // excl < P <= 64
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t tk = mk[lane];
     uint32_t p = 0xffffffffu;
     {
-        uint32_t msp = 0, madd = 0, midx = 0;
-        for (uint32_t k = 0; k < maxT; k++) {          // k is wave-uniform: v_readlane, no LDS round trip
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k);
-            if (!c) continue;
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)k);
-            const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)sp, (int)k);
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)nadd, (int)k);
-            if (lane >= e && lane < e + c) { msp = s; madd = a; midx = lane - e; }
-        }
-        if (lane < P) p = ix.sa[msp - 1 + midx] + madd;
+        const unsigned long long tmask = __ballot(tk != 0);
+        const unsigned long long tb = tmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int s0 = 63 - __clzll(tb | 1ull);              // first seed slot of my sub-read
+        const uint32_t tid = __shfl(tk, s0, 64);             // its lane + 1
+        const uint32_t msp = __shfl(sp, (int)tid - 1, 64), madd = __shfl(nadd, (int)tid - 1, 64);
+        if (lane < P) p = ix.sa[msp - 1 + (lane - (uint32_t)s0)] + madd;
     }
     // bitonic sort ascending over 64 lanes
 #pragma unroll
