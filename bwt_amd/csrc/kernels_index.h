@@ -65,15 +65,26 @@ static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__res
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t nchunks = (total + 63) >> 6;
-    for (uint64_t ci = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ci < nchunks; ci += nwaves) {
-        const uint64_t pos = ci * 64 + lane;
-        const uint32_t c = pos < total ? bases[pos] : 'A';
-        const int code = base_code(c);
-        const unsigned long long lo = __ballot(code == 1 || code == 3), hi = __ballot(code >= 2),
-                                 nn = __ballot(c == 'N'), oo = __ballot(code < 0 && c != 'N');
-        if (lane < 8) {
-            const unsigned long long m = (lane >> 1) == 0 ? lo : (lane >> 1) == 1 ? hi : (lane >> 1) == 2 ? nn : oo;
-            planes[(uint64_t)(lane >> 1) * pw + 2 * ci + (lane & 1)] = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    // four independent 64-byte loads in flight per wave before any of them is consumed
+    for (uint64_t c0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c0 < nchunks; c0 += 4 * nwaves) {
+        uint32_t ch[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t pos = (c0 + (uint64_t)u * nwaves) * 64 + lane;
+            ch[u] = pos < total ? bases[pos] : 'A';
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t ci = c0 + (uint64_t)u * nwaves;
+            if (ci >= nchunks) break;
+            const uint32_t c = ch[u];
+            const int code = base_code(c);
+            const unsigned long long lo = __ballot(code == 1 || code == 3), hi = __ballot(code >= 2),
+                                     nn = __ballot(c == 'N'), oo = __ballot(code < 0 && c != 'N');
+            if (lane < 8) {
+                const unsigned long long m = (lane >> 1) == 0 ? lo : (lane >> 1) == 1 ? hi : (lane >> 1) == 2 ? nn : oo;
+                planes[(uint64_t)(lane >> 1) * pw + 2 * ci + (lane & 1)] = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+            }
         }
     }
 }
