@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
                                                  uint32_t *__restrict__ t_cnt, Counters *ctr) {
     const int ql = (int)(threadIdx.x & 3);
     const int row0 = 48 * ql;                                    // first row of this lane's quarter
+    const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;      // the one block whose planes hold the `$` row
     const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
     uint32_t steps = 0, live = 0;
     for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; base < n_tasks; base += (uint64_t)U * nquads) {
@@ -256,16 +257,20 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
                 const int pos = m2 - row0;                        // L[Ep] is row m2 of block b2
                 const uint32_t sel = pos < 32 ? yb0 >> (pos & 31) : yb1 >> ((pos - 32) & 31);
                 uint32_t bit = quad_sum((pos >= 0 && pos < 48) ? sel & 1u : 0u);                     // L[Ep] == c
-                if (code == 0) {                                  // take the `$` row out again
-                    const uint32_t f1 = b1[u] * BWT_BLOCK_ROWS, f2 = b2[u] * BWT_BLOCK_ROWS;
-                    if (ix.dollar > f1 && ix.dollar <= k1) o1 -= 1;
-                    if (ix.dollar > f2 && ix.dollar <= k2) o2 -= 1;
-                    if (ix.dollar == t.ep) bit = 0;
+                if (b1[u] == dblk || b2[u] == dblk) {             // (rare) the block that holds the `$` row: take it out again
+                    if (code == 0) {
+                        const uint32_t f = dblk * BWT_BLOCK_ROWS;
+                        if (b1[u] == dblk && ix.dollar > f && ix.dollar <= k1) o1 -= 1;
+                        if (b2[u] == dblk && ix.dollar > f && ix.dollar <= k2) o2 -= 1;
+                        if (ix.dollar == t.ep) bit = 0;
+                    }
                 }
                 steps++;
                 if (!(o2 > o1)) { t.check = false; t.active = false; continue; }   // se_down: not_found (bwa.erl:38)
-                // C0 by selects: indexing the kernel-argument array with a per-lane code sends it through scratch
-                const uint32_t c0 = code == 0 ? 1u : code == 1 ? ix.Pc - 1 : code == 2 ? ix.Pg - 1 : ix.Pt - 1;
+                // C0[code] as bitwise selects on the code's plane masks (a per-lane index into the kernel-argument array
+                // goes through scratch; chained ?: becomes divergent branches): nl/nh are all ones when that code bit is 0
+                const uint32_t c_lo = (nl & 1u) | (~nl & (ix.Pc - 1)), c_hi = (nl & (ix.Pg - 1)) | (~nl & (ix.Pt - 1));
+                const uint32_t c0 = (nh & c_lo) | (~nh & c_hi);
                 t.sp = c0 + o1;
                 t.ep = c0 + o2 + bit - 1;                         // C0 + occ(c,Ep) - 1
                 t.n++;
