@@ -41,9 +41,10 @@ def synth_genome(n, seed):
     return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)]
 
 
-def synth_reads(ref, n, length, seed, max_subs):
+def synth_reads(ref, n, length, seed, max_subs, indel_p=0.0):
     """uniform start, exactly k substitutions with k uniform in 0..max_subs (a substituted
-    base always differs from the original).  Generated in slices to bound host memory."""
+    base always differs from the original); with probability indel_p one insertion or deletion of 1-5 bp.
+    Generated in slices to bound host memory."""
     rng = np.random.default_rng(seed)
     out = np.empty(n * length, np.uint8)
     code = np.zeros(256, np.uint8)
@@ -52,8 +53,22 @@ def synth_reads(ref, n, length, seed, max_subs):
     step = 1 << 20
     for lo in range(0, n, step):
         m = min(step, n - lo)
-        starts = rng.integers(0, len(ref) - length + 1, size=m, dtype=np.int64)
-        blk = ref[starts[:, None] + np.arange(length, dtype=np.int64)[None, :]]
+        starts = rng.integers(0, len(ref) - length - 8, size=m, dtype=np.int64)
+        if indel_p:
+            # column j of a read copies reference offset j + shift[j]: +k after a deletion of k ref bases, and an
+            # insertion of k read bases re-reads k reference bases later on (the inserted bases are then randomised)
+            has = rng.random(m) < indel_p
+            k = rng.integers(1, 6, size=m) * has
+            at = rng.integers(10, length - 10, size=m)
+            dele = rng.random(m) < 0.5
+            cols = np.arange(length, dtype=np.int64)[None, :]
+            after = cols >= at[:, None]
+            shift = np.where(dele[:, None], after * k[:, None], -np.minimum(np.maximum(cols - at[:, None], 0), k[:, None]))
+            blk = ref[starts[:, None] + cols + shift]
+            ins = (~dele[:, None]) & (cols >= at[:, None]) & (cols < (at + k)[:, None])
+            blk[ins] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(ins.sum()), dtype=np.uint8)]
+        else:
+            blk = ref[starts[:, None] + np.arange(length, dtype=np.int64)[None, :]]
         if max_subs:
             k = rng.integers(0, max_subs + 1, size=m)
             for s in range(max_subs):
@@ -133,7 +148,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="grch38", choices=["grch38", "chr1", "config2", "config2-align"])
+    ap.add_argument("--workload", default="grch38", choices=["grch38", "chr1", "paired150", "config2", "config2-align"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the workload's own)")
     ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,23 +190,28 @@ def main():
         desc = ("BASELINE configs[1]: bundled GL000193.1_p1 index, %d exact-match 100 bp reads per GPU, %s"
                 % (n_reads, "whole path" if stages == lib.STAGE_EXTEND else "FM backward-search stage only"))
     else:
-        glen = args.genome_len or (3_100_000_000 if wl == "grch38" else 230_000_000)
-        n_reads = args.reads or (12_500_000 if wl == "grch38" else 10_000_000)
+        if wl == "paired150":
+            length = 150
+        glen = args.genome_len or (230_000_000 if wl == "chr1" else 3_100_000_000)
+        n_reads = args.reads or (10_000_000 if wl == "chr1" else 12_500_000)
         t0 = time.perf_counter()
-        ref = synth_genome(glen, seed=5 if wl == "grch38" else 3)
+        ref = synth_genome(glen, seed=3 if wl == "chr1" else 5)
         log("rank %d: synthetic genome of %d bp in %.1f s" % (rank, glen, time.perf_counter() - t0))
         t0 = time.perf_counter()
         ix = lib.Index.build(ref, shift=1, device=local_rank)
         log("rank %d: FM index built on the GPU in %.1f s (%s)" % (rank, time.perf_counter() - t0, ix.device_bytes()))
         t0 = time.perf_counter()
-        bases, off = synth_reads(ref, n_reads, length, seed=(5 if wl == "grch38" else 4) * 1000 + rank, max_subs=2)
+        bases, off = synth_reads(ref, n_reads, length, seed={"grch38": 5, "chr1": 4, "paired150": 6}[wl] * 1000 + rank,
+                                 max_subs=2, indel_p=0.2 if wl == "paired150" else 0.0)
         log("rank %d: %d reads in %.1f s" % (rank, n_reads, time.perf_counter() - t0))
         stages = lib.STAGE_EXTEND
         desc = ("BASELINE configs[%d]: %s synthetic i.i.d. ACGT genome of %d bp (no GRCh38 FASTA offline), FM index "
-                "(%d rows) built on the GPU and resident in HBM, %d reads of 100 bp per GPU per step with 0/1/2 "
-                "substitutions (p=1/3 each), seed search + clustering + SW extension + CIGAR"
-                % (3 if wl == "grch38" else 2, "whole-GRCh38-scale" if wl == "grch38" else "chr1-scale", glen,
-                   glen + 1, n_reads))
+                "(%d rows) built on the GPU and resident in HBM, %d reads of %d bp per GPU per step with 0/1/2 "
+                "substitutions (p=1/3 each)%s, seed search + clustering + SW extension + CIGAR"
+                % ({"grch38": 3, "chr1": 2, "paired150": 4}[wl], "chr1-scale" if wl == "chr1" else "whole-GRCh38-scale",
+                   glen, glen + 1, n_reads, length,
+                   " and one indel of 1-5 bp with p=0.2 (2x150 bp mates aligned independently, as the reference does)"
+                   if wl == "paired150" else ""))
 
     batch = lib.Batch(ix)
     batch.set_reads(bases, off)                         # resident in HBM before the timed region

@@ -196,7 +196,7 @@ struct bwt_batch {
     // tasks
     DevBuf t_def, t_sp, t_ep, t_info, t_cnt;
     // reads
-    DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, seed_off, clus_off, hit_off, cigb_off;
+    DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
     // candidates
     uint64_t n_cand = 0;
@@ -304,7 +304,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
     prof_collect(b);
     for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
     DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
-                     &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->seed_off, &b->clus_off, &b->hit_off,
+                     &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->h_rec, &b->h_woff, &b->h_wlen,
@@ -423,6 +423,7 @@ static int stage_cluster(bwt_batch *b) {
     int rc;
     if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
         (rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->bigq.ensure((size_t)n * 4 + 4)) ||
+        (rc = b->mid2q.ensure((size_t)n * 4 + 4)) || (rc = b->mid4q.ensure((size_t)n * 4 + 4)) ||
         (rc = b->seed_off.ensure(((size_t)n + 1) * 8)) || (rc = b->clus_off.ensure(((size_t)n + 1) * 8)))
         return rc;
     if (n == 0) {
@@ -432,7 +433,7 @@ static int stage_cluster(bwt_batch *b) {
     }
     KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
             b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
-            b->ctr.as<Counters>());
+            b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>());
     if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
     uint64_t total_seeds = 0;
     HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
@@ -444,6 +445,16 @@ static int stage_cluster(bwt_batch *b) {
             b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
             b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
             b->r_K.as<uint32_t>());
+    if (b->hctr.n_mid2)
+        KLAUNCH(b, "cluster_wave2", k_cluster_wave<2>, cdiv((uint64_t)b->hctr.n_mid2 * 64, 256), 256, b->ix->d, b->hctr.n_mid2,
+                b->mid2q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
+                b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
+                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>());
+    if (b->hctr.n_mid4)
+        KLAUNCH(b, "cluster_wave4", k_cluster_wave<4>, cdiv((uint64_t)b->hctr.n_mid4 * 64, 256), 256, b->ix->d, b->hctr.n_mid4,
+                b->mid4q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
+                b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
+                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>());
     if (b->hctr.n_big)
         KLAUNCH(b, "cluster_big", k_cluster_big, b->hctr.n_big, 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),

@@ -26,6 +26,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
     return v;
 }
+// queue append with ONE atomic per wave: the lanes whose `pred` holds get consecutive slots.
+// Must be reached by every active lane of the wave that could append in this iteration (the ballot covers
+// the currently active lanes only, so divergent callers still work: each divergent group does its own atomic).
+__device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (!m) return 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
 __device__ __forceinline__ bool is_acgt(uint32_t c) {
     uint32_t i = c - 'A';   // A=0 C=2 G=6 T=19
     return i < 20u && ((0x80045u >> i) & 1u);
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(256) void k_seed_list(DevIndex ix, uint64_t n_tasks
 __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, const uint32_t *__restrict__ t_info,
                                                       const uint32_t *__restrict__ t_cnt, uint32_t *__restrict__ r_P,
                                                       uint32_t *__restrict__ r_qty, uint32_t *__restrict__ bigq,
-                                                      Counters *ctr) {
+                                                      uint32_t *__restrict__ mid2q, uint32_t *__restrict__ mid4q, Counters *ctr) {
     // grid-stride (capped grid): one counter atomic per wave for the whole launch, not per 64 reads
     unsigned long long Psum = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
@@ -339,7 +352,13 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
         if (P > 0x7fffffffull) { atomicOr(&ctr->err_flags, 1ull); P = 0; }
         r_P[r] = (uint32_t)P;
         r_qty[r] = qty | (crash << 31);
-        if (P > 64 || (P > 0 && maxT > 64)) bigq[atomicAdd(&ctr->n_big, 1u)] = r;
+        {
+            const bool big = P > 256 || (P > 0 && maxT > 64), m4 = !big && P > 128, m2 = !big && !m4 && P > 64;
+            const uint32_t ib = wave_append(&ctr->n_big, big), i4 = wave_append(&ctr->n_mid4, m4), i2 = wave_append(&ctr->n_mid2, m2);
+            if (big) bigq[ib] = r;
+            if (m4) mid4q[i4] = r;
+            if (m2) mid2q[i2] = r;
+        }
         Psum += P;
     }
     unsigned long long s = wave_sum_u64(Psum);
@@ -425,6 +444,133 @@ __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, 
         pos[o + 1] = p - pfirst;
     }
     if (lane == 0) r_K[r] = (uint32_t)__popcll(emask);
+}
+
+// k_cluster_wave<R>: wave per read with 64 < P <= 64*R seeds (R = 2, 4; 150 bp reads on a large index sit
+// here).  Same algorithm as k_cluster_small with R elements per lane, element e = r*64 + lane: bitonic
+// strides >= 64 are register-to-register exchanges, smaller strides are lane shuffles; run starts and
+// emitters carry across the R chunks as wave-uniform scalars.
+template <int R>
+__global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, const uint32_t *__restrict__ queue,
+                                                       uint32_t maxT, const uint32_t *__restrict__ t_def,
+                                                       const uint32_t *__restrict__ t_sp,
+                                                       const uint32_t *__restrict__ t_info,
+                                                       const uint32_t *__restrict__ t_cnt,
+                                                       const uint32_t *__restrict__ r_P,
+                                                       const uint32_t *__restrict__ r_qty,
+                                                       const uint64_t *__restrict__ seed_off,
+                                                       uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+    constexpr int N = 64 * R;
+    __shared__ uint32_t lds[4][2 * N];
+    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (w >= nq) return;
+    const uint32_t r = queue[w];
+    const uint32_t P = r_P[r];
+    const uint32_t qty = r_qty[r] & 0x7fffffffu;
+    uint32_t *mk = lds[threadIdx.x >> 6], *srt = mk + N;
+    uint32_t cnt = 0, sp = 0, nadd = 0;
+    if (lane < maxT) {
+        const uint64_t t = (uint64_t)r * maxT + lane;
+        cnt = t_cnt[t]; sp = t_sp[t];
+        nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);   // N + Shift + Skip (sga.erl:32,37-39)
+    }
+    uint32_t incl = cnt;
+    for (uint32_t o = 1; o < maxT; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const uint32_t excl = incl - cnt;
+#pragma unroll
+    for (int q = 0; q < R; q++) mk[q * 64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < maxT && cnt) mk[excl] = lane + 1;           // excl < P <= 64*R
+    __builtin_amdgcn_wave_barrier();
+    uint32_t p[R];
+    {
+        uint32_t carry_tid = 0, carry_start = 0;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const uint32_t tk = mk[q * 64 + lane];
+            const unsigned long long tmask = __ballot(tk != 0);
+            const unsigned long long tb = tmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+            uint32_t tid = carry_tid, start = carry_start;
+            const int s0 = 63 - __clzll(tb | 1ull);
+            const uint32_t tid_here = __shfl(tk, s0, 64);
+            if (tb) { tid = tid_here; start = (uint32_t)(q * 64 + s0); }
+            if (tmask) {
+                const int top = 63 - __clzll(tmask);
+                carry_tid = (uint32_t)__builtin_amdgcn_readlane((int)tk, top);
+                carry_start = (uint32_t)(q * 64 + top);
+            }
+            const uint32_t i = (uint32_t)(q * 64) + lane;
+            const uint32_t msp = __shfl(sp, (int)tid - 1, 64), madd = __shfl(nadd, (int)tid - 1, 64);
+            p[q] = i < P ? ix.sa[msp - 1 + (i - start)] + madd : 0xffffffffu;
+        }
+    }
+    // bitonic sort ascending over N = 64*R elements, element e = q*64 + lane
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    if (q & (j / 64)) continue;
+                    const int q2 = q + j / 64;
+                    const bool up = ((q * 64) & k) == 0;          // k >= 128 here: decided by the chunk index
+                    const uint32_t a = p[q], b = p[q2];
+                    const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+                    p[q] = up ? mn : mx; p[q2] = up ? mx : mn;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const uint32_t o = __shfl_xor(p[q], j, 64);
+                    const bool up = k >= 64 ? (((q * 64) & k) == 0) : ((lane & k) == 0);
+                    const bool lower = (lane & j) == 0;
+                    const uint32_t mn = p[q] < o ? p[q] : o, mx = p[q] < o ? o : p[q];
+                    p[q] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) srt[q * 64 + lane] = p[q];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nthr = 2 + qty / 7;                    // sga.erl:46
+    // pass 1: run starts, emit flags per chunk (ascending), carrying the last run start across chunks
+    unsigned long long emask[R];
+    uint32_t s_of[R];
+    {
+        uint32_t carry_s = 0;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const uint32_t e = (uint32_t)(q * 64) + lane;
+            const uint32_t prev = e ? srt[e - 1] : 0u, next = e + 1 < (uint32_t)N ? srt[e + 1] : 0xffffffffu;
+            const bool valid = e < P;
+            const bool start = valid && (e == 0 || p[q] - prev > BWT_TOLERANCE);
+            const bool end = valid && (e == P - 1 || next - p[q] > BWT_TOLERANCE);
+            const unsigned long long smask = __ballot(start);
+            const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+            uint32_t s_e = carry_s;
+            if (below) s_e = (uint32_t)(q * 64 + (63 - __clzll(below)));
+            if (smask) carry_s = (uint32_t)(q * 64 + (63 - __clzll(smask)));
+            s_of[q] = s_e;
+            emask[q] = __ballot(end && (e - s_e + 1 >= nthr));
+        }
+    }
+    // pass 2: output in descending position order: rank = emitters above me
+    uint32_t above = 0;
+#pragma unroll
+    for (int q = R - 1; q >= 0; q--) {
+        const bool emit = (emask[q] >> lane) & 1ull;
+        if (emit) {
+            const uint32_t kk = above + (uint32_t)__popcll(lane == 63 ? 0ull : (emask[q] >> (lane + 1)));
+            const uint64_t o = seed_off[r] + 2ull * kk;
+            pos[o] = p[q];
+            pos[o + 1] = p[q] - srt[s_of[q]];
+        }
+        above += (uint32_t)__popcll(emask[q]);
+    }
+    if (lane == 0) r_K[r] = above;
 }
 
 // k_cluster_big: workgroup per read (P > 64): gather into the read's slice of `pos`, sort it
@@ -777,67 +923,72 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
     const uint32_t *qn = io.qplanes + RP_N * io.qpw, *qx = io.qplanes + RP_O * io.qpw;
     const uint32_t *wlo = io.wplanes + RP_LO * io.wpw, *whi = io.wplanes + RP_HI * io.wpw;
     const uint32_t *wn = io.wplanes + RP_N * io.wpw, *wx = io.wplanes + RP_O * io.wpw;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_items; c += gridDim.x * blockDim.x) {
-        const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
-        const int64_t wo = io.c_woff[c];
-        const uint64_t qo = io.c_qoff[c];
-        if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
-            io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
-            continue;
-        }
-        uint32_t bad = 0;
-        for (uint32_t i = 0; i < lq; i += 32) {
-            uint32_t m = plane_bits(qn, qo + i) | plane_bits(qx, qo + i);
-            if (lq - i < 32) m &= (1u << (lq - i)) - 1u;
-            bad |= m;
-        }
-        for (uint32_t i = 0; i < w; i += 32) {
-            uint32_t m = plane_bits(wn, (uint64_t)wo + i) | plane_bits(wx, (uint64_t)wo + i);
-            if (w - i < 32) m &= (1u << (w - i)) - 1u;
-            bad |= m;
-        }
-        if (bad) {
-            io.c_status[c] = CS_NEED_FP;
-            io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = c;
-            continue;
-        }
-        bool done = false;
-        int score = 2 * (int)lq;
-        if (w == lq) {
-            // square window: one full diagonal.  With <= 1 mismatch on it (loss <= 3) it is the unique optimum:
-            // any other path into the last row needs an insertion (gap -2 and a lost match -2: loss >= 4).
-            uint32_t mism = 0;
-            for (uint32_t i = 0; i < lq && mism <= 1; i += 32) {
-                uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
-                             (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + i));
-                if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
-                mism += __popc(e);
-            }
-            done = mism <= 1 && lq >= 8;
-            score -= 3 * (int)mism;
-        } else if (w > lq && w - lq <= 64) {
-            for (uint32_t d = 0; d + lq <= w && !done; d++) {
-                bool all = true;
-                for (uint32_t i = 0; i < lq && all; i += 32) {
-                    uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + d + i)) |
-                                 (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + d + i));
-                    if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
-                    all = e == 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); c0 < n_items; c0 += stride) {   // whole waves iterate together
+        const uint32_t c = c0 + (threadIdx.x & 63);
+        int route = 0;                 // 0 nothing (idle / out of range / settled), 1 fp64 queue, 2 DP queue
+        if (c < n_items) {
+            const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
+            const int64_t wo = io.c_woff[c];
+            const uint64_t qo = io.c_qoff[c];
+            if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
+                io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
+            } else {
+                uint32_t bad = 0;
+                for (uint32_t i = 0; i < lq; i += 32) {
+                    uint32_t m = plane_bits(qn, qo + i) | plane_bits(qx, qo + i);
+                    if (lq - i < 32) m &= (1u << (lq - i)) - 1u;
+                    bad |= m;
                 }
-                done = all;
+                for (uint32_t i = 0; i < w; i += 32) {
+                    uint32_t m = plane_bits(wn, (uint64_t)wo + i) | plane_bits(wx, (uint64_t)wo + i);
+                    if (w - i < 32) m &= (1u << (w - i)) - 1u;
+                    bad |= m;
+                }
+                if (bad) { io.c_status[c] = CS_NEED_FP; route = 1; }
+                else {
+                    bool done = false;
+                    int score = 2 * (int)lq;
+                    if (w == lq) {
+                        // square window: one full diagonal.  With <= 1 mismatch on it (loss <= 3) it is the unique optimum:
+                        // any other path into the last row needs an insertion (gap -2 and a lost match -2: loss >= 4).
+                        uint32_t mism = 0;
+                        for (uint32_t i = 0; i < lq && mism <= 1; i += 32) {
+                            uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
+                                         (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + i));
+                            if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                            mism += __popc(e);
+                        }
+                        done = mism <= 1 && lq >= 8;
+                        score -= 3 * (int)mism;
+                    } else if (w > lq && w - lq <= 64) {
+                        for (uint32_t d = 0; d + lq <= w && !done; d++) {
+                            bool all = true;
+                            for (uint32_t i = 0; i < lq && all; i += 32) {
+                                uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + d + i)) |
+                                             (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + d + i));
+                                if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                                all = e == 0;
+                            }
+                            done = all;
+                        }
+                    }
+                    if (!done) { io.c_status[c] = CS_PENDING; route = 2; }
+                    else {
+                        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+                        int p = (int)io.cig_stride, len = 0;
+                        cig_emit(slot, p, len, lq, 'M');
+                        io.c_score[c] = score;
+                        io.c_ciglen[c] = (uint32_t)len;
+                        io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                    }
+                }
             }
         }
-        if (!done) {
-            io.c_status[c] = CS_PENDING;
-            io.dq[atomicAdd(&io.ctr->dq_count, 1u)] = c;
-            continue;
-        }
-        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
-        int p = (int)io.cig_stride, len = 0;
-        cig_emit(slot, p, len, lq, 'M');
-        io.c_score[c] = score;
-        io.c_ciglen[c] = (uint32_t)len;
-        io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+        // one atomic per wave and queue
+        const uint32_t ifp = wave_append(&io.ctr->fp_count, route == 1), idq = wave_append(&io.ctr->dq_count, route == 2);
+        if (route == 1) io.fpq[ifp] = c;
+        if (route == 2) io.dq[idq] = c;
     }
 }
 
