@@ -203,7 +203,7 @@ struct bwt_batch {
     DevBuf c_read, c_S, c_D, c_qoff, c_qlen, c_woff, c_wlen, c_status, c_score, c_ciglen, cig, fpq;
     uint32_t cig_stride = 32;
     // sw slabs
-    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, tq, dq;
+    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig;
@@ -307,7 +307,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -489,14 +489,14 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     int rc;
     if ((rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) ||
         (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)) || (rc = b->tq.ensure(nc * 4 + 4)) ||
-        (rc = b->dq.ensure(nc * 4 + 4)))
+        (rc = b->dq.ensure(nc * 4 + 4)) || (rc = b->tq2.ensure(nc * 4 + 4)))
         return rc;
     if (nc == 0) return 0;
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, b->device);
     if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
-    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 12, b->stream));     // fp_count, tq_count, dq_count
+    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
     io.c_qoff = b->c_qoff.as<uint64_t>(); io.c_qlen = b->c_qlen.as<uint32_t>();
@@ -504,7 +504,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
-    io.dq = nullptr; io.qplanes = qplanes; io.wplanes = wplanes; io.qpw = qpw; io.wpw = wpw;
+    io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.qpw = qpw; io.wpw = wpw;
     static const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
     if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
         io.dq = b->dq.as<uint32_t>();
@@ -527,11 +527,29 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         const uint64_t lds_pk = (uint64_t)(2 * ((wcap + 31) / 32) + 2 * qw) * 64 * 4 * 2 * 4;     // 2 sets x 4 waves
         const uint32_t per_cu = 2;                                                             // VGPR-limited (181 / 247 VGPRs)
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * per_cu);
-        ProfScope ps(b, "sw_extend");
-        if (max_lq == 100)
-            hipLaunchKernelGGL(k_sw_score_pk<100>, dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap);
-        else
-            hipLaunchKernelGGL(k_sw_score_pk<150>, dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap);
+        {
+            ProfScope ps(b, "sw_extend");
+            if (max_lq == 100)
+                hipLaunchKernelGGL((k_sw_pk<100, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
+                                   (uint32_t *)nullptr, 0u);
+            else
+                hipLaunchKernelGGL((k_sw_pk<150, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
+                                   (uint32_t *)nullptr, 0u);
+        }
+        // packed traceback pass over the alignments that are not the plain diagonal: per-wave direction slab
+        const uint32_t ndg = (max_lq + 7) / 8, w1 = wcap + 1;
+        const uint64_t per_wave_pk = (uint64_t)w1 * ndg * 64 * 4;
+        uint32_t tblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (4ull << 30) / (per_wave_pk * 4)));
+        if ((rc = b->slab_dir_pk.ensure((uint64_t)tblocks * 4 * per_wave_pk))) return rc;
+        {
+            ProfScope ps(b, "sw_trace_pk");
+            if (max_lq == 100)
+                hipLaunchKernelGGL((k_sw_pk<100, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
+                                   b->slab_dir_pk.as<uint32_t>(), w1);
+            else
+                hipLaunchKernelGGL((k_sw_pk<150, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
+                                   b->slab_dir_pk.as<uint32_t>(), w1);
+        }
     } else if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
         static const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
@@ -651,7 +669,8 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
         counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
-        counts->n_float = b->hctr.fp_count; counts->n_traced = b->hctr.tq_count; counts->n_dp = b->hctr.dq_count;
+        counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
+        counts->n_dp = b->hctr.dq_count;
     }
     return 0;
 }

@@ -738,6 +738,7 @@ struct SwIO {
     uint32_t *fpq;             // queue of candidates for the fp64 kernel
     uint32_t *tq;              // queue of candidates that need a real traceback
     uint32_t *dq;              // queue of candidates that need the DP at all (filled by k_sw_prefilter)
+    uint32_t *tq2;             // traceback queue of the packed kernels (same read length, window <= cap)
     const uint32_t *qplanes, *wplanes;   // bit-planes over qbuf / rbuf (k_read_planes layout)
     uint64_t qpw, wpw;
     Counters *ctr;
@@ -1166,9 +1167,13 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
     return d;
 }
 
-template <int LQ>
-__global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, uint32_t wcap) {
-    constexpr int QW = (LQ + 31) / 32, NG = (LQ + 15) / 16;
+// TRACE = false: score pass over the DP queue (non-diagonal alignments go on to io.tq2).
+// TRACE = true : the same DP over io.tq2 that also keeps the 2-bit direction of every cell (8 rows of both
+//                alignments per dword, [column][row group][lane] in a per-wave HBM slab) and walks the traceback.
+template <int LQ, bool TRACE>
+__global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32_t wcap, uint32_t *__restrict__ slab_dir,
+                                               uint32_t maxW1) {
+    constexpr int QW = (LQ + 31) / 32, NG = (LQ + 15) / 16, NDG = (LQ + 7) / 8;   // NDG: direction dwords per column
     extern __shared__ uint32_t lds_sw[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -1177,7 +1182,9 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
     const uint32_t set_words = (2 * PW + 2 * QW) * 64;                      // one set = 64 candidates
     uint32_t *pl = lds_sw + (uint64_t)(threadIdx.x >> 6) * 2 * set_words;
 
-    if (io.dq) n_items = io.ctr->dq_count;
+    const uint32_t *const queue = TRACE ? io.tq2 : io.dq;
+    if (TRACE) n_items = io.ctr->tq2_count; else if (io.dq) n_items = io.ctr->dq_count;
+    uint32_t *const dirs = TRACE ? slab_dir + (uint64_t)wave * maxW1 * NDG * 64 + lane : nullptr;   // [(j*NDG + g)*64]
     for (uint32_t g = wave; (uint64_t)g * 128 < n_items; g += nwaves) {
         uint32_t cc[2], lq[2], w[2];
         int64_t wo[2];
@@ -1189,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
             cc[h] = 0;
             lq[h] = 0; w[h] = 0; wo[h] = 0; qo[h] = 0; state[h] = 1;
             if (item < n_items) {
-                cc[h] = io.dq ? io.dq[item] : item;
+                cc[h] = queue ? queue[item] : item;
                 lq[h] = io.c_qlen[cc[h]]; w[h] = io.c_wlen[cc[h]]; wo[h] = io.c_woff[cc[h]]; qo[h] = io.c_qoff[cc[h]];
                 if (wo[h] < 0 || (uint64_t)wo[h] + w[h] > io.rbuf_len || w[h] == 0 || lq[h] == 0) state[h] = 2;
                 else if (w[h] > wcap || lq[h] != (uint32_t)LQ) state[h] = 3;
@@ -1235,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (state[h] == 2) { io.c_status[cc[h]] = CS_WINDOW_OOR; io.c_ciglen[cc[h]] = 0; }
-            else if (state[h] == 3) { io.c_status[cc[h]] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = cc[h]; }
+            else if (state[h] == 3) { io.c_status[cc[h]] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = cc[h]; }   // generic trace kernel
             else if (state[h] == 4) { io.c_status[cc[h]] = CS_NEED_FP; io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = cc[h]; }
         }
         const bool runA = state[0] == 0, runB = state[1] == 0;
@@ -1277,6 +1284,7 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
             for (int m = 0; m < NG; m++) e2[m] = ~((q2lo[m] ^ rl2) | (q2hi[m] ^ rh2));   // bit: row matches this column
             uint32_t dbase = 0;                              // row 0, column j-1: V = 0
             uint32_t cu = KM14;                              // row 0 as the up source: 8*(-2) + 2
+            uint32_t dacc = 0;
 #pragma unroll
             for (int t = 0; t < LQ; t++) {
                 const uint32_t old = H[t];
@@ -1288,6 +1296,10 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
                 H[t] = h;
                 dbase = base_o;
                 cu = pk_add(pk_mad(h & 0x00020002u, K4, h & 0xFFF8FFF8u), KM14);
+                if (TRACE) {        // one-hot 1/2/4 -> 0/1/2 (left/up/up_left), 8 rows per 16-bit half, newest in the low bits
+                    dacc = ((dacc << 2) & 0xFFFCFFFCu) | ((h >> 1) & 0x00030003u);
+                    if ((t & 7) == 7 || t == LQ - 1) { dirs[((uint64_t)j * NDG + (t >> 3)) * 64] = dacc; dacc = 0; }
+                }
             }
             const uint32_t lastp = H[LQ - 1];
             const int vA = (int)(int16_t)(lastp & 0xffffu) >> 3, vB = (int)lastp >> 19;
@@ -1303,6 +1315,36 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
             const uint32_t bestj = h ? bestjB : bestjA;
             if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; continue; }
             const uint32_t *wlo = h ? wloB : wloA, *whi = h ? whiB : whiA, *qlo = h ? qloB : qloA, *qhi = h ? qhiB : qhiA;
+            uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+            int p = (int)io.cig_stride, len = 0;
+            if (TRACE) {
+                // traceback (sw.erl:116-160) from the leftmost maximum of the last row up to row 0
+                uint32_t i = LQ, j = bestj;
+                int runop = -1; uint32_t runlen = 0;
+                for (;;) {
+                    int code = -1;
+                    if (i > 0) {
+                        if (j == 0) code = DIR_UP;
+                        else {
+                            const uint32_t t = i - 1, grp = t >> 3;
+                            const uint32_t rows = (grp == (uint32_t)(NDG - 1)) ? (uint32_t)(LQ - 8 * (NDG - 1)) : 8u;
+                            const uint32_t wd = dirs[((uint64_t)j * NDG + grp) * 64];
+                            code = (int)((wd >> (16 * h + 2 * (rows - 1 - (t & 7)))) & 3u);
+                        }
+                    }
+                    if (code == runop) { runlen++; }
+                    else {
+                        if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
+                        runop = code; runlen = 1;
+                    }
+                    if (code < 0) break;
+                    if (code == DIR_UL) { i--; j--; } else if (code == DIR_UP) i--; else j--;
+                }
+                io.c_score[c] = score;
+                io.c_ciglen[c] = (uint32_t)len;
+                io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                continue;
+            }
             bool diag = bestj >= (uint32_t)LQ;
             if (diag) {                                      // pure diagonal ending at (Lq, bestj)?
                 const uint32_t shd = bestj - LQ;
@@ -1318,9 +1360,7 @@ __global__ __launch_bounds__(256) void k_sw_score_pk(SwIO io, uint32_t n_items, 
                 }
                 diag = (3 * m - LQ) == score;
             }
-            if (!diag) { io.c_status[c] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c; continue; }
-            uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
-            int p = (int)io.cig_stride, len = 0;
+            if (!diag) { io.c_status[c] = CS_PENDING; io.tq2[atomicAdd(&io.ctr->tq2_count, 1u)] = c; continue; }
             cig_emit(slot, p, len, LQ, 'M');
             io.c_score[c] = score;
             io.c_ciglen[c] = (uint32_t)len;

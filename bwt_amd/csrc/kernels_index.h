@@ -97,6 +97,6 @@ __device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plan
 
 struct Counters {          // device-side work counters (roofline accounting)
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags;
-    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, n_mid2, n_mid4;
+    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, pad_;
 };
 
