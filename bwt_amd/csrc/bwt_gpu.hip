@@ -180,6 +180,45 @@ extern "C" int bwt_ref1_read(const bwt_index *ix, uint64_t off, uint64_t len, ui
     return 0;
 }
 
+__global__ __launch_bounds__(256) static void k_ref1_gather(const uint8_t *__restrict__ ref1, const int64_t *__restrict__ woff,
+                                                             const uint64_t *__restrict__ ooff, uint64_t n, uint8_t *__restrict__ out) {
+    // wave per window: coalesced byte copies
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (w >= n) return;
+    const uint64_t o = ooff[w], len = ooff[w + 1] - o;
+    const uint8_t *src = ref1 + woff[w];
+    for (uint64_t i = lane; i < len; i += 64) out[o + i] = src[i];
+}
+
+extern "C" int bwt_ref1_gather(const bwt_index *ix, const int64_t *win_off, const int32_t *win_len, uint64_t n, uint8_t *outp,
+                               uint64_t out_cap, uint64_t *out_off, uint64_t *needed) {
+    if (!ix || (!win_off && n) || (!win_len && n) || !out_off) return fail(BWT_EINVAL, "bwt_ref1_gather: null argument");
+    uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (win_off[i] < 0 || win_len[i] < 0 || (uint64_t)win_off[i] + (uint64_t)win_len[i] > ix->ref1_len)
+            return fail(BWT_EINVAL, "bwt_ref1_gather: window outside Ref1");
+        out_off[i] = tot; tot += (uint64_t)win_len[i];
+    }
+    out_off[n] = tot;
+    if (needed) *needed = tot;
+    if (tot > out_cap || (!outp && tot)) return fail(BWT_ENOSPC, "RefSeq capacity too small");
+    if (!n || !tot) return 0;
+    HIPCHK(hipSetDevice(ix->device));
+    DevBuf dwo, doo, dout;
+    struct G { DevBuf &a, &b, &c; ~G() { a.release(); b.release(); c.release(); } } g{dwo, doo, dout};
+    int rc;
+    if ((rc = dwo.ensure(n * 8)) || (rc = doo.ensure((n + 1) * 8)) || (rc = dout.ensure(tot))) return rc;
+    HIPCHK(hipMemcpyAsync(dwo.p, win_off, n * 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(doo.p, out_off, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+    hipLaunchKernelGGL(k_ref1_gather, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, ix->stream, ix->ref1.as<uint8_t>(),
+                       dwo.as<int64_t>(), doo.as<uint64_t>(), n, dout.as<uint8_t>());
+    HIPCHK(hipMemcpyAsync(outp, dout.p, tot, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct KernelStat { double ms = 0; uint64_t launches = 0; };
 

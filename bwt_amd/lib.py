@@ -16,7 +16,7 @@ EXPORTS = [
     "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
-    "bwt_build_index", "bwt_index_save", "bwt_index_export", "bwt_fastq_open", "bwt_fastq_close", "bwt_fastq_read_seqs",
+    "bwt_build_index", "bwt_index_save", "bwt_index_export", "bwt_fastq_open", "bwt_fastq_close", "bwt_fastq_read_seqs", "bwt_ref1_gather",
 ]
 
 
@@ -173,6 +173,18 @@ class Index:
         out = np.empty(length, np.uint8)
         _chk(load().bwt_ref1_read(self.h, C.c_uint64(off), C.c_uint64(length), _p(out)))
         return out.tobytes()
+
+    def ref1_gather(self, win_off, win_len):
+        """RefSeq of many hits in one call -> list of bytes."""
+        win_off = np.ascontiguousarray(win_off, np.int64); win_len = np.ascontiguousarray(win_len, np.int32)
+        n = len(win_off)
+        ooff = np.empty(n + 1, np.uint64)
+        need = C.c_uint64(0)
+        out = np.empty(int(win_len.sum()) + 1, np.uint8)
+        _chk(load().bwt_ref1_gather(self.h, _p(win_off), _p(win_len), C.c_uint64(n), _p(out), C.c_uint64(len(out)),
+                                    _p(ooff), C.byref(need)))
+        raw = out.tobytes()
+        return [raw[int(ooff[i]):int(ooff[i + 1])] for i in range(n)]
 
     # ---- host-buffer entry points -------------------------------------------------------------
     def find_seeds_batch(self, bases, off):

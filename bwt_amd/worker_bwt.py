@@ -25,6 +25,7 @@ def align_batch(fm, qseq_list):
     reads = [bytes(s) for _, s in qseq_list]
     bases, off = lib.pack_reads(reads)
     out = fm.index.align_batch(bases, off)
+    refseqs = fm.index.ref1_gather(out["win_off"], out["win_len"])         # RefSeq of every hit in one call
     res = []
     for i, (name, _) in enumerate(qseq_list):
         st = int(out["read_status"][i])
@@ -37,8 +38,7 @@ def align_batch(fm, qseq_list):
         cig = []
         for h in range(int(out["hit_off"][i]), int(out["hit_off"][i + 1])):
             text = out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode()
-            refseq = fm.index.ref1(int(out["win_off"][h]), int(out["win_len"][h]))
-            cig.append(((int(out["score"][h]), text), int(out["pos"][h]), refseq))
+            cig.append(((int(out["score"][h]), text), int(out["pos"][h]), refseqs[h]))
         res.append(cig)
     return res
 

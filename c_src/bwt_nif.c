@@ -113,6 +113,14 @@ static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM
         coff = malloc(8 * (need[0] + 2)); cig = malloc(need[1] + 1);
         rc = bwt_align_batch(r->ix, bases, off, n, rstat, hoff, score, pos, woff, wlen, coff, cig, need[0], need[1], need);
     }
+    /* RefSeq of every hit in one device gather */
+    uint8_t *wins = NULL; uint64_t *woffs = NULL;
+    if (!rc && need[0]) {
+        uint64_t tot = 0;
+        woffs = malloc(8 * (need[0] + 1));
+        rc = bwt_ref1_gather(r->ix, woff, wlen, need[0], NULL, 0, woffs, &tot);
+        if (rc == BWT_ENOSPC) { wins = malloc(tot + 1); rc = bwt_ref1_gather(r->ix, woff, wlen, need[0], wins, tot, woffs, &tot); }
+    }
     ERL_NIF_TERM out = enif_make_list(env, 0);
     if (rc) out = mk_error(env, rc);
     else {
@@ -124,13 +132,11 @@ static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM
             else {
                 v = enif_make_list(env, 0);
                 for (uint64_t h = hoff[i + 1]; h-- > hoff[i];) {
-                    uint8_t *win = malloc((size_t)wlen[h] + 1);
-                    bwt_ref1_read(r->ix, (uint64_t)woff[h], (uint64_t)wlen[h], win);
+                    const uint8_t *win = wins + woffs[h];
                     ERL_NIF_TERM sc = enif_make_tuple2(env, enif_make_int(env, score[h]),
                         enif_make_string_len(env, cig + coff[h], (size_t)(coff[h + 1] - coff[h]), ERL_NIF_LATIN1));
                     ERL_NIF_TERM t = enif_make_tuple3(env, sc, enif_make_int64(env, pos[h]),
                         enif_make_string_len(env, (char *)win, (size_t)wlen[h], ERL_NIF_LATIN1));
-                    free(win);
                     v = enif_make_list_cell(env, t, v);
                 }
             }
@@ -138,7 +144,7 @@ static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM
         }
     }
     free(names); free(off); free(bases); free(rstat); free(hoff);
-    free(score); free(wlen); free(pos); free(woff); free(coff); free(cig);
+    free(score); free(wlen); free(pos); free(woff); free(coff); free(cig); free(wins); free(woffs);
     return out;
 }
 

@@ -125,6 +125,10 @@ int bwt_align_batch(bwt_index *idx, const uint8_t *bases, const uint64_t *off, u
                     uint64_t hit_cap, uint64_t cig_cap, uint64_t needed[2]);
 /* Ref1 = 200 x 'N' ++ .ref ++ 200 x 'N' (src/worker_bwt.erl:54-55): copy [off, off+len) to out. */
 int bwt_ref1_read(const bwt_index *idx, uint64_t off, uint64_t len, uint8_t *out);
+/* the RefSeq of n hits in one go: windows [win_off[i], win_off[i]+win_len[i]) of Ref1, concatenated into out
+ * (capacity out_cap bytes; out_off[n+1] receives the offsets; BWT_ENOSPC reports the total in *needed) */
+int bwt_ref1_gather(const bwt_index *idx, const int64_t *win_off, const int32_t *win_len, uint64_t n,
+                    uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint64_t *needed);
 
 /* ------------------------------------------------------------------ 8f-2: FASTQ ingest
  * fastq:read_seqs/2 (src/fastq.erl:5-40) on a memory-mapped file, straight into the packed batch layout:
