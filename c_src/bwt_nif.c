@@ -11,7 +11,7 @@
  *   index_meta(Index) -> {Pc,Pg,Pt,Last,Shift}
  *   align_batch(Index, [{Name, Seq}]) ->
  *        [{Name, nothing | {error, Reason} | [{{Score,Cigar}, Pos, RefSeq}]}]      (reference list order)
- * align_batch replaces the two per-read calls of worker_bwt.erl (sga:sga/6 at :76, sw:sw/2 at :92)
+ * align_batch (bwt_batch_set_reads + bwt_batch_run + bwt_batch_fetch_hits) replaces the two per-read calls of worker_bwt.erl (sga:sga/6 at :76, sw:sw/2 at :92)
  * and runs on a dirty IO scheduler (a batch of 200 reads x 10 lists takes well over 1 ms).
  */
 #include <erl_nif.h>
@@ -20,9 +20,13 @@
 #include "bwt_gpu.h"
 
 static ErlNifResourceType *INDEX_RT;
-typedef struct { bwt_index *ix; } index_res;
+typedef struct { bwt_index *ix; bwt_batch *batch; } index_res;   /* one resident batch per index handle */
 
-static void index_dtor(ErlNifEnv *env, void *obj) { (void)env; bwt_index_close(((index_res *)obj)->ix); }
+static void index_dtor(ErlNifEnv *env, void *obj) {
+    (void)env;
+    bwt_batch_destroy(((index_res *)obj)->batch);
+    bwt_index_close(((index_res *)obj)->ix);
+}
 
 static int load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
     (void)priv; (void)info;
@@ -58,7 +62,8 @@ static ERL_NIF_TERM nif_index_open(ErlNifEnv *env, int argc, const ERL_NIF_TERM 
     int rc = bwt_index_open(fm, ref, dev, &ix);
     if (rc) return mk_error(env, rc);
     index_res *r = enif_alloc_resource(INDEX_RT, sizeof *r);
-    r->ix = ix;
+    r->ix = ix; r->batch = NULL;
+    if ((rc = bwt_batch_create(ix, &r->batch))) { enif_release_resource(r); return mk_error(env, rc); }
     ERL_NIF_TERM t = enif_make_resource(env, r);
     enif_release_resource(r);
     return enif_make_tuple2(env, enif_make_atom(env, "ok"), t);
@@ -105,13 +110,19 @@ static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM
     int32_t *rstat = malloc(sizeof(int32_t) * (n ? n : 1));
     uint64_t *hoff = malloc(sizeof(uint64_t) * (n + 1));
     uint64_t need[2] = {0, 0};
-    int rc = bwt_align_batch(r->ix, bases, off, n, rstat, hoff, 0, 0, 0, 0, 0, 0, 0, 0, need);
+    /* resident-batch interface: upload, run the three stages once, then size and fetch the hit tables
+     * (bwt_align_batch's two-call pattern would run the pipeline twice).  One call at a time per handle. */
+    int rc = bwt_batch_set_reads(r->batch, bases, off, n);
+    if (!rc) rc = bwt_batch_run(r->batch, BWT_STAGE_EXTEND, NULL);
     int32_t *score = NULL, *wlen = NULL; int64_t *pos = NULL, *woff = NULL; uint64_t *coff = NULL; char *cig = NULL;
-    if (rc == BWT_ENOSPC) {
-        score = malloc(4 * (need[0] + 1)); wlen = malloc(4 * (need[0] + 1));
-        pos = malloc(8 * (need[0] + 1)); woff = malloc(8 * (need[0] + 1));
-        coff = malloc(8 * (need[0] + 2)); cig = malloc(need[1] + 1);
-        rc = bwt_align_batch(r->ix, bases, off, n, rstat, hoff, score, pos, woff, wlen, coff, cig, need[0], need[1], need);
+    if (!rc) {
+        rc = bwt_batch_fetch_hits(r->batch, rstat, hoff, 0, 0, 0, 0, 0, 0, 0, 0, need);
+        if (rc == BWT_ENOSPC || rc == 0) {
+            score = malloc(4 * (need[0] + 1)); wlen = malloc(4 * (need[0] + 1));
+            pos = malloc(8 * (need[0] + 1)); woff = malloc(8 * (need[0] + 1));
+            coff = malloc(8 * (need[0] + 2)); cig = malloc(need[1] + 1);
+            rc = bwt_batch_fetch_hits(r->batch, rstat, hoff, score, pos, woff, wlen, coff, cig, need[0], need[1], need);
+        }
     }
     /* RefSeq of every hit in one device gather */
     uint8_t *wins = NULL; uint64_t *woffs = NULL;
