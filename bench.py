@@ -129,6 +129,14 @@ def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
            "checksum": int(res[3])}
     if batch is not None and mode == 1:
         out["parity_sample"] = parity_sample(batch, ofm, ref1, bases, off, length)
+        # at-scale parity: the oracle's aggregate over the whole CPU sample (reads with a hit, hits kept,
+        # sum of 31*pos + score) against the same aggregate of the GPU's hit table for those reads
+        hits = batch.fetch_hits()
+        a, b = int(hits["hit_off"][0]), int(hits["hit_off"][n])
+        gpu = [int((np.diff(hits["hit_off"][: n + 1].astype(np.int64)) > 0).sum()), b - a,
+               int((hits["pos"][a:b].astype(np.int64) * 31 + hits["score"][a:b].astype(np.int64)).sum())]
+        cpu = [int(res[0]), int(res[1]), int(res[3])]
+        out["parity_aggregate"] = {"reads": n, "cpu": cpu, "gpu": gpu, "equal": cpu == gpu}
     return out
 
 
