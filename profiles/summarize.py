@@ -15,7 +15,8 @@ dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, wl, "trace_kernel_stats.csv"), os.path.join(dst, wl + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, wl + ".bench.json"), os.path.join(dst, wl + "_bench_under_rocprof.json"))
-short = {"k_search": "k_search", "void k_search<1>": "k_search", "void k_search<2>": "k_search", "void k_sw_score_pk<100>": "k_sw", "void k_sw_score_pk<150>": "k_sw", "k_sw_score": "k_sw",
+short = {"k_search": "k_search", "void k_search<1>": "k_search", "void k_search<2>": "k_search", "void k_sw_score_pk<100>": "k_sw", "void k_sw_score_pk<150>": "k_sw", "void k_sw_pk<100, false>": "k_sw", "void k_sw_pk<150, false>": "k_sw",
+         "void k_sw_pk<100, true>": "k_sw_trace_pk", "void k_sw_pk<150, true>": "k_sw_trace_pk", "void k_cluster_wave<2>": "k_cluster_wave2", "void k_cluster_wave<4>": "k_cluster_wave4", "k_sw_prefilter": "k_sw_prefilter", "k_sw_score": "k_sw",
          "void k_sw<0, false>": "k_sw", "void k_sw<1, false>": "k_sw_trace", "void k_sw<2, false>": "k_sw_fp64",
          "k_cluster_small": "k_cluster_small", "k_subreads": "k_subreads", "k_read_planes": "k_read_planes",
          "k_candidates": "k_candidates", "k_cluster_big": "k_cluster_big", "k_read_counts": "k_read_counts",
