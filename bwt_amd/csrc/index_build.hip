@@ -8,13 +8,12 @@
 //   fmi:get_index_pointers/1  src/fmi.erl:66-76          Pc, Pg, Pt, Last
 // The suffix array of Seq++"$" is unique, so any correct construction reproduces the reference's
 // rows; here: prefix doubling on the GPU (21-symbol packed initial keys, then (rank[i], rank[i+h])
-// pairs), each round one 64-bit LSD radix sort of (key, position) pairs.  The sort itself is
-// rocPRIM's device radix sort (AMD's native primitive library; the builder is an offline tool,
-// not one of the hot kernels).
+// pairs), each round one 64-bit LSD radix sort of (key, position) pairs (radix.hip.h: hand-written
+// histogram / scan / stable scatter, 8 bits per pass).
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "radix.hip.h"
 #include "etf_fm.h"
 
 #include <string>
@@ -157,7 +156,7 @@ extern "C" int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, ui
     int rc = 0;
     bwt_index *ix = new bwt_index();
     ix->device = device;
-    DevBuf d_sym, d_key0, d_key1, d_val0, d_val1, d_rank, d_head, d_tmp, d_cnt, d_scan, d_small;
+    DevBuf d_sym, d_key0, d_key1, d_val0, d_val1, d_rank, d_head, d_tmp, d_cnt, d_scan, d_small, d_hist;
     hipStream_t s = nullptr;
     const uint32_t nblk = (uint32_t)(N / BWT_BLOCK_ROWS) + 1;
     {
@@ -167,39 +166,43 @@ extern "C" int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, ui
             goto done;
         RPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         RPCHK(hipMemcpyAsync(d_sym.p, sym.data(), N + 64, hipMemcpyHostToDevice, s));
-        rocprim::double_buffer<uint64_t> keys(d_key0.as<uint64_t>(), d_key1.as<uint64_t>());
-        rocprim::double_buffer<uint32_t> vals(d_val0.as<uint32_t>(), d_val1.as<uint32_t>());
-        size_t tmp_sort = 0, tmp_scan = 0;
-        RPCHK(rocprim::radix_sort_pairs(nullptr, tmp_sort, keys, vals, N, 0, 64, s));
-        RPCHK(rocprim::inclusive_scan(nullptr, tmp_scan, d_head.as<uint32_t>(), d_head.as<uint32_t>(), N,
-                                      rocprim::maximum<uint32_t>(), s));
-        if ((rc = d_tmp.exact(std::max(tmp_sort, tmp_scan) + 256))) goto done;
+        uint64_t *kk[2] = {d_key0.as<uint64_t>(), d_key1.as<uint64_t>()};
+        uint32_t *vv[2] = {d_val0.as<uint32_t>(), d_val1.as<uint32_t>()};
+        int cur = 0;
+        const uint64_t sort_tiles = (N + RS_TILE - 1) / RS_TILE;
+        const uint64_t tmp_words = std::max(dev_scan_u32_tmp_words(256 * sort_tiles), dev_scan_u32_tmp_words(N));
+        if ((rc = d_hist.exact(256 * sort_tiles * 4)) || (rc = d_tmp.exact(tmp_words * 4))) goto done;
         unsigned long long *d_ng = d_small.as<unsigned long long>();
         const uint32_t gridN = cdiv_u(N, 256);
 
-        hipLaunchKernelGGL(kb_init_keys, dim3(gridN), dim3(256), 0, s, d_sym.as<uint8_t>(), N, keys.current(), vals.current());
+        hipLaunchKernelGGL(kb_init_keys, dim3(gridN), dim3(256), 0, s, d_sym.as<uint8_t>(), N, kk[cur], vv[cur]);
         uint64_t h = 21;
+        // a (rank[i], rank[i+h]+1) pair key holds two numbers <= N + 1: only rank_bits of each half need sorting
+        int rank_bits = 1;
+        while ((1ull << rank_bits) <= N + 1) rank_bits++;
         for (int round = 0; round < 40; round++) {
-            // the initial keys use 63 bits, the pair keys 64
-            RPCHK(rocprim::radix_sort_pairs(d_tmp.p, tmp_sort, keys, vals, N, 0, round == 0 ? 63 : 64, s));
+            if (round == 0) {
+                RPCHK(dev_radix_sort_pairs(kk, vv, &cur, N, 0, 63, d_hist.as<uint32_t>(), d_tmp.as<uint32_t>(), s));   // 21 x 3 bits
+            } else {
+                RPCHK(dev_radix_sort_pairs(kk, vv, &cur, N, 0, rank_bits, d_hist.as<uint32_t>(), d_tmp.as<uint32_t>(), s));
+                RPCHK(dev_radix_sort_pairs(kk, vv, &cur, N, 32, 32 + rank_bits, d_hist.as<uint32_t>(), d_tmp.as<uint32_t>(), s));
+            }
             RPCHK(hipMemsetAsync(d_ng, 0, 8, s));
-            hipLaunchKernelGGL(kb_heads, dim3(gridN), dim3(256), 0, s, keys.current(), N, d_head.as<uint32_t>(), d_ng);
+            hipLaunchKernelGGL(kb_heads, dim3(gridN), dim3(256), 0, s, kk[cur], N, d_head.as<uint32_t>(), d_ng);
             unsigned long long ng = 0;
             RPCHK(hipMemcpyAsync(&ng, d_ng, 8, hipMemcpyDeviceToHost, s));
             RPCHK(hipStreamSynchronize(s));
             if (ng == N) break;                                   // every suffix has its own rank: vals is the SA
             if (round == 39) { rc = fail(BWT_EHIP, "bwt_build_index: prefix doubling did not converge"); goto done; }
-            RPCHK(rocprim::inclusive_scan(d_tmp.p, tmp_scan, d_head.as<uint32_t>(), d_head.as<uint32_t>(), N,
-                                          rocprim::maximum<uint32_t>(), s));
-            hipLaunchKernelGGL(kb_scatter_rank, dim3(gridN), dim3(256), 0, s, d_head.as<uint32_t>(), vals.current(), N,
+            RPCHK(dev_scan_u32<true>(d_head.as<uint32_t>(), d_head.as<uint32_t>(), N, d_tmp.as<uint32_t>(), s));
+            hipLaunchKernelGGL(kb_scatter_rank, dim3(gridN), dim3(256), 0, s, d_head.as<uint32_t>(), vv[cur], N,
                                d_rank.as<uint32_t>());
-            hipLaunchKernelGGL(kb_pair_keys, dim3(gridN), dim3(256), 0, s, d_rank.as<uint32_t>(), N, h, keys.current(),
-                               vals.current());
+            hipLaunchKernelGGL(kb_pair_keys, dim3(gridN), dim3(256), 0, s, d_rank.as<uint32_t>(), N, h, kk[cur], vv[cur]);
             h *= 2;
         }
         // SA
         if ((rc = ix->sa.exact(N * 4))) goto done;
-        RPCHK(hipMemcpyAsync(ix->sa.p, vals.current(), N * 4, hipMemcpyDeviceToDevice, s));
+        RPCHK(hipMemcpyAsync(ix->sa.p, vv[cur], N * 4, hipMemcpyDeviceToDevice, s));
         // rank blocks
         if ((rc = ix->blocks.exact((size_t)nblk * 64)) || (rc = d_cnt.exact((size_t)nblk * 4 * 4 + 64)) ||
             (rc = d_scan.exact((size_t)nblk * 4 * 4 + 64)))
@@ -210,13 +213,10 @@ extern "C" int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, ui
         uint32_t *d_dollar = d_small.as<uint32_t>() + 4;
         hipLaunchKernelGGL(kb_pack_blocks, dim3(cdiv_u(nblk, 256)), dim3(256), 0, s, ix->sa.as<uint32_t>(),
                            d_sym.as<uint8_t>(), N, nblk, ix->blocks.as<uint32_t>(), cA, cC, cG, cT, d_dollar);
-        size_t tmp_ex = 0;
-        RPCHK(rocprim::exclusive_scan(nullptr, tmp_ex, cA, sA, 0u, nblk, rocprim::plus<uint32_t>(), s));
-        if (tmp_ex > d_tmp.cap) { rc = fail(BWT_EHIP, "bwt_build_index: scan temp larger than expected"); goto done; }
-        RPCHK(rocprim::exclusive_scan(d_tmp.p, tmp_ex, cA, sA, 0u, nblk, rocprim::plus<uint32_t>(), s));
-        RPCHK(rocprim::exclusive_scan(d_tmp.p, tmp_ex, cC, sC, 0u, nblk, rocprim::plus<uint32_t>(), s));
-        RPCHK(rocprim::exclusive_scan(d_tmp.p, tmp_ex, cG, sG, 0u, nblk, rocprim::plus<uint32_t>(), s));
-        RPCHK(rocprim::exclusive_scan(d_tmp.p, tmp_ex, cT, sT, 0u, nblk, rocprim::plus<uint32_t>(), s));
+        RPCHK(dev_scan_u32<false>(cA, sA, nblk, d_tmp.as<uint32_t>(), s));
+        RPCHK(dev_scan_u32<false>(cC, sC, nblk, d_tmp.as<uint32_t>(), s));
+        RPCHK(dev_scan_u32<false>(cG, sG, nblk, d_tmp.as<uint32_t>(), s));
+        RPCHK(dev_scan_u32<false>(cT, sT, nblk, d_tmp.as<uint32_t>(), s));
         hipLaunchKernelGGL(kb_block_counts, dim3(cdiv_u(nblk, 256)), dim3(256), 0, s, nblk, ix->blocks.as<uint32_t>(), sA,
                            sC, sG, sT);
         uint32_t dollar = 0;
@@ -241,7 +241,7 @@ extern "C" int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, ui
     }
 done:
     d_sym.release(); d_key0.release(); d_key1.release(); d_val0.release(); d_val1.release(); d_rank.release();
-    d_head.release(); d_tmp.release(); d_cnt.release(); d_scan.release(); d_small.release();
+    d_head.release(); d_tmp.release(); d_cnt.release(); d_scan.release(); d_small.release(); d_hist.release();
     if (s) (void)hipStreamDestroy(s);
     if (rc) { bwt_index_close(ix); return rc; }
     *out = ix;
