@@ -29,6 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # wave64 integer ops issue at 4 cycles per op per SIMD (SQ counters)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured streaming copy
 
 
@@ -279,15 +280,34 @@ def main():
         value = n_reads * world * args.steps / dt
         per = {k: v["ms"] / v["launches"] for k, v in kt.items()}           # avg ms per launch
         dom = max(per, key=lambda k: kt[k]["ms"])
-        # k_search: algorithmic bytes per launch (search terms): Lq per read in, 128 B per LF step
-        # (two 64-B rank blocks), 16 B per sub-read result out
-        b_search = counts["n_reads"] * length + 128 * counts["lf_steps"] + 16 * counts["n_tasks"]
-        s_search = per["fm_search"] / 1e3
+        # Per-kernel rooflines (algorithmic bytes per launch, SURVEY 8d terms, over the launch time from hipEvents):
+        #   fm_lookup   Lq per read in (plane windows), 8 B table entry per lookup, 16 B per sub-read result out
+        #   fm_search   128 B per LF step (two 64-B rank blocks) [+ the read/result terms when there is no table]
+        #   cluster     4 B per SA entry gathered, 16 B per task-table row in, 8 B per cluster out
+        #   sw_extend   integer VALU (not HBM, not MFMA): 7.4 lane-ops per DP cell against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
         traffic = load_traffic(wl) or {}
-        roof = {"kernel": "k_search", "bound": "hbm", "achieved": b_search / s_search / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": b_search / s_search / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic.get("k_search"), "bytes_per_launch": b_search, "avg_launch_ms": per["fm_search"],
-                "share_of_step": kt["fm_search"]["ms"] / sum(v["ms"] for v in kt.values())}
+        total_ms = sum(v["ms"] for v in kt.values())
+        io_terms = counts["n_reads"] * length + 16 * counts["n_tasks"]
+        models = {
+            "fm_lookup": ("k_lookup", io_terms + 8 * counts["n_lookups"]),
+            "fm_search": ("k_search", 128 * counts["lf_steps"] + (0 if "fm_lookup" in per else io_terms)),
+            "cluster_small": ("k_cluster_small", 4 * counts["sa_reads"] + 16 * counts["n_tasks"] + 8 * counts["n_clusters"]),
+        }
+        roofs = {}
+        for key, (kname, nbytes) in models.items():
+            if key in per and per[key] > 0:
+                gbs = nbytes / (per[key] / 1e3) / 1e9
+                roofs[key] = {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(kname), "bytes_per_launch": nbytes,
+                              "avg_launch_ms": per[key], "share_of_step": kt[key]["ms"] / total_ms}
+        if "sw_extend" in per:
+            dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
+            ops = dp_cells * 7.4 / (per["sw_extend"] / 1e3) / 1e12
+            roofs["sw_extend"] = {"kernel": "k_sw_pk", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS,
+                                  "unit": "Tlane-op/s", "frac": ops / VALU_PEAK_TOPS, "traffic": traffic.get("k_sw"),
+                                  "cells_per_launch": dp_cells, "avg_launch_ms": per["sw_extend"],
+                                  "share_of_step": kt["sw_extend"]["ms"] / total_ms}
+        roof = roofs.get(dom) or roofs[max(roofs, key=lambda k: kt[k]["ms"])]
         line = {
             "metric": "aligned reads/sec (100 bp, GRCh38 FM-index) at 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -297,22 +317,16 @@ def main():
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
                        "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world},
             "roofline": roof,
+            "rooflines": roofs,
             "dominant_kernel": dom,
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(kt.items())},
             "counts_per_step": counts,
         }
         if "sw_extend" in per:
-            # extend stage: integer-VALU bound (not HBM, not MFMA).  wave64 integer ops issue at 4 cycles per op on
-            # gfx950's SIMDs (SQ counters), i.e. 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 3.9e13 lane-ops/s;
-            # the packed kernel spends 7.4 VALU ops per cell on the candidates the prefilter could not settle.
-            s_sw = per["sw_extend"] / 1e3
-            dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
-            line["extend"] = {"kernel": "k_sw_score_pk", "bound": "valu-int", "candidates": counts["n_clusters"],
+            line["extend"] = {"candidates": counts["n_clusters"],
                               "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"],
-                              "dp_candidates": counts["n_dp"], "dp_cells_per_s": dp_cells / s_sw,
-                              "avg_launch_ms": per["sw_extend"], "valu_lane_ops_per_cell": 7.4,
-                              "frac_of_valu_peak": dp_cells * 7.4 / s_sw / (256 * 4 * 16 * 2.4e9),
-                              "traffic": traffic.get("k_sw")}
+                              "dp_candidates": counts["n_dp"],
+                              "dp_cells_per_s": roofs["sw_extend"]["cells_per_launch"] / (per["sw_extend"] / 1e3)}
         # PCIe-inclusive rate (never `value`): host buffers in, host hit tables out, one untimed-extra pass
         t0 = time.perf_counter()
         batch.set_reads(bases, off)

@@ -37,6 +37,40 @@ int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream) {
     return 0;
 }
 
+// Suffix-interval table (kernels.hip.h: kt_build), levels 8..K.  K = 0 drops it; K < 0 picks the default: the
+// environment's BWT_KTAB if set, else the K in 8..15 with 4^K closest above the row count (4^K entries ~ rows:
+// deeper levels would mostly repeat "not found").  GRCh38: K = 15, 11.5 GB next to an 18 GB index.
+extern "C" int bwt_index_set_ktable(bwt_index *ix, int K) {
+    if (!ix) return fail(BWT_EINVAL, "bwt_index_set_ktable: null index");
+    if (K < 0) {
+        const char *env = getenv("BWT_KTAB");
+        if (env && *env) K = atoi(env);
+        else {
+            K = KT_MIN;
+            while (K < BWT_MAX_LEN && (1ull << (2 * K)) < (uint64_t)ix->Last) K++;
+        }
+    }
+    if (K != 0 && (K < KT_MIN || K > BWT_MAX_LEN)) return fail(BWT_EINVAL, "bwt_index_set_ktable: K must be 0 or 8..15");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->d.ktab = nullptr; ix->d.kt_k = 0;
+    if (K == 0) { ix->ktab.release(); return 0; }
+    int rc = ix->ktab.exact(kt_entries(K) * 8);
+    if (rc) return rc;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
+    for (int m = KT_MIN; m <= K; m++) {
+        const uint64_t quads = 1ull << (2 * m);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((quads * 4 + 255) / 256, (uint64_t)cus * 8);
+        hipLaunchKernelGGL(kt_build, dim3(grid), dim3(256), 0, ix->stream, ix->d, ix->ktab.as<uint64_t>(), m);
+    }
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    HIPCHK(hipGetLastError());
+    ix->d.ktab = ix->ktab.as<uint64_t>(); ix->d.kt_k = K;
+    return 0;
+}
+extern "C" int bwt_index_ktable(const bwt_index *ix) { return ix ? ix->d.kt_k : 0; }
+
 static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
     const uint32_t n = (uint32_t)fm.L.size();
     if (n < 8 || fm.Last != n) return fail(BWT_EINVAL, "index: Last must equal the number of rows");
@@ -100,7 +134,7 @@ static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, i
     ix->d.ref1_len = ix->ref1_len;
     ix->d.Pc = fm.Pc; ix->d.Pg = fm.Pg; ix->d.Pt = fm.Pt; ix->d.Last = fm.Last; ix->d.dollar = dollar; ix->d.nblk = nblk;
     ix->d.c0[0] = 1; ix->d.c0[1] = fm.Pc - 1; ix->d.c0[2] = fm.Pg - 1; ix->d.c0[3] = fm.Pt - 1;
-    if ((rc = bwt_index_make_refplanes(ix, ix->stream))) { bwt_index_close(ix); return rc; }
+    if ((rc = bwt_index_make_refplanes(ix, ix->stream)) || (rc = bwt_index_set_ktable(ix, -1))) { bwt_index_close(ix); return rc; }
     *out = ix;
     return 0;
 }
@@ -156,7 +190,7 @@ extern "C" void bwt_index_close(bwt_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    ix->blocks.release(); ix->sa.release(); ix->ref1.release(); ix->refplanes.release();
+    ix->blocks.release(); ix->sa.release(); ix->ref1.release(); ix->refplanes.release(); ix->ktab.release();
     delete ix;
 }
 
@@ -166,9 +200,10 @@ extern "C" int bwt_index_meta(const bwt_index *ix, uint32_t out[5]) {
     return 0;
 }
 
-extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[3]) {
+extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[4]) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_device_bytes: null argument");
     out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len + ix->d.rpw * 16;
+    out[3] = ix->d.kt_k ? kt_entries(ix->d.kt_k) * 8 : 0;
     return 0;
 }
 
@@ -233,7 +268,7 @@ struct bwt_batch {
     DevBuf bases, off, rplanes;
     uint64_t pw = 0;                 // words per read bit-plane
     // tasks
-    DevBuf t_def, t_sp, t_ep, t_info, t_cnt;
+    DevBuf t_def, t_sp, t_ep, t_info, t_cnt, squeue;
     // reads
     DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
@@ -347,7 +382,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
-                     &b->h_cigoff, &b->h_cig, &b->ctr};
+                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->squeue};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -409,8 +444,8 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
 static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks, bool u2 = true) {
     int cus = 256, per_cu = 8;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-    if (u2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<2>, 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<1>, 256, 0);
+    if (u2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<2, false>, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<1, false>, 256, 0);
     per_cu = std::max(1, std::min(per_cu, 8));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n_tasks * 4, 256), (uint64_t)cus * per_cu));
 }
@@ -436,6 +471,32 @@ static int fetch_counters(bwt_batch *b) {
     return 0;
 }
 
+// the seed search over a filled task table (t_def): table lookups + the queued remainder, or every task step by step
+static int launch_search(bwt_batch *b, uint64_t T, uint32_t maxT) {
+    int rc;
+    if (b->ix->d.kt_k > 0 && T < 0xffffffffull) {
+        // the suffix-interval table answers the tasks it covers; the rest are queued and finished step by step
+        if ((rc = b->squeue.ensure(T * 4 + 4))) return rc;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+        KLAUNCH(b, "fm_lookup", k_lookup, (uint32_t)std::min<uint64_t>(cdiv(T, 256), (uint64_t)cus * 8), 256, b->ix->d,
+                b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(),
+                b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->squeue.as<uint32_t>(),
+                b->ctr.as<Counters>());
+        KLAUNCH(b, "fm_search", (k_search<1, true>), search_grid(b, T, false), 256, b->ix->d, b->rplanes.as<uint32_t>(), b->pw,
+                b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
+                b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->squeue.as<uint32_t>(), b->ctr.as<Counters>());
+    } else {
+        static const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
+        const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
+        KLAUNCH(b, "fm_search", (u2 ? k_search<2, false> : k_search<1, false>), search_grid(b, T, u2), 256, b->ix->d,
+                b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(),
+                b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), (const uint32_t *)nullptr,
+                b->ctr.as<Counters>());
+    }
+    return 0;
+}
+
 static int stage_search(bwt_batch *b) {
     const uint32_t n = b->n, maxT = b->maxT;
     const uint64_t T = (uint64_t)n * maxT;
@@ -448,11 +509,7 @@ static int stage_search(bwt_batch *b) {
     if ((rc = read_planes(b))) return rc;
     KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT,
             b->t_def.as<uint32_t>());
-    static const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
-    const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
-    KLAUNCH(b, "fm_search", (u2 ? k_search<2> : k_search<1>), search_grid(b, T, u2), 256, b->ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T,
-            maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
-            b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
+    if ((rc = launch_search(b, T, maxT))) return rc;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -709,7 +766,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
         counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
         counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
-        counts->n_dp = b->hctr.dq_count;
+        counts->n_dp = b->hctr.dq_count; counts->n_lookups = b->hctr.kt_lookups;
     }
     return 0;
 }
@@ -822,9 +879,7 @@ extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const u
     if (T) {
         HIPCHK(hipMemcpyAsync(b->t_def.p, def.data(), T * 4, hipMemcpyHostToDevice, b->stream));
         if ((rc = read_planes(b))) return rc;
-        KLAUNCH(b, "fm_search", k_search<1>, search_grid(b, T, false), 256, ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, 1u,
-                b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(),
-                b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
+        if ((rc = launch_search(b, T, 1u))) return rc;
     }
     if ((rc = dev_scan(b, b->t_cnt.as<uint32_t>(), b->seed_off.as<uint64_t>(), T))) return rc;
     uint64_t total = 0;

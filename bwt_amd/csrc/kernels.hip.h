@@ -183,57 +183,128 @@ struct LfTask {
     bool check_at_limit, check, active;
 };
 
-template <int U>
+// What bwa:find_seeds/6 does before the first LF step, for the sub-read that ends (exclusive) at read base e:
+// the first range (bwa.erl:15-24), the plane windows of the (at most) 15 bases a search consumes -- [e-15, e),
+// bit 15 of each 16-bit window = base e-1, base of step n at bit 15-n -- and the step limit.
+__device__ __forceinline__ void task_init(LfTask &t, const DevIndex &ix, const uint32_t *__restrict__ planes, uint64_t pw,
+                                          uint64_t endp, int e) {
+    uint32_t n16b, o16;
+    if (endp >= 16) {
+        t.lo16 = plane_bits(planes + RP_LO * pw, endp - 16); t.hi16 = plane_bits(planes + RP_HI * pw, endp - 16);
+        n16b = plane_bits(planes + RP_N * pw, endp - 16); o16 = plane_bits(planes + RP_O * pw, endp - 16);
+    } else {                                             // only the very first read of a batch
+        const uint32_t sh = 16 - (uint32_t)endp;
+        t.lo16 = planes[RP_LO * pw] << sh; t.hi16 = planes[RP_HI * pw] << sh;
+        n16b = planes[RP_N * pw] << sh; o16 = planes[RP_O * pw] << sh;
+    }
+    t.lo16 &= 0xffffu; t.hi16 &= 0xffffu;
+    t.status = TS_SEEDS;
+    t.n = 1;
+    const uint32_t hc = ((t.lo16 >> 15) & 1u) | (((t.hi16 >> 15) & 1u) << 1);       // bwa.erl:15-24
+    if ((o16 >> 15) & 1u) { t.status = TS_CRASH; t.active = false; return; }
+    else if (((n16b >> 15) & 1u) || hc == 0) { t.sp = 1; t.ep = ix.Pc - 1; }        // N is searched as A
+    else if (hc == 1) { t.sp = ix.Pc; t.ep = ix.Pg - 1; }
+    else if (hc == 2) { t.sp = ix.Pg; t.ep = ix.Pt - 1; }
+    else { t.sp = ix.Pt; t.ep = ix.Last; }
+    t.nlim = e < BWT_MAX_LEN ? e : BWT_MAX_LEN;          // n == MAX_LEN (bwa.erl:31-32) or read exhausted (:44-45)
+    const uint32_t sm = (n16b | o16) & 0x7fffu;           // base k of step n sits at plane bit 15-n
+    if (sm) {
+        const int hb = 31 - __clz((int)sm);
+        const int nstop = 15 - hb;
+        if (nstop < t.nlim) { t.nlim = nstop; t.check_at_limit = ((o16 >> hb) & 1u) == 0; }   // N: :33-34
+    }
+    t.active = t.n < t.nlim;
+}
+// the clause a finished search leaves through (bwa.erl:31-45) and what get_seed_ends makes of it (fmi.erl:89)
+__device__ __forceinline__ void task_finish(const LfTask &t_in, bool write, uint32_t *__restrict__ t_sp,
+                                            uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
+                                            uint32_t *__restrict__ t_cnt) {
+    LfTask t = t_in;
+    uint32_t status = t.status;
+    if (status == TS_SEEDS) {
+        if (t.n >= t.nlim && t.check) t.check = t.check_at_limit;          // tasks that never stepped
+        if (t.check && t.ep - t.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
+        else if (t.n < BWT_MIN_LEN) status = TS_NO_SEEDS;                  // fmi.erl:89
+    }
+    if (write) {
+        t_sp[t.task] = t.sp; t_ep[t.task] = t.ep;
+        t_info[t.task] = status | ((uint32_t)t.n << 8);
+        t_cnt[t.task] = status == TS_SEEDS ? t.ep - t.sp + 1 : 0;
+    }
+}
+
+// One LF step of a quad on the range [sp, ep] with the base whose code bits are (cl, ch); v1/v2 = this lane's quarter
+// of the blocks of rows sp-1 / ep-1.  Returns found; on found sp/ep are the new range.
+__device__ __forceinline__ bool lf_step(const DevIndex &ix, int ql, uint32_t dblk, uint4 v1, uint4 v2, uint32_t b1, uint32_t b2,
+                                        uint32_t cl, uint32_t ch, uint32_t &sp, uint32_t &ep) {
+    const int row0 = 48 * ql;                                    // first row of this lane's quarter
+    const int code = (int)(cl | (ch << 1));
+    const uint32_t nl = cl - 1u, nh = ch - 1u;        // ~(-bit): all ones when the wanted bit is 0
+    const uint32_t n16 = (nl & 0xffffu) | (nh << 16);
+    const uint32_t k1 = sp - 1, k2 = ep - 1;
+    const int m1 = (int)(k1 - b1 * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2 * BWT_BLOCK_ROWS);
+    uint32_t ya0, ya1, yb0, yb1;
+    quarter_match(v1, nl, nh, n16, ya0, ya1);
+    quarter_match(v2, nl, nh, n16, yb0, yb1);
+    const bool mine = ql == code;                     // this lane's count word is the wanted one
+    uint32_t o1 = quad_sum(quarter_prefix(ya0, ya1, m1 - row0) + (mine ? v1.x : 0u));   // occ(c,Sp-1)
+    uint32_t o2 = quad_sum(quarter_prefix(yb0, yb1, m2 - row0) + (mine ? v2.x : 0u));   // occ(c,Ep-1)
+    const int pos = m2 - row0;                        // L[Ep] is row m2 of block b2
+    const uint32_t sel = pos < 32 ? yb0 >> (pos & 31) : yb1 >> ((pos - 32) & 31);
+    uint32_t bit = quad_sum((pos >= 0 && pos < 48) ? sel & 1u : 0u);                     // L[Ep] == c
+    if (b1 == dblk || b2 == dblk) {             // (rare) the block that holds the `$` row: take it out again
+        if (code == 0) {
+            const uint32_t f = dblk * BWT_BLOCK_ROWS;
+            if (b1 == dblk && ix.dollar > f && ix.dollar <= k1) o1 -= 1;
+            if (b2 == dblk && ix.dollar > f && ix.dollar <= k2) o2 -= 1;
+            if (ix.dollar == ep) bit = 0;
+        }
+    }
+    if (!(o2 > o1)) return false;                                          // se_down: not_found (bwa.erl:38)
+    // C0[code] as bitwise selects on the code's plane masks (a per-lane index into the kernel-argument array
+    // goes through scratch; chained ?: becomes divergent branches): nl/nh are all ones when that code bit is 0
+    const uint32_t c_lo = (nl & 1u) | (~nl & (ix.Pc - 1)), c_hi = (nl & (ix.Pg - 1)) | (~nl & (ix.Pt - 1));
+    const uint32_t c0 = (nh & c_lo) | (~nh & c_hi);
+    sp = c0 + o1;
+    ep = c0 + o2 + bit - 1;                         // C0 + occ(c,Ep) - 1
+    return true;
+}
+
+// QUEUED: the tasks are the ids k_lookup left in `queue` (their count in ctr->sq_count), each resuming from the
+// (Sp, Ep, n) k_lookup stored; else every slot of the task table, from n = 1.
+template <int U, bool QUEUED>
 __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
                                                  const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
                                                  const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                  uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
-                                                 uint32_t *__restrict__ t_cnt, Counters *ctr) {
+                                                 uint32_t *__restrict__ t_cnt, const uint32_t *__restrict__ queue, Counters *ctr) {
     const int ql = (int)(threadIdx.x & 3);
-    const int row0 = 48 * ql;                                    // first row of this lane's quarter
     const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;      // the one block whose planes hold the `$` row
     const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+    const uint64_t n_work = QUEUED ? (uint64_t)ctr->sq_count : n_tasks;
     uint32_t steps = 0, live = 0;
-    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; base < n_tasks; base += (uint64_t)U * nquads) {
+    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; base < n_work; base += (uint64_t)U * nquads) {
         LfTask T[U];
+        bool have[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             LfTask &t = T[u];
-            t.task = base + (uint64_t)u * nquads;
+            const uint64_t w = base + (uint64_t)u * nquads;
+            have[u] = w < n_work;
+            t.task = 0;
             t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
             t.check_at_limit = true; t.check = true; t.active = false;
-            if (t.task >= n_tasks) continue;
+            if (!have[u]) continue;
+            t.task = QUEUED ? (uint64_t)queue[w] : w;
             const int e = (int)(t_def[t.task] & 0xffffu);
             if (e <= 0) continue;
-            live++;
+            if (!QUEUED) live++;
             const uint32_t r = (uint32_t)(t.task / maxT);
-            // the (at most) 15 bases a search consumes, [e-15, e): bit 15 of each 16-bit plane window = base e-1
-            const uint64_t endp = off[r] + (uint64_t)e;
-            uint32_t n16b, o16;
-            if (endp >= 16) {
-                t.lo16 = plane_bits(planes + RP_LO * pw, endp - 16); t.hi16 = plane_bits(planes + RP_HI * pw, endp - 16);
-                n16b = plane_bits(planes + RP_N * pw, endp - 16); o16 = plane_bits(planes + RP_O * pw, endp - 16);
-            } else {                                             // only the very first read of a batch
-                const uint32_t sh = 16 - (uint32_t)endp;
-                t.lo16 = planes[RP_LO * pw] << sh; t.hi16 = planes[RP_HI * pw] << sh;
-                n16b = planes[RP_N * pw] << sh; o16 = planes[RP_O * pw] << sh;
+            task_init(t, ix, planes, pw, off[r] + (uint64_t)e, e);
+            if (QUEUED) {
+                const uint32_t n0 = (t_info[t.task] >> 8) & 0xffu;
+                if (n0 > 1) { t.sp = t_sp[t.task]; t.ep = t_ep[t.task]; t.n = (int)n0; t.active = t.n < t.nlim; }
             }
-            t.status = TS_SEEDS;
-            t.n = 1;
-            const uint32_t hc = ((t.lo16 >> 15) & 1u) | (((t.hi16 >> 15) & 1u) << 1);       // bwa.erl:15-24
-            if ((o16 >> 15) & 1u) { t.status = TS_CRASH; continue; }
-            else if (((n16b >> 15) & 1u) || hc == 0) { t.sp = 1; t.ep = ix.Pc - 1; }        // N is searched as A
-            else if (hc == 1) { t.sp = ix.Pc; t.ep = ix.Pg - 1; }
-            else if (hc == 2) { t.sp = ix.Pg; t.ep = ix.Pt - 1; }
-            else { t.sp = ix.Pt; t.ep = ix.Last; }
-            t.nlim = e < BWT_MAX_LEN ? e : BWT_MAX_LEN;          // n == MAX_LEN (bwa.erl:31-32) or read exhausted (:44-45)
-            const uint32_t sm = (n16b | o16) & 0x7fffu;           // base k of step n sits at plane bit 15-n
-            if (sm) {
-                const int hb = 31 - __clz((int)sm);
-                const int nstop = 15 - hb;
-                if (nstop < t.nlim) { t.nlim = nstop; t.check_at_limit = ((o16 >> hb) & 1u) == 0; }   // N: :33-34
-            }
-            t.active = t.n < t.nlim;
         }
         for (;;) {
             bool any = false;
@@ -255,63 +326,134 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
                 LfTask &t = T[u];
                 if (!t.active) continue;
                 const uint32_t bi = 15u - (uint32_t)t.n;          // plane bit of the base this step consumes
-                const uint32_t cl = (t.lo16 >> bi) & 1u, ch = (t.hi16 >> bi) & 1u;
-                const int code = (int)(cl | (ch << 1));
-                const uint32_t nl = cl - 1u, nh = ch - 1u;        // ~(-bit): all ones when the wanted bit is 0
-                const uint32_t n16 = (nl & 0xffffu) | (nh << 16);
-                const uint32_t k1 = t.sp - 1, k2 = t.ep - 1;
-                const int m1 = (int)(k1 - b1[u] * BWT_BLOCK_ROWS), m2 = (int)(k2 - b2[u] * BWT_BLOCK_ROWS);
-                uint32_t ya0, ya1, yb0, yb1;
-                quarter_match(v1[u], nl, nh, n16, ya0, ya1);
-                quarter_match(v2[u], nl, nh, n16, yb0, yb1);
-                const bool mine = ql == code;                     // this lane's count word is the wanted one
-                uint32_t o1 = quad_sum(quarter_prefix(ya0, ya1, m1 - row0) + (mine ? v1[u].x : 0u));   // occ(c,Sp-1)
-                uint32_t o2 = quad_sum(quarter_prefix(yb0, yb1, m2 - row0) + (mine ? v2[u].x : 0u));   // occ(c,Ep-1)
-                const int pos = m2 - row0;                        // L[Ep] is row m2 of block b2
-                const uint32_t sel = pos < 32 ? yb0 >> (pos & 31) : yb1 >> ((pos - 32) & 31);
-                uint32_t bit = quad_sum((pos >= 0 && pos < 48) ? sel & 1u : 0u);                     // L[Ep] == c
-                if (b1[u] == dblk || b2[u] == dblk) {             // (rare) the block that holds the `$` row: take it out again
-                    if (code == 0) {
-                        const uint32_t f = dblk * BWT_BLOCK_ROWS;
-                        if (b1[u] == dblk && ix.dollar > f && ix.dollar <= k1) o1 -= 1;
-                        if (b2[u] == dblk && ix.dollar > f && ix.dollar <= k2) o2 -= 1;
-                        if (ix.dollar == t.ep) bit = 0;
-                    }
-                }
                 steps++;
-                if (!(o2 > o1)) { t.check = false; t.active = false; continue; }   // se_down: not_found (bwa.erl:38)
-                // C0[code] as bitwise selects on the code's plane masks (a per-lane index into the kernel-argument array
-                // goes through scratch; chained ?: becomes divergent branches): nl/nh are all ones when that code bit is 0
-                const uint32_t c_lo = (nl & 1u) | (~nl & (ix.Pc - 1)), c_hi = (nl & (ix.Pg - 1)) | (~nl & (ix.Pt - 1));
-                const uint32_t c0 = (nh & c_lo) | (~nh & c_hi);
-                t.sp = c0 + o1;
-                t.ep = c0 + o2 + bit - 1;                         // C0 + occ(c,Ep) - 1
+                if (!lf_step(ix, ql, dblk, v1[u], v2[u], b1[u], b2[u], (t.lo16 >> bi) & 1u, (t.hi16 >> bi) & 1u, t.sp, t.ep)) {
+                    t.check = false; t.active = false; continue;
+                }
                 t.n++;
                 if (t.n >= t.nlim) { t.check = t.check_at_limit; t.active = false; }
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            LfTask &t = T[u];
-            if (t.task >= n_tasks) continue;
-            uint32_t status = t.status;
-            if (status == TS_SEEDS) {
-                if (t.n >= t.nlim && t.check) t.check = t.check_at_limit;          // tasks that never stepped
-                if (t.check && t.ep - t.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
-                else if (t.n < BWT_MIN_LEN) status = TS_NO_SEEDS;                  // fmi.erl:89
-            }
-            if (ql == 0) {
-                t_sp[t.task] = t.sp; t_ep[t.task] = t.ep;
-                t_info[t.task] = status | ((uint32_t)t.n << 8);
-                t_cnt[t.task] = status == TS_SEEDS ? t.ep - t.sp + 1 : 0;
-            }
-        }
+        for (int u = 0; u < U; u++)
+            if (have[u]) task_finish(T[u], ql == 0, t_sp, t_ep, t_info, t_cnt);
     }
     // one atomic pair per wave (the grid is capped, so a few thousand per launch) for the work counters
     unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), l = wave_sum_u64(ql == 0 ? live : 0);
     if ((threadIdx.x & 63) == 0 && (s | l)) {
         atomicAdd(&ctr->lf_steps, s);
         atomicAdd(&ctr->n_tasks, l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Suffix-interval table ("ktab"): for every m in 8..K and every m-mer, what the first m-1 LF steps of
+// bwa:find_seeds/5 arrive at -- the same closed-form steps, taken once per k-mer when the index is opened
+// instead of once per task.  Level m, key = lo_m | hi_m << m where lo_m / hi_m are the low / high code bits
+// of the m bases in search order, first searched base in bit m-1 (= the top m bits of a task's plane windows).
+// Entry (u64): Sp | (Ep - Sp) << 32 (28 bits; 0xfffffff = does not fit, search it step by step) | n << 60 with
+// n = bases matched: n == m: the whole m-mer occurs; n < m: step n+1 came back not_found from [Sp, Ep] (bwa.erl:38).
+// Levels below 8 are never asked for: skip_Ns leaves >= 7 N-free bases left of a sub-read's last base and a
+// sub-read has >= 8 bases, so a shorter search only happens in front of a base outside ACGTN.
+#define KT_MIN 8
+#define KT_OVF 0xfffffffu
+__host__ __device__ __forceinline__ uint64_t kt_level_off(int m) { return ((1ull << (2 * m)) - (1ull << (2 * KT_MIN))) / 3ull; }
+__host__ __device__ __forceinline__ uint64_t kt_entries(int K) { return kt_level_off(K + 1); }
+__device__ __forceinline__ uint64_t kt_pack(uint32_t sp, uint32_t ep, int n) {
+    const uint32_t w = ep - sp;
+    return (uint64_t)sp | ((uint64_t)(w >= KT_OVF ? KT_OVF : w) << 32) | ((uint64_t)n << 60);
+}
+
+// quad per key of level m.  m == KT_MIN (or a parent that did not fit): all m-1 steps; else one step from the parent.
+__global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restrict__ tab, int m) {
+    const int ql = (int)(threadIdx.x & 3);
+    const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;
+    const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+    const uint64_t nkeys = 1ull << (2 * m);
+    const uint32_t mask = (1u << m) - 1u;
+    for (uint64_t key = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; key < nkeys; key += nquads) {
+        const uint32_t lo = (uint32_t)key & mask, hi = (uint32_t)(key >> m) & mask;
+        uint32_t sp = 0, ep = 0;
+        int n = 0, todo_from;                 // steps todo_from .. m-1 (step j consumes the base at bit m-1-j) remain
+        bool dead = false;
+        uint64_t par = 0;
+        if (m > KT_MIN) par = tab[kt_level_off(m - 1) + ((uint64_t)(lo >> 1) | ((uint64_t)(hi >> 1) << (m - 1)))];
+        if (m > KT_MIN && ((par >> 32) & KT_OVF) != KT_OVF) {
+            sp = (uint32_t)par; ep = sp + (uint32_t)((par >> 32) & KT_OVF); n = (int)(par >> 60);
+            dead = n < m - 1;
+            todo_from = m - 1;
+        } else {
+            const uint32_t hc = ((lo >> (m - 1)) & 1u) | (((hi >> (m - 1)) & 1u) << 1);
+            if (hc == 0) { sp = 1; ep = ix.Pc - 1; }
+            else if (hc == 1) { sp = ix.Pc; ep = ix.Pg - 1; }
+            else if (hc == 2) { sp = ix.Pg; ep = ix.Pt - 1; }
+            else { sp = ix.Pt; ep = ix.Last; }
+            n = 1;
+            todo_from = 1;
+        }
+        for (int j = todo_from; j < m && !dead; j++) {
+            const uint32_t b1 = (sp - 1) / BWT_BLOCK_ROWS, b2 = (ep - 1) / BWT_BLOCK_ROWS;
+            const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql], v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+            const int bi = m - 1 - j;
+            if (lf_step(ix, ql, dblk, v1, v2, b1, b2, (lo >> bi) & 1u, (hi >> bi) & 1u, sp, ep)) n++;
+            else dead = true;
+        }
+        if (ql == 0) tab[kt_level_off(m) + key] = kt_pack(sp, ep, n);
+    }
+}
+
+// k_lookup: lane per slot of the task table.  Answers every task the table can answer -- all of them when K = 15 --
+// and queues the rest for k_search<QUEUED>: tasks longer than K (resume at n = K), tasks in front of a base outside
+// ACGTN that stop before 8 bases, and entries whose range did not fit (both from n = 1).
+__global__ __launch_bounds__(256) void k_lookup(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
+                                                 const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
+                                                 const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
+                                                 uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
+                                                 uint32_t *__restrict__ t_cnt, uint32_t *__restrict__ queue, Counters *ctr) {
+    const int K = ix.kt_k;
+    uint32_t live = 0, looked = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n_tasks + stride - 1) / stride;      // every lane takes part in every wave_append
+    for (uint64_t it = 0; it < rounds; it++) {
+        const uint64_t w = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        LfTask t;
+        t.task = w;
+        t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
+        t.check_at_limit = true; t.check = true; t.active = false;
+        bool pending = false;
+        const int e = w < n_tasks ? (int)(t_def[w] & 0xffffu) : 0;
+        if (e > 0) {
+            live++;
+            task_init(t, ix, planes, pw, off[(uint32_t)(w / maxT)] + (uint64_t)e, e);
+            if (t.active) {
+                pending = true;
+                if (t.nlim >= KT_MIN) {
+                    const int m = t.nlim < K ? t.nlim : K;
+                    const uint32_t mask = (1u << m) - 1u;
+                    const uint64_t key = (uint64_t)((t.lo16 >> (16 - m)) & mask) | ((uint64_t)((t.hi16 >> (16 - m)) & mask) << m);
+                    const uint64_t ent = ix.ktab[kt_level_off(m) + key];
+                    looked++;
+                    const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF;
+                    if (wd != KT_OVF) {
+                        t.sp = (uint32_t)ent; t.ep = t.sp + wd; t.n = (int)(ent >> 60);
+                        if (t.n < m) { t.check = false; pending = false; }                          // not_found inside the table
+                        else if (m == t.nlim) { t.check = t.check_at_limit; pending = false; }
+                    }
+                }
+            }
+        }
+        const uint32_t qi = wave_append(&ctr->sq_count, pending);
+        if (pending) {
+            queue[qi] = (uint32_t)w;
+            t_sp[w] = t.sp; t_ep[w] = t.ep; t_info[w] = TS_NONE | ((uint32_t)t.n << 8);
+        } else if (w < n_tasks) {
+            task_finish(t, true, t_sp, t_ep, t_info, t_cnt);
+        }
+    }
+    unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked);
+    if ((threadIdx.x & 63) == 0 && (l | k)) {
+        atomicAdd(&ctr->n_tasks, l);
+        atomicAdd(&ctr->kt_lookups, k);
     }
 }
 

@@ -44,6 +44,8 @@ struct DevIndex {
     uint64_t rpw;
     uint32_t Pc, Pg, Pt, Last, dollar, nblk;
     uint32_t c0[4];        // {1, Pc-1, Pg-1, Pt-1}: 0-based first row of each F block (src/bwt.erl:105-112)
+    const uint64_t *ktab;  // suffix-interval table, levels 8..kt_k (kernels.hip.h: kt_build); null when kt_k == 0
+    int kt_k;
 };
 
 // byte-stream bit-planes (reads, Ref1) ---------------------------------------------------------------
@@ -96,7 +98,7 @@ __device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plan
 
 
 struct Counters {          // device-side work counters (roofline accounting)
-    unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags;
-    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, pad_;
+    unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags, kt_lookups;
+    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, sq_count;
 };
 

@@ -12,7 +12,7 @@ ENOSPC = -28
 
 EXPORTS = [
     "bwt_constants", "bwt_last_error", "bwt_index_open", "bwt_index_from_arrays", "bwt_index_close",
-    "bwt_index_meta", "bwt_index_device_bytes", "bwt_find_seeds_batch", "bwt_sga_batch", "bwt_sw_batch",
+    "bwt_index_meta", "bwt_index_device_bytes", "bwt_index_set_ktable", "bwt_index_ktable", "bwt_find_seeds_batch", "bwt_sga_batch", "bwt_sw_batch",
     "bwt_align_batch", "bwt_ref1_read", "bwt_batch_create", "bwt_batch_destroy", "bwt_batch_set_reads",
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
@@ -34,7 +34,7 @@ class Constants(C.Structure):
 
 class BatchCounts(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_reads", "n_tasks", "lf_steps", "sa_reads", "n_clusters", "sw_cells",
-                                          "n_hits", "cigar_bytes", "window_bytes", "n_float", "n_traced", "n_dp")]
+                                          "n_hits", "cigar_bytes", "window_bytes", "n_float", "n_traced", "n_dp", "n_lookups")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -165,9 +165,17 @@ class Index:
         return (pc, pg, pt, last), C.c_int32(shift).value
 
     def device_bytes(self):
-        out = (C.c_uint64 * 3)()
+        out = (C.c_uint64 * 4)()
         _chk(load().bwt_index_device_bytes(self.h, out))
-        return dict(rank_blocks=int(out[0]), sa=int(out[1]), ref1=int(out[2]))
+        return dict(rank_blocks=int(out[0]), sa=int(out[1]), ref1=int(out[2]), ktable=int(out[3]))
+
+    def set_ktable(self, k):
+        """Suffix-interval table depth: 0 = none, 8..15, negative = the library's default for this index."""
+        _chk(load().bwt_index_set_ktable(self.h, int(k)))
+
+    @property
+    def ktable(self):
+        return int(load().bwt_index_ktable(self.h))
 
     def ref1(self, off, length):
         out = np.empty(length, np.uint8)

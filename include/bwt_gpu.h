@@ -58,8 +58,16 @@ int bwt_index_from_arrays(const uint8_t *L, const uint32_t *SA, uint32_t n_rows,
 void bwt_index_close(bwt_index *idx);
 /* out = {Pc, Pg, Pt, Last, Shift}  (proplists pointers / shift of the Meta term) */
 int bwt_index_meta(const bwt_index *idx, uint32_t out[5]);
-/* bytes resident in HBM: {rank blocks, SA, ref1 + its bit-planes} */
-int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[3]);
+/* bytes resident in HBM: {rank blocks, SA, ref1 + its bit-planes, suffix-interval table} */
+int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[4]);
+/* Suffix-interval table: for every k-mer, k = 8..K, the (Sp, Ep, n) that the first k-1 steps of
+ * bwa:find_seeds/5 (src/bwa.erl:31-45) reach -- computed once with the same LF step when the index is
+ * opened, so that a task costs one table read instead of up to 14 dependent steps (K = 15 answers every
+ * task; smaller K leaves 15-K steps).  Results are identical with or without it.
+ * K: 0 = none (every task searched step by step), 8..15, <0 = default (env BWT_KTAB, else by index size).
+ * Not to be called while a batch on this index is running. */
+int bwt_index_set_ktable(bwt_index *idx, int K);
+int bwt_index_ktable(const bwt_index *idx);        /* current K (0 = none) */
 
 /* ------------------------------------------------------------------ a-13 / 8f-1: index construction
  * Replaces fm_index:make_index/4 (src/fm_index.erl:127-141) = IUPAC map + random:uniform(4) for N
@@ -159,6 +167,7 @@ typedef struct {
     uint64_t n_float;                /* candidates that took the fp64 (N / 1.6) path         */
     uint64_t n_traced;               /* candidates that needed a real traceback (not "<Lq>M") */
     uint64_t n_dp;                   /* candidates the prefilter could not settle (ran the DP)  */
+    uint64_t n_lookups;              /* tasks answered or started from the suffix-interval table */
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);
 void bwt_batch_destroy(bwt_batch *b);

@@ -29,9 +29,22 @@ def mixed_reads(ref, n, seed):
             synth_reads(ref, n - n // 2 - n // 4 - n // 8, 150, seed + 3, indel_frac=0.3))
 
 
-def test_search_tasks_match_oracle(gpu_index, orc_fm, ref_bytes):
+@pytest.fixture
+def ktable_depth(gpu_index):
+    """Sets the suffix-interval table depth for one test and puts the default back."""
+    def set_k(k):
+        gpu_index.set_ktable(k)
+        assert gpu_index.ktable == k
+    yield set_k
+    gpu_index.set_ktable(-1)
+
+
+# 0: every task step by step; 8: smallest table; 9/12: table + remaining steps; 15: the table answers everything
+@pytest.mark.parametrize("K", [0, 8, 9, 12, 15])
+def test_search_tasks_match_oracle(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc
+    ktable_depth(K)
     reads = mixed_reads(ref_bytes, 400, 11)
     bases, off = lib.pack_reads(reads)
     b = lib.Batch(gpu_index)
@@ -51,12 +64,20 @@ def test_search_tasks_match_oracle(gpu_index, orc_fm, ref_bytes):
                 steps += n - 1
             k += 1
     assert k == len(t["status"]) == counts["n_tasks"]
-    assert counts["lf_steps"] >= steps          # steps that ended in not_found are counted too
+    if K == 0:
+        assert counts["lf_steps"] >= steps and counts["n_lookups"] == 0   # steps that ended in not_found are counted too
+    else:
+        assert counts["lf_steps"] <= max(0, 15 - K) * counts["n_tasks"] + 14 * (counts["n_tasks"] - counts["n_lookups"])
+        assert 0 < counts["n_lookups"] <= counts["n_tasks"]
+    if K == 15:
+        assert counts["lf_steps"] <= 14 * (counts["n_tasks"] - counts["n_lookups"])   # only tasks the table cannot take
 
 
-def test_find_seeds_batch_lists(gpu_index, orc_fm, ref_bytes):
+@pytest.mark.parametrize("K", [0, 10, 15])
+def test_find_seeds_batch_lists(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc
+    ktable_depth(K)
     subs = []
     for q in mixed_reads(ref_bytes, 120, 21):
         subs += subreads_of(q)
@@ -159,9 +180,11 @@ def test_sw_long_cigar_overflow_path():
     assert (int(out["score"][0]), cig) == exp
 
 
-def test_align_batch_matches_oracle(gpu_index, orc_fm, ref_bytes):
+@pytest.mark.parametrize("K", [0, 9, 15])
+def test_align_batch_matches_oracle(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc, erl_literal as E
+    ktable_depth(K)
     ref1 = E.make_ref1(ref_bytes)
     reads = mixed_reads(ref_bytes, 500, 41)
     # reads hanging over both contig ends: windows reach into the 200-N halo (fp64 path)
@@ -204,7 +227,7 @@ def test_counters_and_profile(gpu_index, ref_bytes):
     kt = b.kernel_times()
     b.destroy()
     assert c["n_reads"] == 2000 and c["n_tasks"] == 2000 * 12
-    assert c["lf_steps"] > 2000 * 60 and c["n_hits"] > 500
+    assert c["lf_steps"] + 14 * c["n_lookups"] > 2000 * 60 and c["n_hits"] > 500
     assert "fm_search" in kt and kt["fm_search"]["launches"] == 1 and kt["fm_search"]["ms"] > 0
     assert "sw_extend" in kt
 
