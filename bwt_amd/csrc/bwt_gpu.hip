@@ -268,7 +268,8 @@ struct bwt_batch {
     DevBuf bases, off, rplanes;
     uint64_t pw = 0;                 // words per read bit-plane
     // tasks
-    DevBuf t_def, t_sp, t_ep, t_info, t_cnt, squeue;
+    DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend;
+    bool counts_done = false;          // the search stage already totalled the reads (k_seed_tasks)
     // reads
     DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
@@ -382,7 +383,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
-                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->squeue};
+                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -444,8 +445,8 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
 static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks, bool u2 = true) {
     int cus = 256, per_cu = 8;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-    if (u2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<2, false>, 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<1, false>, 256, 0);
+    if (u2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<2>, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search<1>, 256, 0);
     per_cu = std::max(1, std::min(per_cu, 8));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n_tasks * 4, 256), (uint64_t)cus * per_cu));
 }
@@ -471,28 +472,40 @@ static int fetch_counters(bwt_batch *b) {
     return 0;
 }
 
-// the seed search over a filled task table (t_def): table lookups + the queued remainder, or every task step by step
-static int launch_search(bwt_batch *b, uint64_t T, uint32_t maxT) {
+// The seed search.  With a suffix-interval table (and reads of at most 64 sub-reads): k_seed_tasks (sub-reads, table
+// lookups, per-read totals) + k_search_pending (the LF steps the table left over) -- the per-read totals of the cluster
+// stage are then already in place (b->counts_done).  Else: k_subreads + k_search over every task, from n = 1.
+// raw: one task per "read", t_def already filled (bwt_find_seeds_batch).
+static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw) {
     int rc;
-    if (b->ix->d.kt_k > 0 && T < 0xffffffffull) {
-        // the suffix-interval table answers the tasks it covers; the rest are queued and finished step by step
-        if ((rc = b->squeue.ensure(T * 4 + 4))) return rc;
+    const uint64_t T = (uint64_t)n * maxT;
+    b->counts_done = false;
+    if (b->ix->d.kt_k > 0 && maxT >= 1 && maxT <= 64) {
+        if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
+            (rc = b->r_pend.ensure((size_t)n * 8 + 8)) || (rc = b->bigq.ensure((size_t)n * 4 + 4)) ||
+            (rc = b->mid2q.ensure((size_t)n * 4 + 4)) || (rc = b->mid4q.ensure((size_t)n * 4 + 4)))
+            return rc;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-        KLAUNCH(b, "fm_lookup", k_lookup, (uint32_t)std::min<uint64_t>(cdiv(T, 256), (uint64_t)cus * 8), 256, b->ix->d,
-                b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(),
-                b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->squeue.as<uint32_t>(),
-                b->ctr.as<Counters>());
-        KLAUNCH(b, "fm_search", (k_search<1, true>), search_grid(b, T, false), 256, b->ix->d, b->rplanes.as<uint32_t>(), b->pw,
-                b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
-                b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->squeue.as<uint32_t>(), b->ctr.as<Counters>());
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(cdiv(n, 64 / maxT), 4), (uint64_t)cus * 8);   // wave per 64/maxT reads
+#define SEED_ARGS b->ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT, b->t_def.as<uint32_t>(),          \
+                  b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),               \
+                  b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),       \
+                  b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>()
+        if (raw) KLAUNCH(b, "fm_lookup", k_seed_tasks<true>, grid, 256, SEED_ARGS);
+        else KLAUNCH(b, "fm_lookup", k_seed_tasks<false>, grid, 256, SEED_ARGS);
+        KLAUNCH(b, "fm_search", k_search_pending, search_grid(b, T, false), 256, SEED_ARGS);
+#undef SEED_ARGS
+        b->counts_done = true;
     } else {
+        if (!raw)
+            KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT,
+                    b->t_def.as<uint32_t>());
         static const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
         const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
-        KLAUNCH(b, "fm_search", (u2 ? k_search<2, false> : k_search<1, false>), search_grid(b, T, u2), 256, b->ix->d,
-                b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(),
-                b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), (const uint32_t *)nullptr,
-                b->ctr.as<Counters>());
+        KLAUNCH(b, "fm_search", (u2 ? k_search<2> : k_search<1>), search_grid(b, T, u2), 256, b->ix->d, b->rplanes.as<uint32_t>(),
+                b->pw, b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
+                b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     }
     return 0;
 }
@@ -507,9 +520,7 @@ static int stage_search(bwt_batch *b) {
     HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
     if (n == 0) return 0;
     if ((rc = read_planes(b))) return rc;
-    KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT,
-            b->t_def.as<uint32_t>());
-    if ((rc = launch_search(b, T, maxT))) return rc;
+    if ((rc = launch_search(b, n, maxT, false))) return rc;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -527,9 +538,10 @@ static int stage_cluster(bwt_batch *b) {
         HIPCHK(hipMemsetAsync(b->clus_off.p, 0, 8, b->stream));
         return fetch_counters(b);
     }
-    KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
-            b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
-            b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>());
+    if (!b->counts_done)
+        KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
+                b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
+                b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>());
     if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
     uint64_t total_seeds = 0;
     HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
@@ -879,7 +891,7 @@ extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const u
     if (T) {
         HIPCHK(hipMemcpyAsync(b->t_def.p, def.data(), T * 4, hipMemcpyHostToDevice, b->stream));
         if ((rc = read_planes(b))) return rc;
-        if ((rc = launch_search(b, T, 1u))) return rc;
+        if ((rc = launch_search(b, n, 1u, true))) return rc;
     }
     if ((rc = dev_scan(b, b->t_cnt.as<uint32_t>(), b->seed_off.as<uint64_t>(), T))) return rc;
     uint64_t total = 0;

@@ -270,41 +270,30 @@ __device__ __forceinline__ bool lf_step(const DevIndex &ix, int ql, uint32_t dbl
     return true;
 }
 
-// QUEUED: the tasks are the ids k_lookup left in `queue` (their count in ctr->sq_count), each resuming from the
-// (Sp, Ep, n) k_lookup stored; else every slot of the task table, from n = 1.
-template <int U, bool QUEUED>
+template <int U>
 __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
                                                  const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
                                                  const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                  uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
-                                                 uint32_t *__restrict__ t_cnt, const uint32_t *__restrict__ queue, Counters *ctr) {
+                                                 uint32_t *__restrict__ t_cnt, Counters *ctr) {
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;      // the one block whose planes hold the `$` row
     const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
-    const uint64_t n_work = QUEUED ? (uint64_t)ctr->sq_count : n_tasks;
     uint32_t steps = 0, live = 0;
-    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; base < n_work; base += (uint64_t)U * nquads) {
+    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; base < n_tasks; base += (uint64_t)U * nquads) {
         LfTask T[U];
-        bool have[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             LfTask &t = T[u];
-            const uint64_t w = base + (uint64_t)u * nquads;
-            have[u] = w < n_work;
-            t.task = 0;
+            t.task = base + (uint64_t)u * nquads;
             t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
             t.check_at_limit = true; t.check = true; t.active = false;
-            if (!have[u]) continue;
-            t.task = QUEUED ? (uint64_t)queue[w] : w;
+            if (t.task >= n_tasks) continue;
             const int e = (int)(t_def[t.task] & 0xffffu);
             if (e <= 0) continue;
-            if (!QUEUED) live++;
+            live++;
             const uint32_t r = (uint32_t)(t.task / maxT);
             task_init(t, ix, planes, pw, off[r] + (uint64_t)e, e);
-            if (QUEUED) {
-                const uint32_t n0 = (t_info[t.task] >> 8) & 0xffu;
-                if (n0 > 1) { t.sp = t_sp[t.task]; t.ep = t_ep[t.task]; t.n = (int)n0; t.active = t.n < t.nlim; }
-            }
         }
         for (;;) {
             bool any = false;
@@ -336,7 +325,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (have[u]) task_finish(T[u], ql == 0, t_sp, t_ep, t_info, t_cnt);
+            if (T[u].task < n_tasks) task_finish(T[u], ql == 0, t_sp, t_ep, t_info, t_cnt);
     }
     // one atomic pair per wave (the grid is capped, so a few thousand per launch) for the work counters
     unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), l = wave_sum_u64(ql == 0 ? live : 0);
@@ -402,58 +391,252 @@ __global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restric
     }
 }
 
-// k_lookup: lane per slot of the task table.  Answers every task the table can answer -- all of them when K = 15 --
-// and queues the rest for k_search<QUEUED>: tasks longer than K (resume at n = K), tasks in front of a base outside
-// ACGTN that stop before 8 bases, and entries whose range did not fit (both from n = 1).
-__global__ __launch_bounds__(256) void k_lookup(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
-                                                 const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
-                                                 const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
-                                                 uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
-                                                 uint32_t *__restrict__ t_cnt, uint32_t *__restrict__ queue, Counters *ctr) {
+// What a finished read hands to the cluster stage: P = seeds in all, Qty = sub-reads that returned a seed list
+// (sga.erl:32); reads with Qty < 2 cluster to [] (sga.erl:42-43) and get P = 0; reads with more than 64 seeds go to
+// the queues of the wider cluster kernels.  Reached by whole waves (wave_append); `active` lanes carry a read.
+#define RQ_CRASH 0x80000000u
+#define RQ_PENDING 0x40000000u
+__device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned long long P, uint32_t qty, uint32_t crash,
+                                            uint32_t maxT, uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
+                                            uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
+                                            uint32_t *__restrict__ mid4q, Counters *ctr, unsigned long long &Psum) {
+    if (qty < 2 || crash) P = 0;
+    if (active && P > 0x7fffffffull) { atomicOr(&ctr->err_flags, 1ull); P = 0; }
+    if (active) { r_P[r] = (uint32_t)P; r_qty[r] = qty | (crash ? RQ_CRASH : 0u); }
+    const bool big = active && (P > 256 || (P > 0 && maxT > 64)), m4 = active && !big && P > 128, m2 = active && !big && !m4 && P > 64;
+    const uint32_t ib = wave_append(&ctr->n_big, big), i4 = wave_append(&ctr->n_mid4, m4), i2 = wave_append(&ctr->n_mid2, m2);
+    if (big) bigq[ib] = r;
+    if (m4) mid4q[i4] = r;
+    if (m2) mid2q[i2] = r;
+    if (active) Psum += P;
+}
+
+// k_seed_tasks: the seed stage with the suffix-interval table.  A wave takes 64 / maxT reads at a time, lane = one
+// task slot of one read (so the five task-table columns are written as contiguous runs):
+//   * the slot's sub-read (sga:sga/9 + skip_Ns, as k_subreads): a read without N has its k-th sub-read end at
+//     len - 8k; only reads that hold an N walk the skip_Ns chain;
+//   * one table read answers the task; what the table cannot finish -- sub-reads longer than K (they resume at n = K),
+//     searches that stop before 8 bases in front of a base outside ACGTN, entries whose range did not fit -- becomes a
+//     bit of r_pend[r] for k_search_pending;
+//   * ballots and one wave prefix sum total each read for the cluster stage (as k_read_counts) when nothing is pending.
+// RAW: one task per "read", already in t_def (bwt_find_seeds_batch).  1 <= maxT <= 64.
+template <bool RAW>
+__global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
+                                                     const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
+                                                     uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
+                                                     uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
+                                                     uint32_t *__restrict__ t_cnt, unsigned long long *__restrict__ r_pend,
+                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
+                                                     uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
+                                                     uint32_t *__restrict__ mid4q, Counters *ctr) {
     const int K = ix.kt_k;
+    const uint32_t *np = planes + RP_N * pw;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t rw = 64u / maxT;                               // reads per wave pass
+    const uint32_t lread = lane / maxT, slot = lane - lread * maxT;
+    const uint32_t seg0 = lread * maxT;                           // first lane of my read
+    const unsigned long long segmask = maxT == 64 ? ~0ull : ((1ull << maxT) - 1ull);
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t groups = (n + rw - 1) / rw;
     uint32_t live = 0, looked = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (n_tasks + stride - 1) / stride;      // every lane takes part in every wave_append
-    for (uint64_t it = 0; it < rounds; it++) {
-        const uint64_t w = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        LfTask t;
-        t.task = w;
-        t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
-        t.check_at_limit = true; t.check = true; t.active = false;
+    unsigned long long Psum = 0;
+    for (uint32_t g = wave; g < groups; g += nwaves) {
+        const uint32_t r = g * rw + lread;
+        const bool valid = lread < rw && r < n;
+        LfTask tk;
+        tk.task = (uint64_t)r * maxT + slot;
+        tk.sp = 0; tk.ep = 0; tk.lo16 = 0; tk.hi16 = 0; tk.status = TS_NONE; tk.n = 0; tk.nlim = 0;
+        tk.check_at_limit = true; tk.check = true; tk.active = false;
         bool pending = false;
-        const int e = w < n_tasks ? (int)(t_def[w] & 0xffffu) : 0;
-        if (e > 0) {
-            live++;
-            task_init(t, ix, planes, pw, off[(uint32_t)(w / maxT)] + (uint64_t)e, e);
-            if (t.active) {
-                pending = true;
-                if (t.nlim >= KT_MIN) {
-                    const int m = t.nlim < K ? t.nlim : K;
+        uint32_t status = TS_NONE, c = 0;
+        if (valid) {
+            const uint64_t P0 = off[r];
+            int e = 0;
+            if (RAW) e = (int)(t_def[tk.task] & 0xffffu);
+            else {
+                const int len = (int)(off[r + 1] - P0);
+                uint32_t anyN = 0;
+                for (int i = 0; i < len; i += 32) {
+                    uint32_t w = plane_bits(np, P0 + (uint64_t)i);
+                    if (len - i < 32) w &= (1u << (len - i)) - 1u;
+                    anyN |= w;
+                }
+                uint32_t shsk = 0;
+                if (!anyN) {                                      // sub-read k ends at len - 8k, nothing skipped
+                    e = len - (int)(BWT_MIN_LEN * slot);
+                    shsk = BWT_MIN_LEN * slot;
+                    if (e < BWT_MIN_LEN) e = 0;
+                } else {                                          // the chain of k_subreads up to this slot
+                    int l2 = len;
+                    uint32_t shift = 0;
+                    for (uint32_t t = 0;; t++) {
+                        e = 0;
+                        if (l2 < BWT_MIN_LEN) break;               // sga.erl:69
+                        int ee = l2;
+                        bool ok = true;
+                        for (;;) {
+                            if (ee < BWT_MIN_LEN) { ok = false; break; }     // list exhausted before J reached 8 (sga.erl:76)
+                            const uint32_t w7 = plane_bits(np, P0 + (uint64_t)(ee - 8)) & 0x7fu;
+                            if (!w7) break;
+                            ee = ee - 7 + (31 - __clz((int)w7));   // the sub-read now ends in that N
+                        }
+                        if (!ok) break;
+                        const uint32_t skipped = (uint32_t)(l2 - ee);
+                        if (t == slot) { e = ee; shsk = shift + skipped; break; }
+                        l2 = ee - BWT_MIN_LEN;
+                        shift += BWT_MIN_LEN + skipped;
+                    }
+                }
+                t_def[tk.task] = e > 0 ? ((uint32_t)e | (shsk << 16)) : 0u;
+            }
+            if (e > 0) {
+                live++;
+                task_init(tk, ix, planes, pw, P0 + (uint64_t)e, e);
+                pending = tk.active;
+                if (tk.active && tk.nlim >= KT_MIN) {
+                    const int m = tk.nlim < K ? tk.nlim : K;
                     const uint32_t mask = (1u << m) - 1u;
-                    const uint64_t key = (uint64_t)((t.lo16 >> (16 - m)) & mask) | ((uint64_t)((t.hi16 >> (16 - m)) & mask) << m);
+                    const uint64_t key = (uint64_t)((tk.lo16 >> (16 - m)) & mask) | ((uint64_t)((tk.hi16 >> (16 - m)) & mask) << m);
                     const uint64_t ent = ix.ktab[kt_level_off(m) + key];
                     looked++;
                     const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF;
                     if (wd != KT_OVF) {
-                        t.sp = (uint32_t)ent; t.ep = t.sp + wd; t.n = (int)(ent >> 60);
-                        if (t.n < m) { t.check = false; pending = false; }                          // not_found inside the table
-                        else if (m == t.nlim) { t.check = t.check_at_limit; pending = false; }
+                        tk.sp = (uint32_t)ent; tk.ep = tk.sp + wd; tk.n = (int)(ent >> 60);
+                        if (tk.n < m) { tk.check = false; pending = false; }                          // not_found inside the table
+                        else if (m == tk.nlim) { tk.check = tk.check_at_limit; pending = false; }
                     }
                 }
             }
+            status = tk.status;
+            if (pending) status = TS_NONE;
+            else if (status == TS_SEEDS) {
+                if (tk.n >= tk.nlim && tk.check) tk.check = tk.check_at_limit;          // tasks that never stepped
+                if (tk.check && tk.ep - tk.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
+                else if (tk.n < BWT_MIN_LEN) status = TS_NO_SEEDS;                      // fmi.erl:89
+            }
+            c = (!pending && status == TS_SEEDS) ? tk.ep - tk.sp + 1 : 0;
+            t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
         }
-        const uint32_t qi = wave_append(&ctr->sq_count, pending);
-        if (pending) {
-            queue[qi] = (uint32_t)w;
-            t_sp[w] = t.sp; t_ep[w] = t.ep; t_info[w] = TS_NONE | ((uint32_t)t.n << 8);
-        } else if (w < n_tasks) {
-            task_finish(t, true, t_sp, t_ep, t_info, t_cnt);
+        // per-read totals: the read's lanes are [seg0, seg0 + maxT)
+        const unsigned long long bp = __ballot(pending), bs = __ballot(valid && !pending && status == TS_SEEDS),
+                                 bc = __ballot(valid && tk.status == TS_CRASH);
+        unsigned long long incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long up = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += up; }
+        const unsigned long long hi = __shfl(incl, (int)((seg0 + maxT - 1) & 63u), 64), lo = __shfl(incl, (int)((seg0 - 1) & 63u), 64);
+        const unsigned long long P = hi - (seg0 ? lo : 0ull);
+        const unsigned long long pend = (bp >> seg0) & segmask;
+        const uint32_t qty = (uint32_t)__popcll((bs >> seg0) & segmask), crash = ((bc >> seg0) & segmask) ? 1u : 0u;
+        const bool leader = valid && slot == 0;
+        if (leader) {
+            r_pend[r] = pend;
+            if (pend) {                                           // k_search_pending adds its share and finishes the read
+                r_P[r] = (uint32_t)(P > 0x7fffffffull ? 0x7fffffffull : P);
+                r_qty[r] = qty | (crash ? RQ_CRASH : 0u) | RQ_PENDING;
+            }
         }
+        read_finish(leader && !pend, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum);
     }
-    unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked);
-    if ((threadIdx.x & 63) == 0 && (l | k)) {
+    unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum);
+    if (lane == 0 && (l | k | s)) {
         atomicAdd(&ctr->n_tasks, l);
         atomicAdd(&ctr->kt_lookups, k);
+        atomicAdd(&ctr->sa_reads, s);
+    }
+}
+
+// k_search_pending: the LF steps the table left over.  A wave scans 64 reads' r_pend words at a time; reads with work
+// are handed to its 16 quads, each quad takes its read's pending tasks in turn (from the (Sp, Ep, n) k_seed_tasks
+// stored, two 16-byte-per-lane block loads per step as in k_search), then totals the read.  No queue, no atomics.
+__global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
+                                                         const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
+                                                         const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
+                                                         uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
+                                                         uint32_t *__restrict__ t_cnt,
+                                                         const unsigned long long *__restrict__ r_pend,
+                                                         uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
+                                                         uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
+                                                         uint32_t *__restrict__ mid4q, Counters *ctr) {
+    __shared__ uint32_t slot_[4][64];
+    uint32_t *slot = slot_[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const int ql = (int)(lane & 3);
+    const uint32_t qi = lane >> 2;
+    const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t steps = 0;
+    unsigned long long Psum = 0;
+    for (uint32_t chunk = wave; (uint64_t)chunk * 64 < n; chunk += nwaves) {
+        const uint32_t rl = chunk * 64 + lane;
+        const unsigned long long mine = rl < n ? r_pend[rl] : 0ull;
+        const unsigned long long bal = __ballot(mine != 0);
+        if (!bal) continue;
+        const uint32_t nwork = (uint32_t)__popcll(bal);
+        if (mine) slot[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b0 = 0; b0 < nwork; b0 += 16) {
+            const bool have = b0 + qi < nwork;
+            const uint32_t src = have ? slot[b0 + qi] : 0u;
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)src, 64);
+            unsigned long long m = have ? ((unsigned long long)hi << 32) | lo : 0ull;
+            const uint32_t r = chunk * 64 + src;
+            unsigned long long P = 0;
+            uint32_t qty = 0, crash = 0;
+            if (have) { P = r_P[r]; const uint32_t q0 = r_qty[r]; qty = q0 & 0x3fffffffu; crash = q0 >> 31; }
+            const uint64_t tb = (uint64_t)r * maxT;
+            const uint64_t P0 = have ? off[r] : 0;
+            while (__ballot(m != 0)) {                            // quads step their tasks side by side
+                LfTask t;
+                t.task = tb; t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
+                t.check_at_limit = true; t.check = true; t.active = false;
+                const bool work = m != 0;
+                if (work) {
+                    const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+                    m &= m - 1ull;
+                    t.task = tb + k;
+                    const int e = (int)(t_def[t.task] & 0xffffu);
+                    task_init(t, ix, planes, pw, P0 + (uint64_t)e, e);
+                    const uint32_t n0 = (t_info[t.task] >> 8) & 0xffu;
+                    if (n0 > 1) { t.sp = t_sp[t.task]; t.ep = t_ep[t.task]; t.n = (int)n0; t.active = t.n < t.nlim; }
+                }
+                while (__ballot(t.active)) {
+                    if (t.active) {
+                        const uint32_t b1 = (t.sp - 1) / BWT_BLOCK_ROWS, b2 = (t.ep - 1) / BWT_BLOCK_ROWS;
+                        const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql], v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+                        const uint32_t bi = 15u - (uint32_t)t.n;
+                        steps++;
+                        if (!lf_step(ix, ql, dblk, v1, v2, b1, b2, (t.lo16 >> bi) & 1u, (t.hi16 >> bi) & 1u, t.sp, t.ep)) {
+                            t.check = false; t.active = false;
+                        } else {
+                            t.n++;
+                            if (t.n >= t.nlim) { t.check = t.check_at_limit; t.active = false; }
+                        }
+                    }
+                }
+                if (work) {
+                    LfTask f = t;
+                    uint32_t status = f.status;
+                    if (status == TS_SEEDS) {
+                        if (f.n >= f.nlim && f.check) f.check = f.check_at_limit;
+                        if (f.check && f.ep - f.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
+                        else if (f.n < BWT_MIN_LEN) status = TS_NO_SEEDS;
+                    }
+                    const uint32_t c = status == TS_SEEDS ? f.ep - f.sp + 1 : 0;
+                    if (ql == 0) { t_sp[f.task] = f.sp; t_ep[f.task] = f.ep; t_info[f.task] = status | ((uint32_t)f.n << 8); t_cnt[f.task] = c; }
+                    if (status == TS_SEEDS) { qty++; P += c; }
+                    else if (status == TS_CRASH) crash = 1;
+                }
+            }
+            read_finish(have && ql == 0, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), ps = wave_sum_u64(Psum);
+    if (lane == 0 && (s | ps)) {
+        atomicAdd(&ctr->lf_steps, s);
+        atomicAdd(&ctr->sa_reads, ps);
     }
 }
 
@@ -482,26 +665,19 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
                                                       uint32_t *__restrict__ mid2q, uint32_t *__restrict__ mid4q, Counters *ctr) {
     // grid-stride (capped grid): one counter atomic per wave for the whole launch, not per 64 reads
     unsigned long long Psum = 0;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t r = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         unsigned long long P = 0;
         uint32_t qty = 0, crash = 0;
-        for (uint32_t k = 0; k < maxT; k++) {
-            uint32_t st = t_info[(uint64_t)r * maxT + k] & 0xff;
-            if (st == TS_SEEDS) { qty++; P += t_cnt[(uint64_t)r * maxT + k]; }
-            else if (st == TS_CRASH) crash = 1;
-        }
-        if (qty < 2 || crash) P = 0;
-        if (P > 0x7fffffffull) { atomicOr(&ctr->err_flags, 1ull); P = 0; }
-        r_P[r] = (uint32_t)P;
-        r_qty[r] = qty | (crash << 31);
-        {
-            const bool big = P > 256 || (P > 0 && maxT > 64), m4 = !big && P > 128, m2 = !big && !m4 && P > 64;
-            const uint32_t ib = wave_append(&ctr->n_big, big), i4 = wave_append(&ctr->n_mid4, m4), i2 = wave_append(&ctr->n_mid2, m2);
-            if (big) bigq[ib] = r;
-            if (m4) mid4q[i4] = r;
-            if (m2) mid2q[i2] = r;
-        }
-        Psum += P;
+        if (r < n)
+            for (uint32_t k = 0; k < maxT; k++) {
+                uint32_t st = t_info[(uint64_t)r * maxT + k] & 0xff;
+                if (st == TS_SEEDS) { qty++; P += t_cnt[(uint64_t)r * maxT + k]; }
+                else if (st == TS_CRASH) crash = 1;
+            }
+        read_finish(r < n, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum);
     }
     unsigned long long s = wave_sum_u64(Psum);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&ctr->sa_reads, s);
@@ -1060,6 +1236,7 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 //   * square window (W = Lq, i.e. D = 0) and at most one mismatch on its only full diagonal -> done as
 //     well: every other path into the last row contains an insertion (loss >= 4 > 3), so the diagonal is
 //     the unique optimum, every cell on it ties or wins as up_left, and no column left of Lq reaches it;
+//     two mismatches -> done unless one of the two single-insertion detours (see the code) exists;
 //   * everything else -> DP queue (dense, so the DP kernels' lanes stay full).
 __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
     const uint32_t *qlo = io.qplanes + RP_LO * io.qpw, *qhi = io.qplanes + RP_HI * io.qpw;
@@ -1093,16 +1270,44 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
                     bool done = false;
                     int score = 2 * (int)lq;
                     if (w == lq) {
-                        // square window: one full diagonal.  With <= 1 mismatch on it (loss <= 3) it is the unique optimum:
-                        // any other path into the last row needs an insertion (gap -2 and a lost match -2: loss >= 4).
-                        uint32_t mism = 0;
-                        for (uint32_t i = 0; i < lq && mism <= 1; i += 32) {
+                        // square window: one full diagonal with m mismatches at p1 <= p2, score 2*Lq - 3m.  Every other path
+                        // into a diagonal cell or into the last row holds u >= 1 insertions, and a run of g gap steps costs
+                        // g + 1: u >= 2 loses >= 7, u = 1 loses >= 4.  m <= 1 (loss <= 3): the diagonal is the unique optimum.
+                        // m = 2 (loss 6): only two kinds of path can reach it -- one insertion and otherwise all matches:
+                        //   (a) into a diagonal cell past p2: start one column in, ride diagonal +1 (q[k] = r[k+1]) for every
+                        //       k < t, insert q[t], t >= p2: exists iff the first f1 = #leading matches on diagonal +1 >= p2;
+                        //   (b) into the last row at column Lq-1 (a tie there would be the LEFTMOST maximum): main diagonal
+                        //       for k < t <= p1, insert q[t], then diagonal -1 (q[k] = r[k-1]) for every k > t: exists iff
+                        //       the highest mismatch on diagonal -1 sits at h <= p1.
+                        // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
+                        // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
+                        uint32_t mism = 0, p1 = 0, p2 = 0;
+                        for (uint32_t i = 0; i < lq && mism <= 2; i += 32) {
                             uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
                                          (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + i));
                             if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
-                            mism += __popc(e);
+                            if (e) {
+                                if (!mism) p1 = i + (uint32_t)__ffs((int)e) - 1u;
+                                p2 = i + 31u - (uint32_t)__clz((int)e);
+                                mism += __popc(e);
+                            }
                         }
                         done = mism <= 1 && lq >= 8;
+                        if (mism == 2 && lq >= 8) {
+                            // diagonals +1 and -1 hold Lq-1 pairs each: bit i of e_up = (q[i] != r[i+1]), of e_dn = (q[i+1] != r[i])
+                            uint32_t f1 = lq - 1, h = 0;
+                            bool seen = false;
+                            for (uint32_t i = 0; i + 1 < lq; i += 32) {
+                                uint32_t eu = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + 1 + i)) |
+                                              (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + 1 + i));
+                                uint32_t ed = (plane_bits(qlo, qo + 1 + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
+                                              (plane_bits(qhi, qo + 1 + i) ^ plane_bits(whi, (uint64_t)wo + i));
+                                if (lq - 1 - i < 32) { const uint32_t mk = (1u << (lq - 1 - i)) - 1u; eu &= mk; ed &= mk; }
+                                if (eu && !seen) { f1 = i + (uint32_t)__ffs((int)eu) - 1u; seen = true; }
+                                if (ed) h = i + 32u - (uint32_t)__clz((int)ed);          // k = bit + 1
+                            }
+                            done = !(f1 >= p2) && !(h <= p1);
+                        }
                         score -= 3 * (int)mism;
                     } else if (w > lq && w - lq <= 64) {
                         for (uint32_t d = 0; d + lq <= w && !done; d++) {

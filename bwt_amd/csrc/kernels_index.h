@@ -67,16 +67,18 @@ static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__res
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t nchunks = (total + 63) >> 6;
-    // four independent 64-byte loads in flight per wave before any of them is consumed
-    for (uint64_t c0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c0 < nchunks; c0 += 4 * nwaves) {
-        uint32_t ch[4];
+    // RP_U independent 64-byte loads in flight per wave before any of them is consumed: the kernel is a pure stream and
+    // bytes in flight per wave set its rate (4 loads: 1.0 TB/s)
+    constexpr int RP_U = 16;
+    for (uint64_t c0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c0 < nchunks; c0 += RP_U * nwaves) {
+        uint32_t ch[RP_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < RP_U; u++) {
             const uint64_t pos = (c0 + (uint64_t)u * nwaves) * 64 + lane;
             ch[u] = pos < total ? bases[pos] : 'A';
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < RP_U; u++) {
             const uint64_t ci = c0 + (uint64_t)u * nwaves;
             if (ci >= nchunks) break;
             const uint32_t c = ch[u];
@@ -99,6 +101,6 @@ __device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plan
 
 struct Counters {          // device-side work counters (roofline accounting)
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags, kt_lookups;
-    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, sq_count;
+    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, pad_;
 };
 

@@ -351,6 +351,71 @@ def test_prefilter_shortcuts_on_low_complexity_pairs():
     assert nshort > 200
 
 
+def test_prefilter_two_mismatch_detours():
+    """Square window, two mismatches on the diagonal: the prefilter answers {2Lq-6, "<Lq>M"} unless one of two
+    single-insertion detours exists (k_sw_prefilter).  Inputs built to contain exactly those detours and their
+    near misses -- run-structured references read one base off the diagonal before / after an inserted base --
+    plus two-letter random pairs where off-diagonal matches are common."""
+    from bwt_amd import lib
+    from oracle import orc
+    rng = np.random.default_rng(321)
+    acgt = b"ACGT"
+    qs, rs = [], []
+
+    def runs(lens, tail):
+        out = bytearray()
+        for i, n in enumerate(lens):
+            out += bytes([acgt[i & 3]]) * n
+        return out + bytes(rng.choice(list(acgt), tail).tolist())
+
+    for a in (1, 2, 4):
+        for b in (1, 3, 5):
+            for c in (1, 2, 6):
+                for tail in (0, 3, 20, 60):
+                    r = runs((a, b, c), tail)
+                    L = len(r)
+                    if L < 8:
+                        continue
+                    for t in range(0, min(L, a + b + c + 2)):
+                        q = bytearray(r)                       # detour (a): diagonal +1 up to t, then the main diagonal
+                        for k in range(min(t, L - 1)):
+                            q[k] = r[k + 1]
+                        qs.append(bytes(q)); rs.append(bytes(r))
+                        q2 = bytearray(q)                      # ... and the inserted base itself mismatching
+                        q2[min(t, L - 1)] = acgt[(acgt.index(q2[min(t, L - 1)]) + 1) & 3]
+                        qs.append(bytes(q2)); rs.append(bytes(r))
+                    rr = bytes(r[::-1])                        # detour (b): the mirror image, runs at the window's end
+                    for t in range(max(0, L - (a + b + c + 2)), L):
+                        q = bytearray(rr)
+                        for k in range(t + 1, L):
+                            q[k] = rr[k - 1]
+                        qs.append(bytes(q)); rs.append(rr)
+                        q2 = bytearray(q)
+                        q2[t] = acgt[(acgt.index(q2[t]) + 1) & 3]
+                        qs.append(bytes(q2)); rs.append(rr)
+    for lq in (8, 9, 12, 16, 33, 40):
+        for _ in range(1500):
+            r = bytes(rng.choice(list(b"AC"), lq).tolist())
+            q = bytearray(r)
+            for p in rng.choice(lq, 2, replace=False):
+                q[p] = b"C"[0] if q[p] == b"A"[0] else b"A"[0]
+            qs.append(bytes(q)); rs.append(r)
+    out = lib.sw_batch(*lib.pack_reads(qs), *lib.pack_reads(rs))
+    ndiag = nother = 0
+    for i in range(len(qs)):
+        exp = orc.sw(qs[i], rs[i])
+        if exp == "no_match":
+            assert out["status"][i] == 1, (qs[i], rs[i])
+            continue
+        cig = out["cigar"][int(out["cig_off"][i]):int(out["cig_off"][i + 1])].decode()
+        assert (out["status"][i], int(out["score"][i]), cig) == (0, exp[0], exp[1]), (qs[i], rs[i])
+        if cig == "%dM" % len(qs[i]):
+            ndiag += 1
+        else:
+            nother += 1
+    assert ndiag > 2000 and nother > 300          # both outcomes are well represented
+
+
 def test_edge_batches(gpu_index, orc_fm, ref_bytes):
     """Empty batch, reads shorter than MIN_LEN, a single read, and 600 bp reads (more than 64 sub-reads:
     the workgroup clustering path and the generic strip kernels)."""
