@@ -22,18 +22,27 @@ extern "C" void bwt_constants(bwt_constants_t *o) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bit-planes of a resident byte stream (k_read_planes); the words past the last base are zeroed so that windows may run on
+static int launch_planes(const uint8_t *bases, uint64_t total, uint32_t *planes, int device, hipStream_t stream) {
+    const uint64_t words = rp_words(total), used = ((total + 31) / 32) * 4;
+    HIPCHK(hipMemsetAsync(planes + used, 0, (words - used) * 4, stream));
+    if (total) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total / 16 + 256) / 256, (uint64_t)cus * 16));
+        hipLaunchKernelGGL(k_read_planes, dim3(grid), dim3(256), 0, stream, bases, total, planes);
+    }
+    return 0;
+}
+
 int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream) {
-    const uint64_t pw = ((ix->ref1_len + 63) / 64) * 2 + 8;
-    int rc = ix->refplanes.exact(pw * 4 * 4);
+    int rc = ix->refplanes.exact(rp_words(ix->ref1_len) * 4);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(ix->refplanes.p, 0, pw * 4 * 4, stream));
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((ix->ref1_len + 255) / 256, 2048));
-    hipLaunchKernelGGL(k_read_planes, dim3(grid), dim3(256), 0, stream, ix->ref1.as<uint8_t>(), ix->ref1_len,
-                       ix->refplanes.as<uint32_t>(), pw);
+    if ((rc = launch_planes(ix->ref1.as<uint8_t>(), ix->ref1_len, ix->refplanes.as<uint32_t>(), ix->device, stream))) return rc;
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipGetLastError());
     ix->d.rplanes = ix->refplanes.as<uint32_t>();
-    ix->d.rpw = pw;
+    ix->d.rpw = rp_words(ix->ref1_len);
     return 0;
 }
 
@@ -202,7 +211,7 @@ extern "C" int bwt_index_meta(const bwt_index *ix, uint32_t out[5]) {
 
 extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[4]) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_device_bytes: null argument");
-    out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len + ix->d.rpw * 16;
+    out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len + ix->d.rpw * 4;
     out[3] = ix->d.kt_k ? kt_entries(ix->d.kt_k) * 8 : 0;
     return 0;
 }
@@ -266,7 +275,6 @@ struct bwt_batch {
     uint32_t n = 0, maxT = 0, max_lq = 0;
     uint64_t total_bases = 0;
     DevBuf bases, off, rplanes;
-    uint64_t pw = 0;                 // words per read bit-plane
     // tasks
     DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend;
     bool counts_done = false;          // the search stage already totalled the reads (k_seed_tasks)
@@ -453,17 +461,10 @@ static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks, bool u2 = true) {
 
 // reads -> bit-planes over the concatenated byte stream (k_read_planes); part of every search pass
 static int read_planes(bwt_batch *b) {
-    b->pw = ((b->total_bases + 63) / 64) * 2 + 8;
-    int rc = b->rplanes.ensure(b->pw * 4 * 4);
+    int rc = b->rplanes.ensure(rp_words(b->total_bases) * 4);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(b->rplanes.p, 0, b->pw * 4 * 4, b->stream));
-    if (b->total_bases) {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(b->total_bases, 256), (uint64_t)cus * 8));
-        KLAUNCH(b, "read_planes", k_read_planes, grid, 256, b->bases.as<uint8_t>(), b->total_bases, b->rplanes.as<uint32_t>(), b->pw);
-    }
-    return 0;
+    ProfScope ps(b, "read_planes");
+    return launch_planes(b->bases.as<uint8_t>(), b->total_bases, b->rplanes.as<uint32_t>(), b->device, b->stream);
 }
 
 static int fetch_counters(bwt_batch *b) {
@@ -488,7 +489,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
         const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(cdiv(n, 64 / maxT), 4), (uint64_t)cus * 8);   // wave per 64/maxT reads
-#define SEED_ARGS b->ix->d, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT, b->t_def.as<uint32_t>(),          \
+#define SEED_ARGS b->ix->d, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT, b->t_def.as<uint32_t>(),          \
                   b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),               \
                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),       \
                   b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>()
@@ -499,12 +500,12 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw) {
         b->counts_done = true;
     } else {
         if (!raw)
-            KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->pw, b->off.as<uint64_t>(), n, maxT,
+            KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT,
                     b->t_def.as<uint32_t>());
         static const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
         const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
         KLAUNCH(b, "fm_search", (u2 ? k_search<2> : k_search<1>), search_grid(b, T, u2), 256, b->ix->d, b->rplanes.as<uint32_t>(),
-                b->pw, b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
+                b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
                 b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
     }
     return 0;
@@ -549,7 +550,9 @@ static int stage_cluster(bwt_batch *b) {
     if (b->hctr.err_flags & 1) return fail(BWT_EOVERFLOW, "a read produced more than 2^31 seeds");
     if (total_seeds > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 seeds: split it");
     if ((rc = b->pos.ensure(total_seeds * 4 + 16))) return rc;
-    KLAUNCH(b, "cluster_small", k_cluster_small, cdiv((uint64_t)n * 64, 256), 256, b->ix->d, n, maxT,
+    int cl_cus = 256;
+    (void)hipDeviceGetAttribute(&cl_cus, hipDeviceAttributeMultiprocessorCount, b->device);
+    KLAUNCH(b, "cluster_small", k_cluster_small, (uint32_t)std::min<uint64_t>(cdiv((uint64_t)n * 64, 256), (uint64_t)cl_cus * 8), 256, b->ix->d, n, maxT,
             b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
             b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
             b->r_K.as<uint32_t>());
@@ -592,7 +595,7 @@ static int stage_cluster(bwt_batch *b) {
 // SW_TRACE over the candidates whose alignment is not the plain diagonal (and those too wide for the
 // LDS pass), then SW_FP over the candidates that met a base outside ACGT.
 static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
-                  uint32_t max_lq, const uint32_t *qplanes, uint64_t qpw, const uint32_t *wplanes, uint64_t wpw) {
+                  uint32_t max_lq, const uint32_t *qplanes, const uint32_t *wplanes) {
     const uint64_t nc = b->n_cand;
     int rc;
     if ((rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) ||
@@ -612,7 +615,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
-    io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.qpw = qpw; io.wpw = wpw;
+    io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes;
     static const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
     if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
         io.dq = b->dq.as<uint32_t>();
@@ -738,10 +741,10 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
 }
 
 static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
-                        uint32_t max_lq, int32_t shift, const uint32_t *qplanes = nullptr, uint64_t qpw = 0,
-                        const uint32_t *wplanes = nullptr, uint64_t wpw = 0) {
+                        uint32_t max_lq, int32_t shift, const uint32_t *qplanes = nullptr,
+                        const uint32_t *wplanes = nullptr) {
     for (int attempt = 0; attempt < 8; attempt++) {
-        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq, qplanes, qpw, wplanes, wpw);
+        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq, qplanes, wplanes);
         if (rc) return rc;
         // clear the sticky CIGAR-overflow flag before counting
         Counters *dc = b->ctr.as<Counters>();
@@ -768,7 +771,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     }
     if (stages & BWT_STAGE_EXTEND) {
         if ((rc = stage_extend(b, b->bases.as<uint8_t>(), b->ix->d.ref1, b->ix->d.ref1_len, b->hctr.max_w, b->hctr.max_lq,
-                               b->ix->shift, b->rplanes.as<uint32_t>(), b->pw, b->ix->d.rplanes, b->ix->d.rpw)))
+                               b->ix->shift, b->rplanes.as<uint32_t>(), b->ix->d.rplanes)))
             return rc;
         b->done |= BWT_STAGE_EXTEND;
     }
@@ -1000,18 +1003,14 @@ extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, 
     // bit-planes of both byte streams so that the prefilter applies here as well
     DevBuf pq, pr;
     struct G3 { DevBuf &a, &b; ~G3() { a.release(); b.release(); } } g3{pq, pr};
-    const uint64_t qpw = ((qtot + 63) / 64) * 2 + 8, rpw = ((rtot + 63) / 64) * 2 + 8;
-    if ((rc = pq.ensure(qpw * 16)) || (rc = pr.ensure(rpw * 16))) return rc;
-    HIPCHK(hipMemsetAsync(pq.p, 0, qpw * 16, b->stream));
-    HIPCHK(hipMemsetAsync(pr.p, 0, rpw * 16, b->stream));
-    if (n) {
-        KLAUNCH(b, "read_planes", k_read_planes, std::min<uint32_t>(cdiv(qtot, 256), 2048), 256, dq.as<uint8_t>(), qtot,
-                pq.as<uint32_t>(), qpw);
-        KLAUNCH(b, "read_planes", k_read_planes, std::min<uint32_t>(cdiv(rtot, 256), 2048), 256, dr.as<uint8_t>(), rtot,
-                pr.as<uint32_t>(), rpw);
+    if ((rc = pq.ensure(rp_words(qtot) * 4)) || (rc = pr.ensure(rp_words(rtot) * 4))) return rc;
+    {
+        ProfScope ps(b, "read_planes");
+        if ((rc = launch_planes(dq.as<uint8_t>(), qtot, pq.as<uint32_t>(), b->device, b->stream)) ||
+            (rc = launch_planes(dr.as<uint8_t>(), rtot, pr.as<uint32_t>(), b->device, b->stream)))
+            return rc;
     }
-    if ((rc = stage_extend(b, dq.as<uint8_t>(), dr.as<uint8_t>(), rtot, max_w, max_lq, 0, pq.as<uint32_t>(), qpw,
-                           pr.as<uint32_t>(), rpw)))
+    if ((rc = stage_extend(b, dq.as<uint8_t>(), dr.as<uint8_t>(), rtot, max_w, max_lq, 0, pq.as<uint32_t>(), pr.as<uint32_t>())))
         return rc;
     if (cig_needed) *cig_needed = b->cig_bytes;
     std::vector<int32_t> cst(n), csc(n);

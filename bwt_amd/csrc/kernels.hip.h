@@ -111,12 +111,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(uint64_t *__restrict__ out
 // last base hold no N.  On the is-N plane that is: while the 7-bit window [e-8, e-2] is non-zero, move e to
 // just past its highest set bit.
 // task word = end (exclusive, = len(Qseq1)) | (Shift+Skip) << 16 ; 0 = no task.
-__global__ __launch_bounds__(256) void k_subreads(const uint32_t *__restrict__ planes, uint64_t pw,
+__global__ __launch_bounds__(256) void k_subreads(const uint32_t *__restrict__ planes,
                                                    const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
                                                    uint32_t *__restrict__ t_def) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const uint32_t *np = planes + RP_N * pw;
     const uint64_t P = off[r];
     int len = (int)(off[r + 1] - P);
     uint32_t shift = 0, t = 0;
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(256) void k_subreads(const uint32_t *__restrict__ p
         bool ok = true;
         for (;;) {
             if (e < BWT_MIN_LEN) { ok = false; break; }     // list exhausted before J reached 8 (sga.erl:76)
-            const uint32_t w7 = plane_bits(np, P + (uint64_t)(e - 8)) & 0x7fu;
+            const uint32_t w7 = plane_bits(planes, RP_N, P + (uint64_t)(e - 8)) & 0x7fu;
             if (!w7) break;
             e = e - 7 + (31 - __clz((int)w7));              // the sub-read now ends in that N
         }
@@ -186,16 +185,16 @@ struct LfTask {
 // What bwa:find_seeds/6 does before the first LF step, for the sub-read that ends (exclusive) at read base e:
 // the first range (bwa.erl:15-24), the plane windows of the (at most) 15 bases a search consumes -- [e-15, e),
 // bit 15 of each 16-bit window = base e-1, base of step n at bit 15-n -- and the step limit.
-__device__ __forceinline__ void task_init(LfTask &t, const DevIndex &ix, const uint32_t *__restrict__ planes, uint64_t pw,
+__device__ __forceinline__ void task_init(LfTask &t, const DevIndex &ix, const uint32_t *__restrict__ planes,
                                           uint64_t endp, int e) {
     uint32_t n16b, o16;
     if (endp >= 16) {
-        t.lo16 = plane_bits(planes + RP_LO * pw, endp - 16); t.hi16 = plane_bits(planes + RP_HI * pw, endp - 16);
-        n16b = plane_bits(planes + RP_N * pw, endp - 16); o16 = plane_bits(planes + RP_O * pw, endp - 16);
+        const uint4 w = planes4(planes, endp - 16);
+        t.lo16 = w.x; t.hi16 = w.y; n16b = w.z; o16 = w.w;
     } else {                                             // only the very first read of a batch
         const uint32_t sh = 16 - (uint32_t)endp;
-        t.lo16 = planes[RP_LO * pw] << sh; t.hi16 = planes[RP_HI * pw] << sh;
-        n16b = planes[RP_N * pw] << sh; o16 = planes[RP_O * pw] << sh;
+        const uint4 w = ((const uint4 *)planes)[0];
+        t.lo16 = w.x << sh; t.hi16 = w.y << sh; n16b = w.z << sh; o16 = w.w << sh;
     }
     t.lo16 &= 0xffffu; t.hi16 &= 0xffffu;
     t.status = TS_SEEDS;
@@ -271,7 +270,7 @@ __device__ __forceinline__ bool lf_step(const DevIndex &ix, int ql, uint32_t dbl
 }
 
 template <int U>
-__global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
+__global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__restrict__ planes,
                                                  const uint64_t *__restrict__ off, uint64_t n_tasks, uint32_t maxT,
                                                  const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                  uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
@@ -293,7 +292,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndex ix, const uint32_t *__r
             if (e <= 0) continue;
             live++;
             const uint32_t r = (uint32_t)(t.task / maxT);
-            task_init(t, ix, planes, pw, off[r] + (uint64_t)e, e);
+            task_init(t, ix, planes, off[r] + (uint64_t)e, e);
         }
         for (;;) {
             bool any = false;
@@ -421,7 +420,7 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 //   * ballots and one wave prefix sum total each read for the cluster stage (as k_read_counts) when nothing is pending.
 // RAW: one task per "read", already in t_def (bwt_find_seeds_batch).  1 <= maxT <= 64.
 template <bool RAW>
-__global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
+__global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t *__restrict__ planes,
                                                      const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
                                                      uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                      uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
@@ -430,7 +429,6 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                                      uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                      uint32_t *__restrict__ mid4q, Counters *ctr) {
     const int K = ix.kt_k;
-    const uint32_t *np = planes + RP_N * pw;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t rw = 64u / maxT;                               // reads per wave pass
     const uint32_t lread = lane / maxT, slot = lane - lread * maxT;
@@ -458,7 +456,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                 const int len = (int)(off[r + 1] - P0);
                 uint32_t anyN = 0;
                 for (int i = 0; i < len; i += 32) {
-                    uint32_t w = plane_bits(np, P0 + (uint64_t)i);
+                    uint32_t w = plane_bits(planes, RP_N, P0 + (uint64_t)i);
                     if (len - i < 32) w &= (1u << (len - i)) - 1u;
                     anyN |= w;
                 }
@@ -477,7 +475,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                         bool ok = true;
                         for (;;) {
                             if (ee < BWT_MIN_LEN) { ok = false; break; }     // list exhausted before J reached 8 (sga.erl:76)
-                            const uint32_t w7 = plane_bits(np, P0 + (uint64_t)(ee - 8)) & 0x7fu;
+                            const uint32_t w7 = plane_bits(planes, RP_N, P0 + (uint64_t)(ee - 8)) & 0x7fu;
                             if (!w7) break;
                             ee = ee - 7 + (31 - __clz((int)w7));   // the sub-read now ends in that N
                         }
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
             }
             if (e > 0) {
                 live++;
-                task_init(tk, ix, planes, pw, P0 + (uint64_t)e, e);
+                task_init(tk, ix, planes, P0 + (uint64_t)e, e);
                 pending = tk.active;
                 if (tk.active && tk.nlim >= KT_MIN) {
                     const int m = tk.nlim < K ? tk.nlim : K;
@@ -549,7 +547,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
 // k_search_pending: the LF steps the table left over.  A wave scans 64 reads' r_pend words at a time; reads with work
 // are handed to its 16 quads, each quad takes its read's pending tasks in turn (from the (Sp, Ep, n) k_seed_tasks
 // stored, two 16-byte-per-lane block loads per step as in k_search), then totals the read.  No queue, no atomics.
-__global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t pw,
+__global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint32_t *__restrict__ planes,
                                                          const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
                                                          const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
                                                          uint32_t *__restrict__ t_ep, uint32_t *__restrict__ t_info,
@@ -597,7 +595,7 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                     m &= m - 1ull;
                     t.task = tb + k;
                     const int e = (int)(t_def[t.task] & 0xffffu);
-                    task_init(t, ix, planes, pw, P0 + (uint64_t)e, e);
+                    task_init(t, ix, planes, P0 + (uint64_t)e, e);
                     const uint32_t n0 = (t_info[t.task] >> 8) & 0xffu;
                     if (n0 > 1) { t.sp = t_sp[t.task]; t.ep = t_ep[t.task]; t.n = (int)n0; t.active = t.n < t.nlim; }
                 }
@@ -688,6 +686,51 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
 // sort across the wave, cluster with ballots (get_similar/7): a run of consecutive gaps <= 20 with
 // Count >= 2 + Qty div 7 emits {LastPos, LastPos-FirstPos}; output in descending position order.
 // Clusters are staged as (S,D) u32 pairs in the read's own slice of `pos` (K <= P/2 pairs fit).
+// Persistent waves, software-pipelined over their reads (read i of a wave = wave + i * nwaves): the kernel is a chain
+// of dependent random reads per read (task row -> SA entries), so while read i is sorted and clustered the SA gather
+// of read i+1 and the task row of read i+2 are in flight.
+struct ClRow { uint32_t P, qty, cnt, sp, info, def; uint64_t so; };
+__device__ __forceinline__ void cl_issue_row(ClRow &w, uint32_t r, uint32_t n, uint32_t maxT, uint32_t lane,
+                                             const uint32_t *__restrict__ t_def, const uint32_t *__restrict__ t_sp,
+                                             const uint32_t *__restrict__ t_info, const uint32_t *__restrict__ t_cnt,
+                                             const uint32_t *__restrict__ r_P, const uint32_t *__restrict__ r_qty,
+                                             const uint64_t *__restrict__ seed_off) {
+    w.P = 0; w.qty = 0; w.cnt = 0; w.sp = 0; w.info = 0; w.def = 0; w.so = 0;
+    if (r < n) {
+        w.P = r_P[r]; w.qty = r_qty[r]; w.so = seed_off[r];
+        if (lane < maxT) {
+            const uint64_t t = (uint64_t)r * maxT + lane;
+            w.cnt = t_cnt[t]; w.sp = t_sp[t]; w.info = t_info[t]; w.def = t_def[t];
+        }
+    }
+}
+// seed `lane` of the read: issues its SA read, returns the raw entry and what is to be added (N + Shift + Skip)
+__device__ __forceinline__ void cl_issue_gather(const ClRow &w, const DevIndex &ix, uint32_t maxT, uint32_t lane, uint32_t *mk,
+                                                uint32_t &raw, uint32_t &madd) {
+    raw = 0; madd = 0;
+    if (w.P == 0 || w.P > 64 || maxT > 64) return;         // wave-uniform
+    const uint32_t cnt = lane < maxT ? w.cnt : 0u;
+    const uint32_t nadd = ((w.info >> 8) & 0xff) + (w.def >> 16);       // N + Shift + Skip (sga.erl:32,37-39)
+    uint32_t incl = cnt;
+    for (uint32_t o = 1; o < maxT; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const uint32_t excl = incl - cnt;
+    // seed i of the read belongs to the sub-read whose slice [excl, excl+cnt) holds i: the sub-read lanes drop their
+    // id at their slice start in a wave-private LDS row, a ballot + clz finds every lane's slice start, and three
+    // ds_bpermutes fetch that sub-read's {Sp, N+Shift+Skip}
+    mk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < maxT && cnt) mk[excl] = lane + 1;           // excl < P <= 64
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t tk = mk[lane];
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long tmask = __ballot(tk != 0);
+    const unsigned long long tb = tmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int s0 = 63 - __clzll(tb | 1ull);              // first seed slot of my sub-read
+    const uint32_t tid = __shfl(tk, s0, 64);             // its lane + 1
+    const uint32_t msp = __shfl(w.sp, (int)tid - 1, 64);
+    madd = __shfl(nadd, (int)tid - 1, 64);
+    if (lane < w.P) raw = ix.sa[msp - 1 + (lane - (uint32_t)s0)];
+}
 __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, uint32_t maxT,
                                                         const uint32_t *__restrict__ t_def,
                                                         const uint32_t *__restrict__ t_sp,
@@ -697,71 +740,64 @@ __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, 
                                                         const uint32_t *__restrict__ r_qty,
                                                         const uint64_t *__restrict__ seed_off,
                                                         uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
-    const uint32_t r = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    if (r >= n) return;
-    const uint32_t P = r_P[r];
-    if (P == 0) { if (lane == 0) r_K[r] = 0; return; }
-    if (P > 64 || maxT > 64) return;                      // k_cluster_big owns this read
-    const uint32_t qty = r_qty[r] & 0x7fffffffu;
-    uint32_t cnt = 0, sp = 0, nadd = 0;
-    if (lane < maxT) {
-        const uint64_t t = (uint64_t)r * maxT + lane;
-        cnt = t_cnt[t]; sp = t_sp[t];
-        nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);   // N + Shift + Skip (sga.erl:32,37-39)
-    }
-    uint32_t incl = cnt;
-    for (uint32_t o = 1; o < maxT; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    const uint32_t excl = incl - cnt;
-    // seed i of the read belongs to the sub-read whose slice [excl, excl+cnt) holds i: the sub-read lanes drop their
-    // id at their slice start in a wave-private LDS row, a ballot + clz finds every lane's slice start, and three
-    // ds_bpermutes fetch that sub-read's {Sp, N+Shift+Skip}
     __shared__ uint32_t mark[4][64];
     uint32_t *mk = mark[threadIdx.x >> 6];
-    mk[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < maxT && cnt) mk[excl] = lane + 1;           // excl < P <= 64
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t tk = mk[lane];
-    uint32_t p = 0xffffffffu;
-    {
-        const unsigned long long tmask = __ballot(tk != 0);
-        const unsigned long long tb = tmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-        const int s0 = 63 - __clzll(tb | 1ull);              // first seed slot of my sub-read
-        const uint32_t tid = __shfl(tk, s0, 64);             // its lane + 1
-        const uint32_t msp = __shfl(sp, (int)tid - 1, 64), madd = __shfl(nadd, (int)tid - 1, 64);
-        if (lane < P) p = ix.sa[msp - 1 + (lane - (uint32_t)s0)] + madd;
-    }
-    // bitonic sort ascending over 64 lanes
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (wave >= n) return;
+    ClRow nx;                                             // task row in flight
+    cl_issue_row(nx, wave, n, maxT, lane, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off);
+    uint32_t cP = nx.P, cqty = nx.qty, craw, cadd;        // the read being clustered: its gather is in flight
+    uint64_t cso = nx.so;
+    cl_issue_gather(nx, ix, maxT, lane, mk, craw, cadd);
+    cl_issue_row(nx, wave + nwaves, n, maxT, lane, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off);
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        // next read: its row has had a whole iteration to arrive; start its gather, then the row after that
+        const uint32_t gP = nx.P, gqty = nx.qty;
+        const uint64_t gso = nx.so;
+        uint32_t graw, gadd;
+        cl_issue_gather(nx, ix, maxT, lane, mk, graw, gadd);
+        if (r + nwaves < n) cl_issue_row(nx, r + 2 * nwaves, n, maxT, lane, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off);
+        // this read
+        const uint32_t P = cP;
+        if (P == 0) { if (lane == 0) r_K[r] = 0; }
+        else if (P <= 64 && maxT <= 64) {                          // else k_cluster_wave / k_cluster_big own this read
+            const uint32_t qty = cqty & 0x3fffffffu;
+            uint32_t p = lane < P ? craw + cadd : 0xffffffffu;
+            // bitonic sort ascending over 64 lanes
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
+            for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            uint32_t o = __shfl_xor(p, j, 64);
-            bool up = ((lane & k) == 0);
-            bool lower = ((lane & j) == 0);
-            uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
-            p = (lower == up) ? mn : mx;
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    uint32_t o = __shfl_xor(p, j, 64);
+                    bool up = ((lane & k) == 0);
+                    bool lower = ((lane & j) == 0);
+                    uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
+                    p = (lower == up) ? mn : mx;
+                }
+            }
+            const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
+            const bool valid = lane < P;
+            const bool start = valid && (lane == 0 || p - prev > BWT_TOLERANCE);
+            const bool end = valid && (lane == P - 1 || next - p > BWT_TOLERANCE);
+            const unsigned long long smask = __ballot(start);
+            const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+            const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
+            const uint32_t pfirst = __shfl(p, s_i, 64);
+            const uint32_t nthr = 2 + qty / 7;                    // sga.erl:46
+            const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
+            const unsigned long long emask = __ballot(emit);
+            if (emit) {
+                const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
+                const uint64_t o = cso + 2ull * kk;
+                pos[o] = p;
+                pos[o + 1] = p - pfirst;
+            }
+            if (lane == 0) r_K[r] = (uint32_t)__popcll(emask);
         }
+        cP = gP; cqty = gqty; cso = gso; craw = graw; cadd = gadd;
     }
-    const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
-    const bool valid = lane < P;
-    const bool start = valid && (lane == 0 || p - prev > BWT_TOLERANCE);
-    const bool end = valid && (lane == P - 1 || next - p > BWT_TOLERANCE);
-    const unsigned long long smask = __ballot(start);
-    const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
-    const uint32_t pfirst = __shfl(p, s_i, 64);
-    const uint32_t nthr = 2 + qty / 7;                    // sga.erl:46
-    const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
-    const unsigned long long emask = __ballot(emit);
-    if (emit) {
-        const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
-        const uint64_t o = seed_off[r] + 2ull * kk;
-        pos[o] = p;
-        pos[o + 1] = p - pfirst;
-    }
-    if (lane == 0) r_K[r] = (uint32_t)__popcll(emask);
 }
 
 // k_cluster_wave<R>: wave per read with 64 < P <= 64*R seeds (R = 2, 4; 150 bp reads on a large index sit
@@ -1058,7 +1094,6 @@ struct SwIO {
     uint32_t *dq;              // queue of candidates that need the DP at all (filled by k_sw_prefilter)
     uint32_t *tq2;             // traceback queue of the packed kernels (same read length, window <= cap)
     const uint32_t *qplanes, *wplanes;   // bit-planes over qbuf / rbuf (k_read_planes layout)
-    uint64_t qpw, wpw;
     Counters *ctr;
 };
 
@@ -1239,10 +1274,7 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 //     two mismatches -> done unless one of the two single-insertion detours (see the code) exists;
 //   * everything else -> DP queue (dense, so the DP kernels' lanes stay full).
 __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
-    const uint32_t *qlo = io.qplanes + RP_LO * io.qpw, *qhi = io.qplanes + RP_HI * io.qpw;
-    const uint32_t *qn = io.qplanes + RP_N * io.qpw, *qx = io.qplanes + RP_O * io.qpw;
-    const uint32_t *wlo = io.wplanes + RP_LO * io.wpw, *whi = io.wplanes + RP_HI * io.wpw;
-    const uint32_t *wn = io.wplanes + RP_N * io.wpw, *wx = io.wplanes + RP_O * io.wpw;
+    const uint32_t *qp = io.qplanes, *wp = io.wplanes;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t c0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); c0 < n_items; c0 += stride) {   // whole waves iterate together
         const uint32_t c = c0 + (threadIdx.x & 63);
@@ -1254,22 +1286,35 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
             if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
                 io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
             } else {
-                uint32_t bad = 0;
+                // one pass over read and window: bases outside ACGT anywhere, and (square window) the mismatches of the diagonal
+                uint32_t bad = 0, mism = 0, p1 = 0, p2 = 0;
+                const bool square = w == lq;
                 for (uint32_t i = 0; i < lq; i += 32) {
-                    uint32_t m = plane_bits(qn, qo + i) | plane_bits(qx, qo + i);
-                    if (lq - i < 32) m &= (1u << (lq - i)) - 1u;
-                    bad |= m;
+                    const uint4 q4 = planes4(qp, qo + i);
+                    const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
+                    bad |= (q4.z | q4.w) & mk;
+                    if (square) {
+                        const uint4 w4 = planes4(wp, (uint64_t)wo + i);
+                        bad |= (w4.z | w4.w) & mk;
+                        const uint32_t e = ((q4.x ^ w4.x) | (q4.y ^ w4.y)) & mk;
+                        if (e) {
+                            if (!mism) p1 = i + (uint32_t)__ffs((int)e) - 1u;
+                            p2 = i + 31u - (uint32_t)__clz((int)e);
+                            mism += __popc(e);
+                        }
+                    }
                 }
-                for (uint32_t i = 0; i < w; i += 32) {
-                    uint32_t m = plane_bits(wn, (uint64_t)wo + i) | plane_bits(wx, (uint64_t)wo + i);
-                    if (w - i < 32) m &= (1u << (w - i)) - 1u;
-                    bad |= m;
-                }
+                if (!square)
+                    for (uint32_t i = 0; i < w; i += 32) {
+                        const uint4 w4 = planes4(wp, (uint64_t)wo + i);
+                        const uint32_t mk = w - i < 32 ? (1u << (w - i)) - 1u : 0xffffffffu;
+                        bad |= (w4.z | w4.w) & mk;
+                    }
                 if (bad) { io.c_status[c] = CS_NEED_FP; route = 1; }
                 else {
                     bool done = false;
                     int score = 2 * (int)lq;
-                    if (w == lq) {
+                    if (square) {
                         // square window: one full diagonal with m mismatches at p1 <= p2, score 2*Lq - 3m.  Every other path
                         // into a diagonal cell or into the last row holds u >= 1 insertions, and a run of g gap steps costs
                         // g + 1: u >= 2 loses >= 7, u = 1 loses >= 4.  m <= 1 (loss <= 3): the diagonal is the unique optimum.
@@ -1281,27 +1326,15 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
                         //       the highest mismatch on diagonal -1 sits at h <= p1.
                         // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
                         // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
-                        uint32_t mism = 0, p1 = 0, p2 = 0;
-                        for (uint32_t i = 0; i < lq && mism <= 2; i += 32) {
-                            uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
-                                         (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + i));
-                            if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
-                            if (e) {
-                                if (!mism) p1 = i + (uint32_t)__ffs((int)e) - 1u;
-                                p2 = i + 31u - (uint32_t)__clz((int)e);
-                                mism += __popc(e);
-                            }
-                        }
                         done = mism <= 1 && lq >= 8;
                         if (mism == 2 && lq >= 8) {
                             // diagonals +1 and -1 hold Lq-1 pairs each: bit i of e_up = (q[i] != r[i+1]), of e_dn = (q[i+1] != r[i])
                             uint32_t f1 = lq - 1, h = 0;
                             bool seen = false;
                             for (uint32_t i = 0; i + 1 < lq; i += 32) {
-                                uint32_t eu = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + 1 + i)) |
-                                              (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + 1 + i));
-                                uint32_t ed = (plane_bits(qlo, qo + 1 + i) ^ plane_bits(wlo, (uint64_t)wo + i)) |
-                                              (plane_bits(qhi, qo + 1 + i) ^ plane_bits(whi, (uint64_t)wo + i));
+                                const uint4 q0 = planes4(qp, qo + i), q1 = planes4(qp, qo + 1 + i);
+                                const uint4 w0 = planes4(wp, (uint64_t)wo + i), w1 = planes4(wp, (uint64_t)wo + 1 + i);
+                                uint32_t eu = (q0.x ^ w1.x) | (q0.y ^ w1.y), ed = (q1.x ^ w0.x) | (q1.y ^ w0.y);
                                 if (lq - 1 - i < 32) { const uint32_t mk = (1u << (lq - 1 - i)) - 1u; eu &= mk; ed &= mk; }
                                 if (eu && !seen) { f1 = i + (uint32_t)__ffs((int)eu) - 1u; seen = true; }
                                 if (ed) h = i + 32u - (uint32_t)__clz((int)ed);          // k = bit + 1
@@ -1313,8 +1346,8 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
                         for (uint32_t d = 0; d + lq <= w && !done; d++) {
                             bool all = true;
                             for (uint32_t i = 0; i < lq && all; i += 32) {
-                                uint32_t e = (plane_bits(qlo, qo + i) ^ plane_bits(wlo, (uint64_t)wo + d + i)) |
-                                             (plane_bits(qhi, qo + i) ^ plane_bits(whi, (uint64_t)wo + d + i));
+                                const uint4 q4 = planes4(qp, qo + i), w4 = planes4(wp, (uint64_t)wo + d + i);
+                                uint32_t e = (q4.x ^ w4.x) | (q4.y ^ w4.y);
                                 if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
                                 all = e == 0;
                             }

@@ -40,8 +40,8 @@ struct DevIndex {
     const uint32_t *sa;    // SA[row] at sa[row-1]
     const uint8_t *ref1;   // 200 x 'N' ++ .ref ++ 200 x 'N'
     uint64_t ref1_len;
-    const uint32_t *rplanes;  // bit-planes over Ref1 (k_read_planes layout), rpw words per plane
-    uint64_t rpw;
+    const uint32_t *rplanes;  // bit-planes over Ref1 (k_read_planes layout)
+    uint64_t rpw;             // their size in words (all four planes)
     uint32_t Pc, Pg, Pt, Last, dollar, nblk;
     uint32_t c0[4];        // {1, Pc-1, Pg-1, Pt-1}: 0-based first row of each F block (src/bwt.erl:105-112)
     const uint64_t *ktab;  // suffix-interval table, levels 8..kt_k (kernels.hip.h: kt_build); null when kt_k == 0
@@ -54,48 +54,82 @@ __device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anyt
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_read_planes: the concatenated read bases as four bit-planes over the byte stream (bit i of a plane
-// = property of base i): low / high bit of the 2-bit code (A C G T = 0..3), is-N, is-other (neither
-// ACGT nor N).  One coalesced 64-byte read and four ballots per wave iteration; everything downstream
-// (sub-read enumeration, LF steps) works on 16..32-bit windows of these planes instead of bytes.
+// k_read_planes: a byte stream of bases (the concatenated reads, Ref1) as four bit-planes (bit i of a plane =
+// property of base i): low / high bit of the 2-bit code (A C G T = 0..3; anything else 0), is-N, is-other (neither
+// ACGT nor N).  The planes are interleaved word by word -- planes[4*w + p] holds bits 32w..32w+31 of plane p -- so the
+// four properties of a stretch of bases sit in the same 16 bytes.  Everything downstream (sub-read enumeration, seed
+// keys, the extend prefilter) works on 16..32-bit windows of these planes instead of bytes.
+// Lane = 16 bases (one 16-byte load); the plane bits come out of each 4-byte word by SWAR arithmetic:
+//   code bits: hi = bit 2, lo = bit 1 ^ bit 2 of the ASCII code (A 41, C 43, G 47, T 54);
+//   is-ACGT: the byte equals 40 | (bits 1,2) | T << 4 | !T  (T = bit 2 & ~bit 1), by an exact zero-byte test;
+//   one multiply by 0x01020408 gathers the flag bits of two words' eight bytes into a byte.
 #define RP_LO 0
 #define RP_HI 1
 #define RP_N 2
 #define RP_O 3
+__device__ __forceinline__ uint32_t rp_zero_bytes(uint32_t d) {            // 1 in bit 0 of every byte of d that is zero
+    return (~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
+}
+__device__ __forceinline__ void rp_word(uint32_t x, uint32_t &l, uint32_t &h, uint32_t &nb, uint32_t &ob) {
+    h = (x >> 2) & 0x01010101u;
+    l = ((x >> 1) ^ (x >> 2)) & 0x01010101u;
+    const uint32_t t = h & ~(x >> 1);
+    const uint32_t expect = 0x40404040u | (x & 0x06060606u) | (t << 4) | (t ^ 0x01010101u);
+    const uint32_t a = rp_zero_bytes(x ^ expect);
+    nb = rp_zero_bytes(x ^ 0x4E4E4E4Eu);
+    ob = (a | nb) ^ 0x01010101u;
+    l &= a; h &= a;
+}
 static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
-                                                      uint32_t *__restrict__ planes, uint64_t pw) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t nchunks = (total + 63) >> 6;
-    // RP_U independent 64-byte loads in flight per wave before any of them is consumed: the kernel is a pure stream and
-    // bytes in flight per wave set its rate (4 loads: 1.0 TB/s)
-    constexpr int RP_U = 16;
-    for (uint64_t c0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c0 < nchunks; c0 += RP_U * nwaves) {
-        uint32_t ch[RP_U];
-#pragma unroll
-        for (int u = 0; u < RP_U; u++) {
-            const uint64_t pos = (c0 + (uint64_t)u * nwaves) * 64 + lane;
-            ch[u] = pos < total ? bases[pos] : 'A';
+                                                      uint32_t *__restrict__ planes) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nseg = (((total + 15) >> 4) + 1) & ~1ull;      // 16-base segments, lane pairs finish whole words
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += nthreads) {
+        const uint64_t p0 = s * 16;
+        uint32_t x[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};       // past the end: 'A' = all planes 0
+        if (p0 + 16 <= total) {
+            const uint4 v = *(const uint4 *)(bases + p0);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else if (p0 < total) {
+            for (uint32_t i = 0; p0 + i < total; i++)
+                x[i >> 2] = (x[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)bases[p0 + i] << (8 * (i & 3)));
         }
+        uint32_t out[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < RP_U; u++) {
-            const uint64_t ci = c0 + (uint64_t)u * nwaves;
-            if (ci >= nchunks) break;
-            const uint32_t c = ch[u];
-            const int code = base_code(c);
-            const unsigned long long lo = __ballot(code == 1 || code == 3), hi = __ballot(code >= 2),
-                                     nn = __ballot(c == 'N'), oo = __ballot(code < 0 && c != 'N');
-            if (lane < 8) {
-                const unsigned long long m = (lane >> 1) == 0 ? lo : (lane >> 1) == 1 ? hi : (lane >> 1) == 2 ? nn : oo;
-                planes[(uint64_t)(lane >> 1) * pw + 2 * ci + (lane & 1)] = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
-            }
+        for (int k = 0; k < 4; k += 2) {
+            uint32_t l0, h0, n0, o0, l1, h1, n1, o1;
+            rp_word(x[k], l0, h0, n0, o0);
+            rp_word(x[k + 1], l1, h1, n1, o1);
+            out[RP_LO] |= (((l0 | (l1 << 4)) * 0x01020408u) >> 24) << (4 * k);
+            out[RP_HI] |= (((h0 | (h1 << 4)) * 0x01020408u) >> 24) << (4 * k);
+            out[RP_N] |= (((n0 | (n1 << 4)) * 0x01020408u) >> 24) << (4 * k);
+            out[RP_O] |= (((o0 | (o1 << 4)) * 0x01020408u) >> 24) << (4 * k);
         }
+        // the odd lane's 16 bits complete the even lane's word
+        uint4 w;
+        w.x = out[0] | ((uint32_t)__shfl_xor((int)out[0], 1, 64) << 16);
+        w.y = out[1] | ((uint32_t)__shfl_xor((int)out[1], 1, 64) << 16);
+        w.z = out[2] | ((uint32_t)__shfl_xor((int)out[2], 1, 64) << 16);
+        w.w = out[3] | ((uint32_t)__shfl_xor((int)out[3], 1, 64) << 16);
+        if (!(s & 1)) ((uint4 *)planes)[s >> 1] = w;
     }
 }
-// 32 bits of a plane starting at absolute bit position pos
-__device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ plane, uint64_t pos) {
+// words the plane buffer of a stream of `total` bases needs (u32; 16-byte groups, padded so that windows may run on)
+static inline uint64_t rp_words(uint64_t total) { return 4 * (((total + 63) / 64) * 2 + 8); }
+// 32 bits of plane p starting at absolute bit position pos
+__device__ __forceinline__ uint32_t plane_bits(const uint32_t *__restrict__ planes, int p, uint64_t pos) {
     const uint64_t w = pos >> 5;
-    return __builtin_amdgcn_alignbit(plane[w + 1], plane[w], (uint32_t)pos & 31u);
+    return __builtin_amdgcn_alignbit(planes[4 * (w + 1) + p], planes[4 * w + p], (uint32_t)pos & 31u);
+}
+// ... of all four planes (x lo, y hi, z is-N, w is-other): two 16-byte loads
+__device__ __forceinline__ uint4 planes4(const uint32_t *__restrict__ planes, uint64_t pos) {
+    const uint64_t w = pos >> 5;
+    const uint32_t sh = (uint32_t)pos & 31u;
+    const uint4 a = ((const uint4 *)planes)[w], b = ((const uint4 *)planes)[w + 1];
+    uint4 r;
+    r.x = __builtin_amdgcn_alignbit(b.x, a.x, sh); r.y = __builtin_amdgcn_alignbit(b.y, a.y, sh);
+    r.z = __builtin_amdgcn_alignbit(b.z, a.z, sh); r.w = __builtin_amdgcn_alignbit(b.w, a.w, sh);
+    return r;
 }
 
 
