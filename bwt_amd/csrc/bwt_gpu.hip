@@ -48,8 +48,11 @@ int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream) {
 
 // Suffix-interval table (kernels.hip.h: kt_build), levels 8..K.  K = 0 drops it; K < 0 picks the default: the
 // environment's BWT_KTAB if set, else the K in 8..15 with 4^K closest above the row count (4^K entries ~ rows:
-// deeper levels would mostly repeat "not found").  GRCh38: K = 15, 11.5 GB next to an 18 GB index.
-extern "C" int bwt_index_set_ktable(bwt_index *ix, int K) {
+// deeper levels would mostly repeat "not found").  GRCh38: K = 15.
+// wide: the top level as 64-byte entries that carry the first 14 SA values of the range (a task that ends there needs
+// no SA read, and the seed kernel clusters such reads itself); only useful at K = 15 = MAX_LEN, where every full-length
+// task ends.  < 0: env BWT_KTAB_WIDE if set, else on when K = 15 and the 64 * 4^15 = 68.7 GB leave >= 32 GB of HBM free.
+extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
     if (!ix) return fail(BWT_EINVAL, "bwt_index_set_ktable: null index");
     if (K < 0) {
         const char *env = getenv("BWT_KTAB");
@@ -62,23 +65,37 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K) {
     if (K != 0 && (K < KT_MIN || K > BWT_MAX_LEN)) return fail(BWT_EINVAL, "bwt_index_set_ktable: K must be 0 or 8..15");
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->d.ktab = nullptr; ix->d.kt_k = 0;
-    if (K == 0) { ix->ktab.release(); return 0; }
-    int rc = ix->ktab.exact(kt_entries(K) * 8);
+    ix->d.ktab = nullptr; ix->d.ktw = nullptr; ix->d.kt_k = 0;
+    ix->ktab.release(); ix->ktw.release();
+    if (K == 0) return 0;
+    const uint64_t wide_bytes = 64ull << (2 * K);
+    if (wide < 0) {
+        const char *env = getenv("BWT_KTAB_WIDE");
+        if (env && *env) wide = atoi(env) != 0;
+        else {
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            wide = K == BWT_MAX_LEN && free_b >= wide_bytes + (32ull << 30);
+        }
+    }
+    int rc = ix->ktab.exact((wide ? kt_level_off(K) : kt_entries(K)) * 8);
     if (rc) return rc;
+    if (wide && (rc = ix->ktw.exact(wide_bytes))) { ix->ktab.release(); return rc; }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
     for (int m = KT_MIN; m <= K; m++) {
         const uint64_t quads = 1ull << (2 * m);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((quads * 4 + 255) / 256, (uint64_t)cus * 8);
-        hipLaunchKernelGGL(kt_build, dim3(grid), dim3(256), 0, ix->stream, ix->d, ix->ktab.as<uint64_t>(), m);
+        hipLaunchKernelGGL(kt_build, dim3(grid), dim3(256), 0, ix->stream, ix->d, ix->ktab.as<uint64_t>(), m,
+                           (wide && m == K) ? ix->ktw.as<uint4>() : (uint4 *)nullptr);
     }
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipGetLastError());
     ix->d.ktab = ix->ktab.as<uint64_t>(); ix->d.kt_k = K;
+    ix->d.ktw = wide ? ix->ktw.as<uint4>() : nullptr;
     return 0;
 }
-extern "C" int bwt_index_ktable(const bwt_index *ix) { return ix ? ix->d.kt_k : 0; }
+extern "C" int bwt_index_ktable(const bwt_index *ix) { return ix ? (ix->d.kt_k | (ix->d.ktw ? 16 : 0)) : 0; }
 
 static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
     const uint32_t n = (uint32_t)fm.L.size();
@@ -143,7 +160,7 @@ static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, i
     ix->d.ref1_len = ix->ref1_len;
     ix->d.Pc = fm.Pc; ix->d.Pg = fm.Pg; ix->d.Pt = fm.Pt; ix->d.Last = fm.Last; ix->d.dollar = dollar; ix->d.nblk = nblk;
     ix->d.c0[0] = 1; ix->d.c0[1] = fm.Pc - 1; ix->d.c0[2] = fm.Pg - 1; ix->d.c0[3] = fm.Pt - 1;
-    if ((rc = bwt_index_make_refplanes(ix, ix->stream)) || (rc = bwt_index_set_ktable(ix, -1))) { bwt_index_close(ix); return rc; }
+    if ((rc = bwt_index_make_refplanes(ix, ix->stream)) || (rc = bwt_index_set_ktable(ix, -1, -1))) { bwt_index_close(ix); return rc; }
     *out = ix;
     return 0;
 }
@@ -199,7 +216,7 @@ extern "C" void bwt_index_close(bwt_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    ix->blocks.release(); ix->sa.release(); ix->ref1.release(); ix->refplanes.release(); ix->ktab.release();
+    ix->blocks.release(); ix->sa.release(); ix->ref1.release(); ix->refplanes.release(); ix->ktab.release(); ix->ktw.release();
     delete ix;
 }
 
@@ -212,7 +229,7 @@ extern "C" int bwt_index_meta(const bwt_index *ix, uint32_t out[5]) {
 extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[4]) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_device_bytes: null argument");
     out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len + ix->d.rpw * 4;
-    out[3] = ix->d.kt_k ? kt_entries(ix->d.kt_k) * 8 : 0;
+    out[3] = ix->d.kt_k ? (ix->d.ktw ? kt_level_off(ix->d.kt_k) * 8 + (64ull << (2 * ix->d.kt_k)) : kt_entries(ix->d.kt_k) * 8) : 0;
     return 0;
 }
 
@@ -276,8 +293,11 @@ struct bwt_batch {
     uint64_t total_bases = 0;
     DevBuf bases, off, rplanes;
     // tasks
-    DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend;
+    DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend, r_cl, smallq;
     bool counts_done = false;          // the search stage already totalled the reads (k_seed_tasks)
+    uint32_t n_small = 0;
+    bool rows_kept = true;             // every read's task-table rows were written (not so after a lean fused run)
+    bool fused = false;                // ... and clustered what it could (r_K zeroed, RQ_DONE reads staged in r_cl)
     // reads
     DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
@@ -391,7 +411,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
-                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend};
+                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -477,10 +497,10 @@ static int fetch_counters(bwt_batch *b) {
 // lookups, per-read totals) + k_search_pending (the LF steps the table left over) -- the per-read totals of the cluster
 // stage are then already in place (b->counts_done).  Else: k_subreads + k_search over every task, from n = 1.
 // raw: one task per "read", t_def already filled (bwt_find_seeds_batch).
-static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw) {
+static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool lean = false) {
     int rc;
     const uint64_t T = (uint64_t)n * maxT;
-    b->counts_done = false;
+    b->counts_done = false; b->fused = false; b->rows_kept = true;
     if (b->ix->d.kt_k > 0 && maxT >= 1 && maxT <= 64) {
         if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
             (rc = b->r_pend.ensure((size_t)n * 8 + 8)) || (rc = b->bigq.ensure((size_t)n * 4 + 4)) ||
@@ -489,13 +509,23 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
         const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(cdiv(n, 64 / maxT), 4), (uint64_t)cus * 8);   // wave per 64/maxT reads
-#define SEED_ARGS b->ix->d, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT, b->t_def.as<uint32_t>(),          \
+#define SEED_ARGS b->ix->d, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT, b->t_def.as<uint32_t>(),                  \
                   b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),               \
                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),       \
-                  b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>()
-        if (raw) KLAUNCH(b, "fm_lookup", k_seed_tasks<true>, grid, 256, SEED_ARGS);
-        else KLAUNCH(b, "fm_lookup", k_seed_tasks<false>, grid, 256, SEED_ARGS);
-        KLAUNCH(b, "fm_search", k_search_pending, search_grid(b, T, false), 256, SEED_ARGS);
+                  b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>()
+        // with SA values in the table's top level (and 8..64 sub-reads per read) the seed kernel clusters what it can itself
+        static const char *env_f = getenv("BWT_SEED_FUSE");
+        const bool fuse = !raw && b->ix->d.ktw && maxT >= 8 && !(env_f && env_f[0] == '0');
+        if (fuse) {
+            if ((rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->r_cl.ensure((size_t)n * 8 * CL_STAGE + 16))) return rc;
+            HIPCHK(hipMemsetAsync(b->r_K.p, 0, (size_t)n * 4, b->stream));      // k_cluster_small only runs if reads are left for it
+        }
+        b->fused = fuse;
+        b->rows_kept = !(fuse && lean);
+        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), grid, 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
+        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), grid, 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0);
+        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), grid, 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
+        KLAUNCH(b, "fm_search", k_search_pending, search_grid(b, T, false), 256, SEED_ARGS, b->ctr.as<Counters>());
 #undef SEED_ARGS
         b->counts_done = true;
     } else {
@@ -511,7 +541,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw) {
     return 0;
 }
 
-static int stage_search(bwt_batch *b) {
+static int stage_search(bwt_batch *b, bool lean) {
     const uint32_t n = b->n, maxT = b->maxT;
     const uint64_t T = (uint64_t)n * maxT;
     int rc;
@@ -521,7 +551,7 @@ static int stage_search(bwt_batch *b) {
     HIPCHK(hipMemsetAsync(b->ctr.p, 0, sizeof(Counters), b->stream));
     if (n == 0) return 0;
     if ((rc = read_planes(b))) return rc;
-    if ((rc = launch_search(b, n, maxT, false))) return rc;
+    if ((rc = launch_search(b, n, maxT, false, lean))) return rc;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -550,12 +580,25 @@ static int stage_cluster(bwt_batch *b) {
     if (b->hctr.err_flags & 1) return fail(BWT_EOVERFLOW, "a read produced more than 2^31 seeds");
     if (total_seeds > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 seeds: split it");
     if ((rc = b->pos.ensure(total_seeds * 4 + 16))) return rc;
-    int cl_cus = 256;
-    (void)hipDeviceGetAttribute(&cl_cus, hipDeviceAttributeMultiprocessorCount, b->device);
-    KLAUNCH(b, "cluster_small", k_cluster_small, (uint32_t)std::min<uint64_t>(cdiv((uint64_t)n * 64, 256), (uint64_t)cl_cus * 8), 256, b->ix->d, n, maxT,
-            b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
-            b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
-            b->r_K.as<uint32_t>());
+    b->n_small = b->hctr.n_small;
+    if (b->fused && b->hctr.n_small < n / 8) {
+        // few reads left for the wave-per-read kernel: list them first (a wave per read of the batch costs ~1 ms in launches alone)
+        if (b->hctr.n_small) {
+            if ((rc = b->smallq.ensure((size_t)b->hctr.n_small * 4 + 64))) return rc;
+            unsigned int *cnt = &b->ctr.as<Counters>()->n_small;           // recounted by the listing kernel
+            HIPCHK(hipMemsetAsync(cnt, 0, 4, b->stream));
+            KLAUNCH(b, "cluster_small", k_collect_small, std::min<uint32_t>(cdiv(n, 256), 256), 256, n, b->r_P.as<uint32_t>(),
+                    b->r_qty.as<uint32_t>(), b->smallq.as<uint32_t>(), cnt);
+            KLAUNCH(b, "cluster_small", k_cluster_small, cdiv((uint64_t)b->hctr.n_small * 64, 256), 256, b->ix->d, b->hctr.n_small, maxT,
+                    b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
+                    b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
+                    b->r_K.as<uint32_t>(), b->smallq.as<uint32_t>(), cnt);
+        }
+    } else
+        KLAUNCH(b, "cluster_small", k_cluster_small, cdiv((uint64_t)n * 64, 256), 256, b->ix->d, n, maxT,
+                b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
+                b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
+                b->r_K.as<uint32_t>(), (const uint32_t *)nullptr, (const unsigned int *)nullptr);
     if (b->hctr.n_mid2)
         KLAUNCH(b, "cluster_wave2", k_cluster_wave<2>, cdiv((uint64_t)b->hctr.n_mid2 * 64, 256), 256, b->ix->d, b->hctr.n_mid2,
                 b->mid2q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
@@ -583,7 +626,8 @@ static int stage_cluster(bwt_batch *b) {
         (rc = b->c_wlen.ensure(nc * 4)))
         return rc;
     KLAUNCH(b, "candidates", k_candidates, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
-            b->seed_off.as<uint64_t>(), b->clus_off.as<uint64_t>(), b->pos.as<uint32_t>(), b->c_read.as<uint32_t>(),
+            b->seed_off.as<uint64_t>(), b->clus_off.as<uint64_t>(), b->pos.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_cl.as<uint32_t>(),
+            b->c_read.as<uint32_t>(),
             b->c_S.as<uint32_t>(), b->c_D.as<uint32_t>(), b->c_qoff.as<uint64_t>(), b->c_qlen.as<uint32_t>(),
             b->c_woff.as<int64_t>(), b->c_wlen.as<uint32_t>(), b->ctr.as<Counters>());
     HIPCHK(hipGetLastError());
@@ -762,7 +806,8 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     HIPCHK(hipSetDevice(b->device));
     int rc;
     if (stages & (BWT_STAGE_SEARCH | BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
-        if ((rc = stage_search(b))) return rc;
+        // a run that goes straight through to the extend stage does not keep the task rows of reads the seed kernel clusters itself
+        if ((rc = stage_search(b, (stages & BWT_STAGE_EXTEND) != 0))) return rc;
         b->done = BWT_STAGE_SEARCH;
     }
     if (stages & (BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
@@ -781,7 +826,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
         counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
         counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
-        counts->n_dp = b->hctr.dq_count; counts->n_lookups = b->hctr.kt_lookups;
+        counts->n_dp = b->hctr.dq_count; counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
     }
     return 0;
 }
@@ -795,6 +840,7 @@ template <typename T> static int d2h(bwt_batch *b, T *dst, const DevBuf &src, si
 extern "C" int bwt_batch_fetch_tasks(bwt_batch *b, int32_t *status, uint32_t *sp, uint32_t *ep, uint32_t *nmatch,
                                      uint32_t *task_read, uint32_t *task_end, uint64_t cap, uint64_t *needed) {
     if (!b || !(b->done & BWT_STAGE_SEARCH)) return fail(BWT_EINVAL, "bwt_batch_fetch_tasks: search stage not run");
+    if (!b->rows_kept) return fail(BWT_EINVAL, "bwt_batch_fetch_tasks: the task table was not kept (the run included the extend stage); run BWT_STAGE_SEARCH alone first");
     HIPCHK(hipSetDevice(b->device));
     const uint64_t T = (uint64_t)b->n * b->maxT;
     std::vector<uint32_t> def(T), info(T), vsp(T), vep(T);

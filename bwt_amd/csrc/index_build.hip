@@ -237,12 +237,14 @@ extern "C" int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, ui
         ix->d.ref1_len = ix->ref1_len;
         ix->d.Pc = ix->Pc; ix->d.Pg = ix->Pg; ix->d.Pt = ix->Pt; ix->d.Last = ix->Last; ix->d.dollar = dollar; ix->d.nblk = nblk;
         ix->d.c0[0] = 1; ix->d.c0[1] = ix->Pc - 1; ix->d.c0[2] = ix->Pg - 1; ix->d.c0[3] = ix->Pt - 1;
-        if ((rc = bwt_index_make_refplanes(ix, s)) || (rc = bwt_index_set_ktable(ix, -1))) goto done;
+        if ((rc = bwt_index_make_refplanes(ix, s))) goto done;
     }
 done:
     d_sym.release(); d_key0.release(); d_key1.release(); d_val0.release(); d_val1.release(); d_rank.release();
     d_head.release(); d_tmp.release(); d_cnt.release(); d_scan.release(); d_small.release(); d_hist.release();
     if (s) (void)hipStreamDestroy(s);
+    // the suffix-interval table last: the builder's buffers are gone, so its size is weighed against what is really free
+    if (!rc) rc = bwt_index_set_ktable(ix, -1, -1);
     if (rc) { bwt_index_close(ix); return rc; }
     *out = ix;
     return 0;

@@ -45,6 +45,43 @@ __device__ __forceinline__ bool is_acgt(uint32_t c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bitonic sort of one u32 per lane across the wave, ascending.  Stage (K, J): lane l meets lane l ^ J and keeps the
+// smaller value iff ((l & J) == 0) == ((l & K) == 0) -- a compile-time lane mask, fed to v_cndmask as an SGPR pair.
+// The partner comes by DPP quad_perm (J = 1, 2), ds_swizzle xor mode (J = 4, 8, 16) or ds_bpermute (J = 32).
+template <int K, int J>
+__device__ __forceinline__ constexpr unsigned long long bitonic_keep_min() {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; l++)
+        if (((l & J) == 0) == ((l & K) == 0)) m |= 1ull << l;
+    return m;
+}
+template <int K, int J>
+__device__ __forceinline__ uint32_t bitonic_stage(uint32_t p) {
+    uint32_t o;
+    if constexpr (J == 1) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J <= 16) o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)p, (J << 10) | 0x1f);         // lane ^ J inside 32
+    else o = (uint32_t)__shfl_xor((int)p, J, 64);
+    const uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
+    constexpr unsigned long long M = bitonic_keep_min<K, J>();
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(mx), "v"(mn), "s"(M));
+    return r;
+}
+template <int K, int J>
+__device__ __forceinline__ uint32_t bitonic_merge(uint32_t p) {
+    p = bitonic_stage<K, J>(p);
+    if constexpr (J > 1) p = bitonic_merge<K, J / 2>(p);
+    return p;
+}
+template <int K>
+__device__ __forceinline__ uint32_t bitonic_sort_upto(uint32_t p) {
+    if constexpr (K > 2) p = bitonic_sort_upto<K / 2>(p);
+    return bitonic_merge<K, K / 2>(p);
+}
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) { return bitonic_sort_upto<64>(p); }
+
+// ------------------------------------------------------------------------------------------------
 // exclusive scan  u32 -> u64   (3 kernels: per-block, block sums, add back)
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK 256
@@ -148,6 +185,11 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
     return v;
+}
+// lane T of the quad's value in all four lanes (DPP quad_perm [T,T,T,T])
+template <int T>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, T * 0x55, 0xF, 0xF, true);
 }
 // match bits of this quarter's 48 rows against a code given as plane masks (nl = ~(-(c&1)), nh = ~(-(c>>1)))
 __device__ __forceinline__ void quarter_match(uint4 v, uint32_t nl, uint32_t nh, uint32_t n16, uint32_t &y0, uint32_t &y1) {
@@ -353,7 +395,10 @@ __device__ __forceinline__ uint64_t kt_pack(uint32_t sp, uint32_t ep, int n) {
 }
 
 // quad per key of level m.  m == KT_MIN (or a parent that did not fit): all m-1 steps; else one step from the parent.
-__global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restrict__ tab, int m) {
+// wide != null: the level is written as 64-byte entries {Sp, width | n << 28, SA[Sp], SA[Sp+1], ... 14 values} instead
+// (lane q of the quad writes 16-byte quarter q): a task that ends at this level gets its seeds with the same line.
+#define KT_INLINE 14
+__global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restrict__ tab, int m, uint4 *__restrict__ wide) {
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;
     const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
@@ -386,7 +431,23 @@ __global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restric
             if (lf_step(ix, ql, dblk, v1, v2, b1, b2, (lo >> bi) & 1u, (hi >> bi) & 1u, sp, ep)) n++;
             else dead = true;
         }
-        if (ql == 0) tab[kt_level_off(m) + key] = kt_pack(sp, ep, n);
+        const uint64_t ent = kt_pack(sp, ep, n);
+        if (!wide) { if (ql == 0) tab[kt_level_off(m) + key] = ent; }
+        else {
+            const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF;
+            const uint32_t cnt = wd == KT_OVF ? 0u : wd + 1u;
+            uint32_t w[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int wi = 4 * ql + c;
+                uint32_t v = 0;
+                if (wi == 0) v = (uint32_t)ent;
+                else if (wi == 1) v = (uint32_t)(ent >> 32);
+                else if ((uint32_t)(wi - 2) < cnt) v = ix.sa[sp - 1 + (uint32_t)(wi - 2)];
+                w[c] = v;
+            }
+            wide[key * 4 + (uint64_t)ql] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
 }
 
@@ -398,7 +459,7 @@ __global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restric
 __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned long long P, uint32_t qty, uint32_t crash,
                                             uint32_t maxT, uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                             uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
-                                            uint32_t *__restrict__ mid4q, Counters *ctr, unsigned long long &Psum) {
+                                            uint32_t *__restrict__ mid4q, Counters *ctr, unsigned long long &Psum, uint32_t &nsmall) {
     if (qty < 2 || crash) P = 0;
     if (active && P > 0x7fffffffull) { atomicOr(&ctr->err_flags, 1ull); P = 0; }
     if (active) { r_P[r] = (uint32_t)P; r_qty[r] = qty | (crash ? RQ_CRASH : 0u); }
@@ -407,7 +468,7 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
     if (big) bigq[ib] = r;
     if (m4) mid4q[i4] = r;
     if (m2) mid2q[i2] = r;
-    if (active) Psum += P;
+    if (active) { Psum += P; nsmall += (P > 0 && P <= 64 && maxT <= 64) ? 1u : 0u; }   // nsmall: reads k_cluster_small has to take
 }
 
 // k_seed_tasks: the seed stage with the suffix-interval table.  A wave takes 64 / maxT reads at a time, lane = one
@@ -417,9 +478,16 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 //   * one table read answers the task; what the table cannot finish -- sub-reads longer than K (they resume at n = K),
 //     searches that stop before 8 bases in front of a base outside ACGTN, entries whose range did not fit -- becomes a
 //     bit of r_pend[r] for k_search_pending;
-//   * ballots and one wave prefix sum total each read for the cluster stage (as k_read_counts) when nothing is pending.
+//   * ballots and one wave prefix sum total each read for the cluster stage (as k_read_counts) when nothing is pending;
+//   * FUSE (the table's top level carries SA values, 8 <= maxT): reads whose every seed came with its table entry and
+//     that hold at most 64 seeds are clustered on the spot -- positions through a wave-private LDS row per read, then
+//     sort and get_similar exactly as k_cluster_small -- into r_cl[r] (up to CL_STAGE {S, D} pairs) and marked
+//     RQ_DONE: no SA gather, no second pass over the task table.  Everything else takes the cluster kernels.
+//     lean: the task-table rows of such reads are not written at all (nothing reads them; bwt_batch_fetch_tasks refuses).
 // RAW: one task per "read", already in t_def (bwt_find_seeds_batch).  1 <= maxT <= 64.
-template <bool RAW>
+#define RQ_DONE 0x20000000u
+#define CL_STAGE 4
+template <bool RAW, bool FUSE>
 __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t *__restrict__ planes,
                                                      const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
                                                      uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
@@ -427,17 +495,20 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                                      uint32_t *__restrict__ t_cnt, unsigned long long *__restrict__ r_pend,
                                                      uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                      uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
-                                                     uint32_t *__restrict__ mid4q, Counters *ctr) {
+                                                     uint32_t *__restrict__ mid4q, uint32_t *__restrict__ r_K,
+                                                     uint32_t *__restrict__ r_cl, Counters *ctr, int lean) {
+    __shared__ uint32_t lds_[FUSE ? 4 * 8 * 64 : 1];
     const int K = ix.kt_k;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t rw = 64u / maxT;                               // reads per wave pass
+    uint32_t *lp = lds_ + (FUSE ? (threadIdx.x >> 6) * 8 * 64 : 0);      // [read of the pass][seed]
+    const uint32_t rw = 64u / maxT;                               // reads per wave pass (FUSE: <= 8)
     const uint32_t lread = lane / maxT, slot = lane - lread * maxT;
     const uint32_t seg0 = lread * maxT;                           // first lane of my read
     const unsigned long long segmask = maxT == 64 ? ~0ull : ((1ull << maxT) - 1ull);
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t groups = (n + rw - 1) / rw;
-    uint32_t live = 0, looked = 0;
+    uint32_t live = 0, looked = 0, nsmall = 0;
     unsigned long long Psum = 0;
     for (uint32_t g = wave; g < groups; g += nwaves) {
         const uint32_t r = g * rw + lread;
@@ -446,21 +517,31 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         tk.task = (uint64_t)r * maxT + slot;
         tk.sp = 0; tk.ep = 0; tk.lo16 = 0; tk.hi16 = 0; tk.status = TS_NONE; tk.n = 0; tk.nlim = 0;
         tk.check_at_limit = true; tk.check = true; tk.active = false;
-        bool pending = false;
-        uint32_t status = TS_NONE, c = 0;
+        bool pending = false, inl = false;                        // inl: my seeds came with the table entry
+        uint32_t status = TS_NONE, c = 0, nadd = 0, shsk = 0;
+        int m = 0;                                                // table level asked (0: none)
+        uint64_t key = 0;
+        // does the read hold an N at all?  lane k of the read looks at word k of its is-N plane (len / 32 < maxT words)
+        uint64_t P0 = 0;
+        int len = 0;
+        bool nword = false;
         if (valid) {
-            const uint64_t P0 = off[r];
+            P0 = off[r];
+            if (!RAW) {
+                len = (int)(off[r + 1] - P0);
+                const int i = 32 * (int)slot;
+                if (i < len) {
+                    uint32_t w = plane_bits(planes, RP_N, P0 + (uint64_t)i);
+                    if (len - i < 32) w &= (1u << (len - i)) - 1u;
+                    nword = w != 0;
+                }
+            }
+        }
+        const bool anyN = ((__ballot(nword) >> seg0) & segmask) != 0;
+        if (valid) {
             int e = 0;
             if (RAW) e = (int)(t_def[tk.task] & 0xffffu);
             else {
-                const int len = (int)(off[r + 1] - P0);
-                uint32_t anyN = 0;
-                for (int i = 0; i < len; i += 32) {
-                    uint32_t w = plane_bits(planes, RP_N, P0 + (uint64_t)i);
-                    if (len - i < 32) w &= (1u << (len - i)) - 1u;
-                    anyN |= w;
-                }
-                uint32_t shsk = 0;
                 if (!anyN) {                                      // sub-read k ends at len - 8k, nothing skipped
                     e = len - (int)(BWT_MIN_LEN * slot);
                     shsk = BWT_MIN_LEN * slot;
@@ -493,17 +574,46 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                 task_init(tk, ix, planes, P0 + (uint64_t)e, e);
                 pending = tk.active;
                 if (tk.active && tk.nlim >= KT_MIN) {
-                    const int m = tk.nlim < K ? tk.nlim : K;
+                    m = tk.nlim < K ? tk.nlim : K;
                     const uint32_t mask = (1u << m) - 1u;
-                    const uint64_t key = (uint64_t)((tk.lo16 >> (16 - m)) & mask) | ((uint64_t)((tk.hi16 >> (16 - m)) & mask) << m);
-                    const uint64_t ent = ix.ktab[kt_level_off(m) + key];
+                    key = (uint64_t)((tk.lo16 >> (16 - m)) & mask) | ((uint64_t)((tk.hi16 >> (16 - m)) & mask) << m);
                     looked++;
-                    const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF;
-                    if (wd != KT_OVF) {
-                        tk.sp = (uint32_t)ent; tk.ep = tk.sp + wd; tk.n = (int)(ent >> 60);
-                        if (tk.n < m) { tk.check = false; pending = false; }                          // not_found inside the table
-                        else if (m == tk.nlim) { tk.check = tk.check_at_limit; pending = false; }
-                    }
+                }
+            }
+        }
+        // the table read.  Wide top level under FUSE: the four lanes of a quad fetch the quad's four 64-byte entries one
+        // after the other, lane q taking quarter q -- one L2 request per entry instead of four (the L2 request rate, not
+        // HBM, is what a lane-per-entry fetch of all four quarters runs into); Q[t] = my quarter of the entry of lane t.
+        const bool askw = m == K && m > 0 && ix.ktw != nullptr;
+        uint64_t ent = 0;
+        uint4 Q[4];
+        if (FUSE) {
+            const int ql = (int)(lane & 3);
+            const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32), aw = askw ? 1u : 0u;
+#define KT_QLOAD(T)                                                                                                    \
+            {                                                                                                          \
+                const uint64_t kt = (uint64_t)quad_bcast<T>(klo) | ((uint64_t)quad_bcast<T>(khi) << 32);                \
+                Q[T] = quad_bcast<T>(aw) ? ix.ktw[kt * 4 + (uint64_t)ql] : make_uint4(0, 0, 0, 0);                      \
+            }
+            KT_QLOAD(0) KT_QLOAD(1) KT_QLOAD(2) KT_QLOAD(3)
+#undef KT_QLOAD
+            // {Sp, width | n} of my own entry: quarter 0 lives in lane 0 of the quad, register [my lane]
+            const uint32_t x0 = quad_bcast<0>(Q[0].x), x1 = quad_bcast<0>(Q[1].x), x2 = quad_bcast<0>(Q[2].x), x3 = quad_bcast<0>(Q[3].x);
+            const uint32_t y0 = quad_bcast<0>(Q[0].y), y1 = quad_bcast<0>(Q[1].y), y2 = quad_bcast<0>(Q[2].y), y3 = quad_bcast<0>(Q[3].y);
+            const uint32_t ex = ql == 0 ? x0 : ql == 1 ? x1 : ql == 2 ? x2 : x3, ey = ql == 0 ? y0 : ql == 1 ? y1 : ql == 2 ? y2 : y3;
+            if (askw) { ent = (uint64_t)ex | ((uint64_t)ey << 32); inl = true; }
+        } else if (askw) {
+            const uint4 q0 = ix.ktw[key * 4];
+            ent = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
+        }
+        if (m > 0 && !askw) ent = ix.ktab[kt_level_off(m) + key];
+        if (valid) {
+            if (m > 0) {
+                const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF;
+                if (wd != KT_OVF) {
+                    tk.sp = (uint32_t)ent; tk.ep = tk.sp + wd; tk.n = (int)(ent >> 60);
+                    if (tk.n < m) { tk.check = false; pending = false; }                          // not_found inside the table
+                    else if (m == tk.nlim) { tk.check = tk.check_at_limit; pending = false; }
                 }
             }
             status = tk.status;
@@ -514,7 +624,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                 else if (tk.n < BWT_MIN_LEN) status = TS_NO_SEEDS;                      // fmi.erl:89
             }
             c = (!pending && status == TS_SEEDS) ? tk.ep - tk.sp + 1 : 0;
-            t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
+            nadd = (uint32_t)tk.n + shsk;                                               // N + Shift + Skip (sga.erl:32,37-39)
         }
         // per-read totals: the read's lanes are [seg0, seg0 + maxT)
         const unsigned long long bp = __ballot(pending), bs = __ballot(valid && !pending && status == TS_SEEDS),
@@ -523,7 +633,8 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned long long up = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += up; }
         const unsigned long long hi = __shfl(incl, (int)((seg0 + maxT - 1) & 63u), 64), lo = __shfl(incl, (int)((seg0 - 1) & 63u), 64);
-        const unsigned long long P = hi - (seg0 ? lo : 0ull);
+        const unsigned long long before = seg0 ? lo : 0ull;
+        unsigned long long P = hi - before;
         const unsigned long long pend = (bp >> seg0) & segmask;
         const uint32_t qty = (uint32_t)__popcll((bs >> seg0) & segmask), crash = ((bc >> seg0) & segmask) ? 1u : 0u;
         const bool leader = valid && slot == 0;
@@ -534,13 +645,79 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                 r_qty[r] = qty | (crash ? RQ_CRASH : 0u) | RQ_PENDING;
             }
         }
-        read_finish(leader && !pend, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum);
+        bool fuse_read = false;
+        if (FUSE) {
+            // a read is clustered here when it is complete, clusters at all (Qty >= 2, no crash), holds <= 64 seeds, and
+            // every task with seeds has all of them inline (<= KT_INLINE, top level of the table)
+            const unsigned long long bx = __ballot(c > 0 && (!inl || c > KT_INLINE));
+            fuse_read = valid && !pend && qty >= 2 && !crash && P > 0 && P <= 64 && !((bx >> seg0) & segmask);
+            // positions into the read's LDS row: lane q of the quad holds quarter q of the quad's four entries, i.e. SA values
+            // [4q-2, 4q+2) of each (quarter 0: values 0, 1 in its .z, .w)
+            {
+                const int ql = (int)(lane & 3);
+                const uint32_t dsto = fuse_read && c ? lread * 64 + (uint32_t)(incl - c - before) : 0u;
+                const uint32_t cw = fuse_read ? c : 0u;                       // seeds of mine to write
+#define KT_QWRITE(T)                                                                                                   \
+                {                                                                                                      \
+                    const uint32_t ct = quad_bcast<T>(cw), dt = quad_bcast<T>(dsto), at = quad_bcast<T>(nadd);         \
+                    const uint32_t i0 = ql ? 4u * (uint32_t)ql - 2u : 0u;                                              \
+                    const uint32_t v0 = ql ? Q[T].x : Q[T].z, v1 = ql ? Q[T].y : Q[T].w;                               \
+                    if (i0 < ct) lp[dt + i0] = v0 + at;                                                                \
+                    if (i0 + 1 < ct) lp[dt + i0 + 1] = v1 + at;                                                        \
+                    if (ql && i0 + 2 < ct) lp[dt + i0 + 2] = Q[T].z + at;                                              \
+                    if (ql && i0 + 3 < ct) lp[dt + i0 + 3] = Q[T].w + at;                                              \
+                }
+                KT_QWRITE(0) KT_QWRITE(1) KT_QWRITE(2) KT_QWRITE(3)
+#undef KT_QWRITE
+            }
+        }
+        // the task-table row (lean: only where a later kernel reads it -- the reads not clustered here)
+        if (valid && !(lean && fuse_read)) {
+            t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
+        }
+        read_finish(leader && !pend && !fuse_read, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall);
+        if (FUSE) {
+            if (leader && fuse_read) { r_P[r] = 0; r_qty[r] = qty | RQ_DONE; Psum += P; }   // r_P: seeds still to be clustered
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long bf = __ballot(leader && fuse_read);                   // bit seg0 of every read to cluster
+            for (uint32_t j = 0; j < rw; j++) {
+                if (!((bf >> (j * maxT)) & 1ull)) continue;                                  // wave-uniform
+                const uint32_t rj = g * rw + j;
+                const uint32_t Pj = (uint32_t)__shfl((int)(uint32_t)P, (int)(j * maxT), 64), qj = (uint32_t)__shfl((int)qty, (int)(j * maxT), 64);
+                uint32_t p = lane < Pj ? lp[j * 64 + lane] : 0xffffffffu;
+                p = wave_sort_u32(p);
+                const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
+                const bool vl = lane < Pj;
+                const bool start = vl && (lane == 0 || p - prev > BWT_TOLERANCE);
+                const bool end = vl && (lane == Pj - 1 || next - p > BWT_TOLERANCE);
+                const unsigned long long smask = __ballot(start);
+                const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
+                const uint32_t pfirst = __shfl(p, s_i, 64);
+                const uint32_t nthr = 2 + qj / 7;                     // sga.erl:46
+                const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
+                const unsigned long long emask = __ballot(emit);
+                const uint32_t Kc = (uint32_t)__popcll(emask);
+                if (Kc <= CL_STAGE) {
+                    if (emit) {
+                        const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
+                        r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = p;
+                        r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = p - pfirst;
+                    }
+                    if (lane == 0) r_K[rj] = Kc;
+                } else if (lane == 0) {                               // more clusters than the staging row holds: the cluster kernels redo it
+                    r_P[rj] = Pj; r_qty[rj] = qj; nsmall++;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum);
-    if (lane == 0 && (l | k | s)) {
+    unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
+    if (lane == 0 && (l | k | s | ns)) {
         atomicAdd(&ctr->n_tasks, l);
         atomicAdd(&ctr->kt_lookups, k);
         atomicAdd(&ctr->sa_reads, s);
+        if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns);
     }
 }
 
@@ -564,7 +741,7 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
     const uint32_t dblk = (ix.dollar - 1) / BWT_BLOCK_ROWS;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    uint32_t steps = 0;
+    uint32_t steps = 0, nsmall = 0;
     unsigned long long Psum = 0;
     for (uint32_t chunk = wave; (uint64_t)chunk * 64 < n; chunk += nwaves) {
         const uint32_t rl = chunk * 64 + lane;
@@ -627,14 +804,15 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                     else if (status == TS_CRASH) crash = 1;
                 }
             }
-            read_finish(have && ql == 0, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum);
+            read_finish(have && ql == 0, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall);
         }
         __builtin_amdgcn_wave_barrier();
     }
-    unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), ps = wave_sum_u64(Psum);
-    if (lane == 0 && (s | ps)) {
+    unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), ps = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
+    if (lane == 0 && (s | ps | ns)) {
         atomicAdd(&ctr->lf_steps, s);
         atomicAdd(&ctr->sa_reads, ps);
+        if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns);
     }
 }
 
@@ -663,6 +841,7 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
                                                       uint32_t *__restrict__ mid2q, uint32_t *__restrict__ mid4q, Counters *ctr) {
     // grid-stride (capped grid): one counter atomic per wave for the whole launch, not per 64 reads
     unsigned long long Psum = 0;
+    uint32_t nsmall = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (n + stride - 1) / stride;
     for (uint32_t it = 0; it < rounds; it++) {
@@ -675,10 +854,47 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
                 if (st == TS_SEEDS) { qty++; P += t_cnt[(uint64_t)r * maxT + k]; }
                 else if (st == TS_CRASH) crash = 1;
             }
-        read_finish(r < n, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum);
+        read_finish(r < n, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall);
     }
-    unsigned long long s = wave_sum_u64(Psum);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&ctr->sa_reads, s);
+    unsigned long long s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
+    if ((threadIdx.x & 63) == 0 && (s | ns)) { atomicAdd(&ctr->sa_reads, s); if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns); }
+}
+
+// k_collect_small: after a fused seed stage only a few reads are left for k_cluster_small (more clusters than the
+// staging row, tasks whose seeds were not inline, reads finished by k_search_pending): list them instead of launching
+// a wave per read of the batch.  Lane per read; a wave gathers its finds in LDS and takes queue space 64 at a time
+// (same-address atomics run at ~88 per us: one per wave-iteration would cost more than the clustering).
+__global__ __launch_bounds__(256) void k_collect_small(uint32_t n, const uint32_t *__restrict__ r_P,
+                                                        const uint32_t *__restrict__ r_qty, uint32_t *__restrict__ queue,
+                                                        unsigned int *count) {
+    __shared__ uint32_t buf_[4][128];
+    uint32_t *buf = buf_[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    uint32_t have = 0;                                            // wave-uniform: entries waiting in buf
+    for (uint32_t it = 0; it <= rounds; it++) {
+        bool take = false;
+        const uint32_t r = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        if (it < rounds && r < n) { const uint32_t P = r_P[r]; take = P > 0 && P <= 64 && !(r_qty[r] & RQ_DONE); }
+        const unsigned long long m = __ballot(take);
+        if (take) buf[have + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        have += (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        const bool last = it == rounds;
+        if (have >= 64 || (last && have)) {
+            const uint32_t nout = have >= 64 ? 64u : have;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(count, nout);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (lane < nout) queue[base + lane] = buf[lane];
+            const uint32_t rest = lane + 64 < have ? buf[lane + 64] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane + 64 < have) buf[lane] = rest;
+            have -= nout;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,51 +902,6 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
 // sort across the wave, cluster with ballots (get_similar/7): a run of consecutive gaps <= 20 with
 // Count >= 2 + Qty div 7 emits {LastPos, LastPos-FirstPos}; output in descending position order.
 // Clusters are staged as (S,D) u32 pairs in the read's own slice of `pos` (K <= P/2 pairs fit).
-// Persistent waves, software-pipelined over their reads (read i of a wave = wave + i * nwaves): the kernel is a chain
-// of dependent random reads per read (task row -> SA entries), so while read i is sorted and clustered the SA gather
-// of read i+1 and the task row of read i+2 are in flight.
-struct ClRow { uint32_t P, qty, cnt, sp, info, def; uint64_t so; };
-__device__ __forceinline__ void cl_issue_row(ClRow &w, uint32_t r, uint32_t n, uint32_t maxT, uint32_t lane,
-                                             const uint32_t *__restrict__ t_def, const uint32_t *__restrict__ t_sp,
-                                             const uint32_t *__restrict__ t_info, const uint32_t *__restrict__ t_cnt,
-                                             const uint32_t *__restrict__ r_P, const uint32_t *__restrict__ r_qty,
-                                             const uint64_t *__restrict__ seed_off) {
-    w.P = 0; w.qty = 0; w.cnt = 0; w.sp = 0; w.info = 0; w.def = 0; w.so = 0;
-    if (r < n) {
-        w.P = r_P[r]; w.qty = r_qty[r]; w.so = seed_off[r];
-        if (lane < maxT) {
-            const uint64_t t = (uint64_t)r * maxT + lane;
-            w.cnt = t_cnt[t]; w.sp = t_sp[t]; w.info = t_info[t]; w.def = t_def[t];
-        }
-    }
-}
-// seed `lane` of the read: issues its SA read, returns the raw entry and what is to be added (N + Shift + Skip)
-__device__ __forceinline__ void cl_issue_gather(const ClRow &w, const DevIndex &ix, uint32_t maxT, uint32_t lane, uint32_t *mk,
-                                                uint32_t &raw, uint32_t &madd) {
-    raw = 0; madd = 0;
-    if (w.P == 0 || w.P > 64 || maxT > 64) return;         // wave-uniform
-    const uint32_t cnt = lane < maxT ? w.cnt : 0u;
-    const uint32_t nadd = ((w.info >> 8) & 0xff) + (w.def >> 16);       // N + Shift + Skip (sga.erl:32,37-39)
-    uint32_t incl = cnt;
-    for (uint32_t o = 1; o < maxT; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    const uint32_t excl = incl - cnt;
-    // seed i of the read belongs to the sub-read whose slice [excl, excl+cnt) holds i: the sub-read lanes drop their
-    // id at their slice start in a wave-private LDS row, a ballot + clz finds every lane's slice start, and three
-    // ds_bpermutes fetch that sub-read's {Sp, N+Shift+Skip}
-    mk[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < maxT && cnt) mk[excl] = lane + 1;           // excl < P <= 64
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t tk = mk[lane];
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long tmask = __ballot(tk != 0);
-    const unsigned long long tb = tmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int s0 = 63 - __clzll(tb | 1ull);              // first seed slot of my sub-read
-    const uint32_t tid = __shfl(tk, s0, 64);             // its lane + 1
-    const uint32_t msp = __shfl(w.sp, (int)tid - 1, 64);
-    madd = __shfl(nadd, (int)tid - 1, 64);
-    if (lane < w.P) raw = ix.sa[msp - 1 + (lane - (uint32_t)s0)];
-}
 __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, uint32_t maxT,
                                                         const uint32_t *__restrict__ t_def,
                                                         const uint32_t *__restrict__ t_sp,
@@ -739,65 +910,64 @@ __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, 
                                                         const uint32_t *__restrict__ r_P,
                                                         const uint32_t *__restrict__ r_qty,
                                                         const uint64_t *__restrict__ seed_off,
-                                                        uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+                                                        uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
+                                                        const uint32_t *__restrict__ queue, const unsigned int *qcount) {
+    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (w >= n || (queue && w >= *qcount)) return;
+    const uint32_t r = queue ? queue[w] : w;              // queue: the reads k_collect_small listed
+    const uint32_t P = r_P[r], q0 = r_qty[r];
+    if (q0 & RQ_DONE) return;                             // clustered by k_seed_tasks already
+    if (P == 0) { if (lane == 0) r_K[r] = 0; return; }
+    if (P > 64 || maxT > 64) return;                      // k_cluster_big owns this read
+    const uint32_t qty = q0 & 0x1fffffffu;
+    uint32_t cnt = 0, sp = 0, nadd = 0;
+    if (lane < maxT) {
+        const uint64_t t = (uint64_t)r * maxT + lane;
+        cnt = t_cnt[t]; sp = t_sp[t];
+        nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);   // N + Shift + Skip (sga.erl:32,37-39)
+    }
+    uint32_t incl = cnt;
+    for (uint32_t o = 1; o < maxT; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const uint32_t excl = incl - cnt;
+    // seed i of the read belongs to the sub-read whose slice [excl, excl+cnt) holds i: the sub-read lanes drop their
+    // id at their slice start in a wave-private LDS row, a ballot + clz finds every lane's slice start, and three
+    // ds_bpermutes fetch that sub-read's {Sp, N+Shift+Skip}
     __shared__ uint32_t mark[4][64];
     uint32_t *mk = mark[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    if (wave >= n) return;
-    ClRow nx;                                             // task row in flight
-    cl_issue_row(nx, wave, n, maxT, lane, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off);
-    uint32_t cP = nx.P, cqty = nx.qty, craw, cadd;        // the read being clustered: its gather is in flight
-    uint64_t cso = nx.so;
-    cl_issue_gather(nx, ix, maxT, lane, mk, craw, cadd);
-    cl_issue_row(nx, wave + nwaves, n, maxT, lane, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off);
-    for (uint32_t r = wave; r < n; r += nwaves) {
-        // next read: its row has had a whole iteration to arrive; start its gather, then the row after that
-        const uint32_t gP = nx.P, gqty = nx.qty;
-        const uint64_t gso = nx.so;
-        uint32_t graw, gadd;
-        cl_issue_gather(nx, ix, maxT, lane, mk, graw, gadd);
-        if (r + nwaves < n) cl_issue_row(nx, r + 2 * nwaves, n, maxT, lane, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off);
-        // this read
-        const uint32_t P = cP;
-        if (P == 0) { if (lane == 0) r_K[r] = 0; }
-        else if (P <= 64 && maxT <= 64) {                          // else k_cluster_wave / k_cluster_big own this read
-            const uint32_t qty = cqty & 0x3fffffffu;
-            uint32_t p = lane < P ? craw + cadd : 0xffffffffu;
-            // bitonic sort ascending over 64 lanes
-#pragma unroll
-            for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    uint32_t o = __shfl_xor(p, j, 64);
-                    bool up = ((lane & k) == 0);
-                    bool lower = ((lane & j) == 0);
-                    uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
-                    p = (lower == up) ? mn : mx;
-                }
-            }
-            const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
-            const bool valid = lane < P;
-            const bool start = valid && (lane == 0 || p - prev > BWT_TOLERANCE);
-            const bool end = valid && (lane == P - 1 || next - p > BWT_TOLERANCE);
-            const unsigned long long smask = __ballot(start);
-            const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-            const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
-            const uint32_t pfirst = __shfl(p, s_i, 64);
-            const uint32_t nthr = 2 + qty / 7;                    // sga.erl:46
-            const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
-            const unsigned long long emask = __ballot(emit);
-            if (emit) {
-                const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
-                const uint64_t o = cso + 2ull * kk;
-                pos[o] = p;
-                pos[o + 1] = p - pfirst;
-            }
-            if (lane == 0) r_K[r] = (uint32_t)__popcll(emask);
-        }
-        cP = gP; cqty = gqty; cso = gso; craw = graw; cadd = gadd;
+    mk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < maxT && cnt) mk[excl] = lane + 1;           // excl < P <= 64
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t tk = mk[lane];
+    uint32_t p = 0xffffffffu;
+    {
+        const unsigned long long tmask = __ballot(tk != 0);
+        const unsigned long long tb = tmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int s0 = 63 - __clzll(tb | 1ull);              // first seed slot of my sub-read
+        const uint32_t tid = __shfl(tk, s0, 64);             // its lane + 1
+        const uint32_t msp = __shfl(sp, (int)tid - 1, 64), madd = __shfl(nadd, (int)tid - 1, 64);
+        if (lane < P) p = ix.sa[msp - 1 + (lane - (uint32_t)s0)] + madd;
     }
+    p = wave_sort_u32(p);                                 // ascending over the 64 lanes
+    const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
+    const bool valid = lane < P;
+    const bool start = valid && (lane == 0 || p - prev > BWT_TOLERANCE);
+    const bool end = valid && (lane == P - 1 || next - p > BWT_TOLERANCE);
+    const unsigned long long smask = __ballot(start);
+    const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
+    const uint32_t pfirst = __shfl(p, s_i, 64);
+    const uint32_t nthr = 2 + qty / 7;                    // sga.erl:46
+    const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
+    const unsigned long long emask = __ballot(emit);
+    if (emit) {
+        const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
+        const uint64_t o = seed_off[r] + 2ull * kk;
+        pos[o] = p;
+        pos[o + 1] = p - pfirst;
+    }
+    if (lane == 0) r_K[r] = (uint32_t)__popcll(emask);
 }
 
 // k_cluster_wave<R>: wave per read with 64 < P <= 64*R seeds (R = 2, 4; 150 bp reads on a large index sit
@@ -1001,7 +1171,8 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
                                                      const uint32_t *__restrict__ r_K,
                                                      const uint64_t *__restrict__ seed_off,
                                                      const uint64_t *__restrict__ clus_off,
-                                                     const uint32_t *__restrict__ pos, uint32_t *__restrict__ c_read,
+                                                     const uint32_t *__restrict__ pos, const uint32_t *__restrict__ r_qty,
+                                                     const uint32_t *__restrict__ r_cl, uint32_t *__restrict__ c_read,
                                                      uint32_t *__restrict__ c_S, uint32_t *__restrict__ c_D,
                                                      uint64_t *__restrict__ c_qoff, uint32_t *__restrict__ c_qlen,
                                                      int64_t *__restrict__ c_woff, uint32_t *__restrict__ c_wlen,
@@ -1013,9 +1184,11 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
         if (K) {
             const uint64_t qo = off[r];
             const uint32_t lq = (uint32_t)(off[r + 1] - qo);
-            const uint64_t co = clus_off[r], so = seed_off[r];
+            const uint64_t co = clus_off[r];
+            // clusters staged by k_seed_tasks (RQ_DONE) sit in the read's r_cl row, the cluster kernels' in its slice of pos
+            const uint32_t *cl = (r_qty[r] & RQ_DONE) ? r_cl + (uint64_t)r * (2 * CL_STAGE) : pos + seed_off[r];
             for (uint32_t k = 0; k < K; k++) {
-                const uint32_t S = pos[so + 2 * k], D = pos[so + 2 * k + 1];
+                const uint32_t S = cl[2 * k], D = cl[2 * k + 1];
                 const uint32_t wl = lq + D;
                 c_read[co + k] = r; c_S[co + k] = S; c_D[co + k] = D;
                 c_qoff[co + k] = qo; c_qlen[co + k] = lq;

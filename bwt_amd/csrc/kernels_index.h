@@ -45,6 +45,7 @@ struct DevIndex {
     uint32_t Pc, Pg, Pt, Last, dollar, nblk;
     uint32_t c0[4];        // {1, Pc-1, Pg-1, Pt-1}: 0-based first row of each F block (src/bwt.erl:105-112)
     const uint64_t *ktab;  // suffix-interval table, levels 8..kt_k (kernels.hip.h: kt_build); null when kt_k == 0
+    const uint4 *ktw;      // level kt_k as 64-byte entries that also carry the first 14 SA values, or null (then ktab holds it)
     int kt_k;
 };
 
@@ -135,6 +136,6 @@ __device__ __forceinline__ uint4 planes4(const uint32_t *__restrict__ planes, ui
 
 struct Counters {          // device-side work counters (roofline accounting)
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags, kt_lookups;
-    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, pad_;
+    unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, n_small;
 };
 

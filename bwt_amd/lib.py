@@ -34,7 +34,7 @@ class Constants(C.Structure):
 
 class BatchCounts(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_reads", "n_tasks", "lf_steps", "sa_reads", "n_clusters", "sw_cells",
-                                          "n_hits", "cigar_bytes", "window_bytes", "n_float", "n_traced", "n_dp", "n_lookups")]
+                                          "n_hits", "cigar_bytes", "window_bytes", "n_float", "n_traced", "n_dp", "n_lookups", "n_small")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -169,13 +169,16 @@ class Index:
         _chk(load().bwt_index_device_bytes(self.h, out))
         return dict(rank_blocks=int(out[0]), sa=int(out[1]), ref1=int(out[2]), ktable=int(out[3]))
 
-    def set_ktable(self, k):
-        """Suffix-interval table depth: 0 = none, 8..15, negative = the library's default for this index."""
-        _chk(load().bwt_index_set_ktable(self.h, int(k)))
+    def set_ktable(self, k, wide=-1):
+        """Suffix-interval table: depth k (0 = none, 8..15, negative = the library's default for this index) and
+        whether its top level carries SA values (1 / 0 / negative = default)."""
+        _chk(load().bwt_index_set_ktable(self.h, int(k), int(wide)))
 
     @property
     def ktable(self):
-        return int(load().bwt_index_ktable(self.h))
+        """(K, wide)"""
+        v = int(load().bwt_index_ktable(self.h))
+        return v & 15, bool(v & 16)
 
     def ref1(self, off, length):
         out = np.empty(length, np.uint8)

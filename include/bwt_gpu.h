@@ -65,9 +65,14 @@ int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[4]);
  * opened, so that a task costs one table read instead of up to 14 dependent steps (K = 15 answers every
  * task; smaller K leaves 15-K steps).  Results are identical with or without it.
  * K: 0 = none (every task searched step by step), 8..15, <0 = default (env BWT_KTAB, else by index size).
+ * wide: 1 = the top level as 64-byte entries that also hold the first 14 SA values of the range, so that
+ *   a task ending there needs no SA read and the seed kernel can cluster the read itself (64 * 4^K bytes:
+ *   68.7 GB at K = 15); 0 = 8-byte entries throughout; <0 = default (env BWT_KTAB_WIDE, else on when
+ *   K = 15 and it leaves >= 32 GB of HBM free).
  * Not to be called while a batch on this index is running. */
-int bwt_index_set_ktable(bwt_index *idx, int K);
-int bwt_index_ktable(const bwt_index *idx);        /* current K (0 = none) */
+int bwt_index_set_ktable(bwt_index *idx, int K, int wide);
+/* current K (0 = none), + 16 when the top level is wide */
+int bwt_index_ktable(const bwt_index *idx);
 
 /* ------------------------------------------------------------------ a-13 / 8f-1: index construction
  * Replaces fm_index:make_index/4 (src/fm_index.erl:127-141) = IUPAC map + random:uniform(4) for N
@@ -168,6 +173,7 @@ typedef struct {
     uint64_t n_traced;               /* candidates that needed a real traceback (not "<Lq>M") */
     uint64_t n_dp;                   /* candidates the prefilter could not settle (ran the DP)  */
     uint64_t n_lookups;              /* tasks answered or started from the suffix-interval table */
+    uint64_t n_small;                /* reads with 1..64 seeds left to k_cluster_small (the rest: none, fused, or wider kernels) */
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);
 void bwt_batch_destroy(bwt_batch *b);

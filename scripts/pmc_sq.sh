@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters for the extend kernel (chr1 workload)
+# SQ counters (VALU / LDS / wait cycles) of the seed, cluster and extend kernels, grch38 workload
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_sq
 mkdir -p $OUT
@@ -16,7 +16,7 @@ for d in ("a","b"):
     for f in glob.glob(root+"/"+d+"/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"].split("(")[0]
-            if ("k_sw_score" in k) or k.startswith("k_search") or k.startswith("k_cluster_small"):
+            if ("k_sw_pk" in k) or k.startswith("k_search") or k.startswith("k_cluster_small") or ("k_seed_tasks" in k) or k.startswith("k_sw_prefilter"):
                 agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])]+=1
     for k in agg:
         print(k, {c: "%.4g"%(v/n[(k,c)]) for c,v in agg[k].items()})

@@ -33,14 +33,16 @@ def mixed_reads(ref, n, seed):
 def ktable_depth(gpu_index):
     """Sets the suffix-interval table depth for one test and puts the default back."""
     def set_k(k):
-        gpu_index.set_ktable(k)
-        assert gpu_index.ktable == k
+        wide = isinstance(k, str)
+        gpu_index.set_ktable(int(k[:-1]) if wide else k, 1 if wide else 0)
+        assert gpu_index.ktable == ((15, True) if wide else (k, False))
     yield set_k
     gpu_index.set_ktable(-1)
 
 
-# 0: every task step by step; 8: smallest table; 9/12: table + remaining steps; 15: the table answers everything
-@pytest.mark.parametrize("K", [0, 8, 9, 12, 15])
+# 0: every task step by step; 8: smallest table; 9/12: table + remaining steps; 15: the table answers everything;
+# "15w": ... and its top level carries the SA values (the seed kernel clusters the reads itself)
+@pytest.mark.parametrize("K", [0, 8, 9, 12, 15, "15w"])
 def test_search_tasks_match_oracle(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc
@@ -67,13 +69,14 @@ def test_search_tasks_match_oracle(gpu_index, orc_fm, ref_bytes, ktable_depth, K
     if K == 0:
         assert counts["lf_steps"] >= steps and counts["n_lookups"] == 0   # steps that ended in not_found are counted too
     else:
-        assert counts["lf_steps"] <= max(0, 15 - K) * counts["n_tasks"] + 14 * (counts["n_tasks"] - counts["n_lookups"])
+        depth = 15 if K == "15w" else K
+        assert counts["lf_steps"] <= max(0, 15 - depth) * counts["n_tasks"] + 14 * (counts["n_tasks"] - counts["n_lookups"])
         assert 0 < counts["n_lookups"] <= counts["n_tasks"]
-    if K == 15:
+    if K in (15, "15w"):
         assert counts["lf_steps"] <= 14 * (counts["n_tasks"] - counts["n_lookups"])   # only tasks the table cannot take
 
 
-@pytest.mark.parametrize("K", [0, 10, 15])
+@pytest.mark.parametrize("K", [0, 10, 15, "15w"])
 def test_find_seeds_batch_lists(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc
@@ -91,9 +94,11 @@ def test_find_seeds_batch_lists(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
         assert got == seeds, sub
 
 
-def test_sga_batch_clusters(gpu_index, orc_fm, ref_bytes):
+@pytest.mark.parametrize("K", [9, "15w"])
+def test_sga_batch_clusters(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc
+    ktable_depth(K)
     reads = mixed_reads(ref_bytes, 600, 31) + [b"ACGT", b"", b"N" * 100, b"ACGTACGTACGTACGTACGT"]
     bases, off = lib.pack_reads(reads)
     out = gpu_index.sga_batch(bases, off)
@@ -180,7 +185,7 @@ def test_sw_long_cigar_overflow_path():
     assert (int(out["score"][0]), cig) == exp
 
 
-@pytest.mark.parametrize("K", [0, 9, 15])
+@pytest.mark.parametrize("K", [0, 9, 15, "15w"])
 def test_align_batch_matches_oracle(gpu_index, orc_fm, ref_bytes, ktable_depth, K):
     from bwt_amd import lib
     from oracle import orc, erl_literal as E
@@ -307,6 +312,53 @@ def test_parity_on_gpu_built_synthetic_index():
         assert got == exp, (i, q)
         nh += len(got)
     assert nh > 400
+    ix.close()
+
+
+def test_repeat_genome_all_cluster_paths():
+    """A genome with a 400-bp segment copied to 3, 6 and 12 places: reads from the copies have several clusters
+    and 36..150 seeds, so every cluster path runs -- the seed kernel's own clustering (wide table), its fall-back
+    when a read has more clusters than its staging row, and the wave / workgroup kernels for > 64 seeds.  The
+    same reads through every table mode must agree with the oracle."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(29)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 400_000, dtype=np.uint8)].tobytes())
+    segs = []
+    for copies, at in ((3, 10_000), (6, 60_000), (12, 150_000)):
+        seg = bytes(g[at:at + 400])
+        segs.append((seg, copies))
+        for c in range(1, copies):
+            p = at + c * 20_011
+            g[p:p + 400] = seg
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=1)
+    L, SA = ix.export()
+    ptr, shift = ix.meta()
+    ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+    ref1 = E.make_ref1(ref)
+    reads = []
+    for seg, copies in segs:
+        for s0 in range(0, 300, 37):
+            q = bytearray(seg[s0:s0 + 100])
+            reads.append(bytes(q))
+            q[50] = b"ACGT"[(b"ACGT".index(q[50]) + 1) & 3]
+            reads.append(bytes(q))
+    reads += synth_reads(ref, 300, 100, 5, max_subs=2)
+    bases, off = lib.pack_reads(reads)
+    exp = [orc.align_read(ofm, ref1, q) for q in reads]
+    assert max(len(e) for e in exp if e) >= 6
+    for mode in ((0, 0), (12, 0), (15, 0), (15, 1)):
+        ix.set_ktable(*mode)
+        out = ix.align_batch(bases, off)
+        for i, q in enumerate(reads):
+            a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+            if exp[i] is None:
+                assert out["read_status"][i] == 1 and a == b, (mode, i)
+                continue
+            got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+                    int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
+            assert got == exp[i], (mode, i, q)
     ix.close()
 
 
