@@ -47,11 +47,12 @@ int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream) {
 }
 
 // Suffix-interval table (kernels.hip.h: kt_build), levels 8..K.  K = 0 drops it; K < 0 picks the default: the
-// environment's BWT_KTAB if set, else the K in 8..15 with 4^K closest above the row count (4^K entries ~ rows:
-// deeper levels would mostly repeat "not found").  GRCh38: K = 15.
+// environment's BWT_KTAB if set, else the K in 8..15 with 4^K closest above the row count (deeper levels would mostly
+// repeat "not found") -- raised to 15 = MAX_LEN, where the table answers every task, once that K is >= 13 (more than
+// 16.7 M rows) and the 11.5 GB leave >= 32 GB of HBM free.  GRCh38: K = 15.
 // wide: the top level as 64-byte entries that carry the first 14 SA values of the range (a task that ends there needs
-// no SA read, and the seed kernel clusters such reads itself); only useful at K = 15 = MAX_LEN, where every full-length
-// task ends.  < 0: env BWT_KTAB_WIDE if set, else on when K = 15 and the 64 * 4^15 = 68.7 GB leave >= 32 GB of HBM free.
+// no SA read, and the seed kernel clusters such reads itself); only useful at K = 15, where every full-length task
+// ends.  < 0: env BWT_KTAB_WIDE if set, else on when K = 15 and the 64 * 4^15 = 68.7 GB leave >= 32 GB of HBM free.
 extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
     if (!ix) return fail(BWT_EINVAL, "bwt_index_set_ktable: null index");
     if (K < 0) {
@@ -60,6 +61,10 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
         else {
             K = KT_MIN;
             while (K < BWT_MAX_LEN && (1ull << (2 * K)) < (uint64_t)ix->Last) K++;
+            size_t free_b = 0, total_b = 0;
+            (void)hipSetDevice(ix->device);
+            if (K >= 13 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= kt_entries(BWT_MAX_LEN) * 8 + (32ull << 30))
+                K = BWT_MAX_LEN;
         }
     }
     if (K != 0 && (K < KT_MIN || K > BWT_MAX_LEN)) return fail(BWT_EINVAL, "bwt_index_set_ktable: K must be 0 or 8..15");

@@ -39,6 +39,34 @@ __device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool pred
     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+// A wave-private LDS staging buffer (128 u32) in front of a global queue: pushes gather in LDS and take queue space 64
+// entries at a time -- one same-address atomic per 64 entries instead of one per wave-iteration (they run at ~88 per us,
+// which a kernel that queues most of its items would spend tens of ms on).  push/drain are reached by whole waves.
+struct WaveQ { uint32_t *buf; uint32_t have; };
+__device__ __forceinline__ void waveq_out(WaveQ &q, uint32_t nout, uint32_t *__restrict__ gq, unsigned int *counter) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(counter, nout);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (lane < nout) gq[base + lane] = q.buf[lane];
+    const uint32_t rest = lane + 64 < q.have ? q.buf[lane + 64] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane + 64 < q.have) q.buf[lane] = rest;
+    q.have -= nout;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void waveq_push(WaveQ &q, bool pred, uint32_t v, uint32_t *__restrict__ gq, unsigned int *counter) {
+    const unsigned long long m = __ballot(pred);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63;
+    if (pred) q.buf[q.have + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+    q.have += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (q.have >= 64) waveq_out(q, 64, gq, counter);
+}
+__device__ __forceinline__ void waveq_drain(WaveQ &q, uint32_t *__restrict__ gq, unsigned int *counter) {
+    if (q.have) waveq_out(q, q.have, gq, counter);
+}
 __device__ __forceinline__ bool is_acgt(uint32_t c) {
     uint32_t i = c - 'A';   // A=0 C=2 G=6 T=19
     return i < 20u && ((0x80045u >> i) & 1u);
@@ -456,18 +484,27 @@ __global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restric
 // the queues of the wider cluster kernels.  Reached by whole waves (wave_append); `active` lanes carry a read.
 #define RQ_CRASH 0x80000000u
 #define RQ_PENDING 0x40000000u
+struct ReadQ { WaveQ big, m4, m2; };          // staging for the three queues of reads with more than 64 seeds
+#define READQ_LDS_WORDS (3 * 128)
+__device__ __forceinline__ void readq_init(ReadQ &q, uint32_t *lds) {
+    q.big.buf = lds; q.m4.buf = lds + 128; q.m2.buf = lds + 256; q.big.have = 0; q.m4.have = 0; q.m2.have = 0;
+}
+__device__ __forceinline__ void readq_drain(ReadQ &q, uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
+                                            uint32_t *__restrict__ mid4q, Counters *ctr) {
+    waveq_drain(q.big, bigq, &ctr->n_big); waveq_drain(q.m4, mid4q, &ctr->n_mid4); waveq_drain(q.m2, mid2q, &ctr->n_mid2);
+}
 __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned long long P, uint32_t qty, uint32_t crash,
                                             uint32_t maxT, uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                             uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
-                                            uint32_t *__restrict__ mid4q, Counters *ctr, unsigned long long &Psum, uint32_t &nsmall) {
+                                            uint32_t *__restrict__ mid4q, Counters *ctr, unsigned long long &Psum, uint32_t &nsmall,
+                                            ReadQ &rq) {
     if (qty < 2 || crash) P = 0;
     if (active && P > 0x7fffffffull) { atomicOr(&ctr->err_flags, 1ull); P = 0; }
     if (active) { r_P[r] = (uint32_t)P; r_qty[r] = qty | (crash ? RQ_CRASH : 0u); }
     const bool big = active && (P > 256 || (P > 0 && maxT > 64)), m4 = active && !big && P > 128, m2 = active && !big && !m4 && P > 64;
-    const uint32_t ib = wave_append(&ctr->n_big, big), i4 = wave_append(&ctr->n_mid4, m4), i2 = wave_append(&ctr->n_mid2, m2);
-    if (big) bigq[ib] = r;
-    if (m4) mid4q[i4] = r;
-    if (m2) mid2q[i2] = r;
+    waveq_push(rq.big, big, r, bigq, &ctr->n_big);
+    waveq_push(rq.m4, m4, r, mid4q, &ctr->n_mid4);
+    waveq_push(rq.m2, m2, r, mid2q, &ctr->n_mid2);
     if (active) { Psum += P; nsmall += (P > 0 && P <= 64 && maxT <= 64) ? 1u : 0u; }   // nsmall: reads k_cluster_small has to take
 }
 
@@ -479,8 +516,8 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 //     searches that stop before 8 bases in front of a base outside ACGTN, entries whose range did not fit -- becomes a
 //     bit of r_pend[r] for k_search_pending;
 //   * ballots and one wave prefix sum total each read for the cluster stage (as k_read_counts) when nothing is pending;
-//   * FUSE (the table's top level carries SA values, 8 <= maxT): reads whose every seed came with its table entry and
-//     that hold at most 64 seeds are clustered on the spot -- positions through a wave-private LDS row per read, then
+//   * FUSE (the table's top level carries SA values, 8 <= maxT): complete reads that hold at most 64 seeds are clustered
+//     on the spot (seeds of tasks that ended below the top level, or more than 14 of them, are read from the SA) -- positions through a wave-private LDS row per read, then
 //     sort and get_similar exactly as k_cluster_small -- into r_cl[r] (up to CL_STAGE {S, D} pairs) and marked
 //     RQ_DONE: no SA gather, no second pass over the task table.  Everything else takes the cluster kernels.
 //     lean: the task-table rows of such reads are not written at all (nothing reads them; bwt_batch_fetch_tasks refuses).
@@ -498,6 +535,9 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                                      uint32_t *__restrict__ mid4q, uint32_t *__restrict__ r_K,
                                                      uint32_t *__restrict__ r_cl, Counters *ctr, int lean) {
     __shared__ uint32_t lds_[FUSE ? 4 * 8 * 64 : 1];
+    __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
+    ReadQ rq;
+    readq_init(rq, rq_ + (threadIdx.x >> 6) * READQ_LDS_WORDS);
     const int K = ix.kt_k;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *lp = lds_ + (FUSE ? (threadIdx.x >> 6) * 8 * 64 : 0);      // [read of the pass][seed]
@@ -647,16 +687,38 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         }
         bool fuse_read = false;
         if (FUSE) {
-            // a read is clustered here when it is complete, clusters at all (Qty >= 2, no crash), holds <= 64 seeds, and
-            // every task with seeds has all of them inline (<= KT_INLINE, top level of the table)
-            const unsigned long long bx = __ballot(c > 0 && (!inl || c > KT_INLINE));
-            fuse_read = valid && !pend && qty >= 2 && !crash && P > 0 && P <= 64 && !((bx >> seg0) & segmask);
+            // a read is clustered here when it is complete, clusters at all (Qty >= 2, no crash) and holds <= 64 seeds
+            fuse_read = valid && !pend && qty >= 2 && !crash && P > 0 && P <= 64;
+            const bool inline_ok = inl && c <= KT_INLINE;                 // my seeds came with the table entry
+            // tasks that ended below the top level, or hold more than 14 seeds: their seeds are read from the SA, the whole
+            // wave on one task's range at a time (lane i takes SA[Sp + i]; c <= 64), four tasks' loads in flight together
+            {
+                unsigned long long need = __ballot(fuse_read && c && !inline_ok);
+                const uint32_t mydst = lread * 64 + (uint32_t)(incl - c - before);
+                while (need) {
+                    uint32_t gsp[4], gc[4], gadd[4], gdst[4], gv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        gc[t] = 0; gsp[t] = 1; gadd[t] = 0; gdst[t] = 0;
+                        if (need) {
+                            const int src = __ffsll((long long)need) - 1;
+                            need &= need - 1ull;
+                            gsp[t] = (uint32_t)__shfl((int)tk.sp, src, 64); gc[t] = (uint32_t)__shfl((int)c, src, 64);
+                            gadd[t] = (uint32_t)__shfl((int)nadd, src, 64); gdst[t] = (uint32_t)__shfl((int)mydst, src, 64);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) gv[t] = lane < gc[t] ? ix.sa[gsp[t] - 1 + lane] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) if (lane < gc[t]) lp[gdst[t] + lane] = gv[t] + gadd[t];
+                }
+            }
             // positions into the read's LDS row: lane q of the quad holds quarter q of the quad's four entries, i.e. SA values
             // [4q-2, 4q+2) of each (quarter 0: values 0, 1 in its .z, .w)
             {
                 const int ql = (int)(lane & 3);
-                const uint32_t dsto = fuse_read && c ? lread * 64 + (uint32_t)(incl - c - before) : 0u;
-                const uint32_t cw = fuse_read ? c : 0u;                       // seeds of mine to write
+                const uint32_t cw = fuse_read && inline_ok ? c : 0u;          // seeds of mine the quad writes
+                const uint32_t dsto = cw ? lread * 64 + (uint32_t)(incl - c - before) : 0u;
 #define KT_QWRITE(T)                                                                                                   \
                 {                                                                                                      \
                     const uint32_t ct = quad_bcast<T>(cw), dt = quad_bcast<T>(dsto), at = quad_bcast<T>(nadd);         \
@@ -675,7 +737,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         if (valid && !(lean && fuse_read)) {
             t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
         }
-        read_finish(leader && !pend && !fuse_read, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall);
+        read_finish(leader && !pend && !fuse_read, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall, rq);
         if (FUSE) {
             if (leader && fuse_read) { r_P[r] = 0; r_qty[r] = qty | RQ_DONE; Psum += P; }   // r_P: seeds still to be clustered
             __builtin_amdgcn_wave_barrier();
@@ -712,6 +774,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
             __builtin_amdgcn_wave_barrier();
         }
     }
+    readq_drain(rq, bigq, mid2q, mid4q, ctr);
     unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
     if (lane == 0 && (l | k | s | ns)) {
         atomicAdd(&ctr->n_tasks, l);
@@ -734,6 +797,9 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                                                          uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                          uint32_t *__restrict__ mid4q, Counters *ctr) {
     __shared__ uint32_t slot_[4][64];
+    __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
+    ReadQ rq;
+    readq_init(rq, rq_ + (threadIdx.x >> 6) * READQ_LDS_WORDS);
     uint32_t *slot = slot_[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63;
     const int ql = (int)(lane & 3);
@@ -804,10 +870,11 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                     else if (status == TS_CRASH) crash = 1;
                 }
             }
-            read_finish(have && ql == 0, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall);
+            read_finish(have && ql == 0, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall, rq);
         }
         __builtin_amdgcn_wave_barrier();
     }
+    readq_drain(rq, bigq, mid2q, mid4q, ctr);
     unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), ps = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
     if (lane == 0 && (s | ps | ns)) {
         atomicAdd(&ctr->lf_steps, s);
@@ -840,6 +907,9 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
                                                       uint32_t *__restrict__ r_qty, uint32_t *__restrict__ bigq,
                                                       uint32_t *__restrict__ mid2q, uint32_t *__restrict__ mid4q, Counters *ctr) {
     // grid-stride (capped grid): one counter atomic per wave for the whole launch, not per 64 reads
+    __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
+    ReadQ rq;
+    readq_init(rq, rq_ + (threadIdx.x >> 6) * READQ_LDS_WORDS);
     unsigned long long Psum = 0;
     uint32_t nsmall = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -854,8 +924,9 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
                 if (st == TS_SEEDS) { qty++; P += t_cnt[(uint64_t)r * maxT + k]; }
                 else if (st == TS_CRASH) crash = 1;
             }
-        read_finish(r < n, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall);
+        read_finish(r < n, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall, rq);
     }
+    readq_drain(rq, bigq, mid2q, mid4q, ctr);
     unsigned long long s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
     if ((threadIdx.x & 63) == 0 && (s | ns)) { atomicAdd(&ctr->sa_reads, s); if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns); }
 }
