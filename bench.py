@@ -281,15 +281,20 @@ def main():
         per = {k: v["ms"] / v["launches"] for k, v in kt.items()}           # avg ms per launch
         dom = max(per, key=lambda k: kt[k]["ms"])
         # Per-kernel rooflines (algorithmic bytes per launch, SURVEY 8d terms, over the launch time from hipEvents):
-        #   fm_lookup   Lq per read in (plane windows), 8 B table entry per lookup, 16 B per sub-read result out
+        #   fm_lookup   k_seed_tasks: Lq per read in (plane windows), one table entry per task (64 B when the top level
+        #               carries the SA values, else 8 B), 4 B per task out (sub-read table) + the rows of the reads it does
+        #               not cluster itself (16 B per task), 8 B per cluster and 16 B per read out
         #   fm_search   128 B per LF step (two 64-B rank blocks) [+ the read/result terms when there is no table]
         #   cluster     4 B per SA entry gathered, 16 B per task-table row in, 8 B per cluster out
         #   sw_extend   integer VALU (not HBM, not MFMA): 7.4 lane-ops per DP cell against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
         traffic = load_traffic(wl) or {}
         total_ms = sum(v["ms"] for v in kt.values())
         io_terms = counts["n_reads"] * length + 16 * counts["n_tasks"]
+        kdepth, kwide = ix.ktable
+        unfused = counts["n_small"] / max(counts["n_reads"], 1) if kwide else 1.0
         models = {
-            "fm_lookup": ("k_lookup", io_terms + 8 * counts["n_lookups"]),
+            "fm_lookup": ("k_seed_tasks", counts["n_reads"] * (length + 16) + (64 if kwide else 8) * counts["n_lookups"]
+                          + 4 * counts["n_tasks"] + int(16 * counts["n_tasks"] * unfused) + 8 * counts["n_clusters"]),
             "fm_search": ("k_search", 128 * counts["lf_steps"] + (0 if "fm_lookup" in per else io_terms)),
             "cluster_small": ("k_cluster_small", 4 * counts["sa_reads"] + 16 * counts["n_tasks"] + 8 * counts["n_clusters"]),
         }
@@ -302,10 +307,11 @@ def main():
                               "avg_launch_ms": per[key], "share_of_step": kt[key]["ms"] / total_ms}
         if "sw_extend" in per:
             dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
-            ops = dp_cells * 7.4 / (per["sw_extend"] / 1e3) / 1e12
+            ops_per_cell = 7.4 if "sw_trace_pk" in per else 9.4      # score-only pass / the traced DP run on the whole DP queue
+            ops = dp_cells * ops_per_cell / (per["sw_extend"] / 1e3) / 1e12
             roofs["sw_extend"] = {"kernel": "k_sw_pk", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS,
                                   "unit": "Tlane-op/s", "frac": ops / VALU_PEAK_TOPS, "traffic": traffic.get("k_sw"),
-                                  "cells_per_launch": dp_cells, "avg_launch_ms": per["sw_extend"],
+                                  "cells_per_launch": dp_cells, "valu_lane_ops_per_cell": ops_per_cell, "avg_launch_ms": per["sw_extend"],
                                   "share_of_step": kt["sw_extend"]["ms"] / total_ms}
         roof = roofs.get(dom) or roofs[max(roofs, key=lambda k: kt[k]["ms"])]
         line = {
@@ -315,6 +321,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
+                       "suffix_interval_table": {"K": ix.ktable[0], "top_level_carries_sa": ix.ktable[1]},
                        "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world},
             "roofline": roof,
             "rooflines": roofs,

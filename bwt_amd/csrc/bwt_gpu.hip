@@ -687,7 +687,15 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         const uint64_t lds_pk = (uint64_t)(2 * ((wcap + 31) / 32) + 2 * qw) * 64 * 4 * 2 * 4;     // 2 sets x 4 waves
         const uint32_t per_cu = 2;                                                             // VGPR-limited (181 / 247 VGPRs)
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * per_cu);
-        {
+        // After the prefilter the DP queue holds hardly any plain diagonal (those with <= 2 mismatches in a square window are
+        // gone): a score-only pass would hand most of it on to the traced pass anyway (measured, 150 bp reads with indels:
+        // 14.7 + 17.6 ms against 26.8 ms for tracing everything), so the traced DP runs on the DP queue directly.
+        static const char *env_ta = getenv("BWT_SW_TRACE_ALL");     // experiments: 0 = score pass first
+        const bool trace_all = io.dq && !(env_ta && env_ta[0] == '0');
+        if (trace_all) {
+            io.tq2 = io.dq;
+            HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->tq2_count, &b->ctr.as<Counters>()->dq_count, 4, hipMemcpyDeviceToDevice, b->stream));
+        } else {
             ProfScope ps(b, "sw_extend");
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
@@ -702,7 +710,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         uint32_t tblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (4ull << 30) / (per_wave_pk * 4)));
         if ((rc = b->slab_dir_pk.ensure((uint64_t)tblocks * 4 * per_wave_pk))) return rc;
         {
-            ProfScope ps(b, "sw_trace_pk");
+            ProfScope ps(b, trace_all ? "sw_extend" : "sw_trace_pk");
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
                                    b->slab_dir_pk.as<uint32_t>(), w1);

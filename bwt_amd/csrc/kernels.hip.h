@@ -1518,6 +1518,9 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 //     two mismatches -> done unless one of the two single-insertion detours (see the code) exists;
 //   * everything else -> DP queue (dense, so the DP kernels' lanes stay full).
 __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
+    __shared__ uint32_t wq_[4][2][128];
+    WaveQ qfp, qdp;
+    qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
     const uint32_t *qp = io.qplanes, *wp = io.wplanes;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t c0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); c0 < n_items; c0 += stride) {   // whole waves iterate together
@@ -1610,11 +1613,12 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
                 }
             }
         }
-        // one atomic per wave and queue
-        const uint32_t ifp = wave_append(&io.ctr->fp_count, route == 1), idq = wave_append(&io.ctr->dq_count, route == 2);
-        if (route == 1) io.fpq[ifp] = c;
-        if (route == 2) io.dq[idq] = c;
+        // the two queues, staged in LDS (one atomic per 64 entries)
+        waveq_push(qfp, route == 1, c, io.fpq, &io.ctr->fp_count);
+        waveq_push(qdp, route == 2, c, io.dq, &io.ctr->dq_count);
     }
+    waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
+    waveq_drain(qdp, io.dq, &io.ctr->dq_count);
 }
 
 // ------------------------------------------------------------------------------------------------
