@@ -524,6 +524,7 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 // RAW: one task per "read", already in t_def (bwt_find_seeds_batch).  1 <= maxT <= 64.
 #define RQ_DONE 0x20000000u
 #define CL_STAGE 4
+#define CL_ROW 128                                            // most seeds of a read the seed kernel clusters itself
 template <bool RAW, bool FUSE>
 __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t *__restrict__ planes,
                                                      const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
@@ -534,13 +535,13 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                                      uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                      uint32_t *__restrict__ mid4q, uint32_t *__restrict__ r_K,
                                                      uint32_t *__restrict__ r_cl, Counters *ctr, int lean) {
-    __shared__ uint32_t lds_[FUSE ? 4 * 8 * 64 : 1];
+    __shared__ uint32_t lds_[FUSE ? 4 * 8 * CL_ROW : 1];
     __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
     ReadQ rq;
     readq_init(rq, rq_ + (threadIdx.x >> 6) * READQ_LDS_WORDS);
     const int K = ix.kt_k;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t *lp = lds_ + (FUSE ? (threadIdx.x >> 6) * 8 * 64 : 0);      // [read of the pass][seed]
+    uint32_t *lp = lds_ + (FUSE ? (threadIdx.x >> 6) * 8 * CL_ROW : 0);  // [read of the pass][seed]
     const uint32_t rw = 64u / maxT;                               // reads per wave pass (FUSE: <= 8)
     const uint32_t lread = lane / maxT, slot = lane - lread * maxT;
     const uint32_t seg0 = lread * maxT;                           // first lane of my read
@@ -687,14 +688,14 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         }
         bool fuse_read = false;
         if (FUSE) {
-            // a read is clustered here when it is complete, clusters at all (Qty >= 2, no crash) and holds <= 64 seeds
-            fuse_read = valid && !pend && qty >= 2 && !crash && P > 0 && P <= 64;
+            // a read is clustered here when it is complete, clusters at all (Qty >= 2, no crash) and holds <= 128 seeds
+            fuse_read = valid && !pend && qty >= 2 && !crash && P > 0 && P <= CL_ROW;
             const bool inline_ok = inl && c <= KT_INLINE;                 // my seeds came with the table entry
             // tasks that ended below the top level, or hold more than 14 seeds: their seeds are read from the SA, the whole
-            // wave on one task's range at a time (lane i takes SA[Sp + i]; c <= 64), four tasks' loads in flight together
+            // wave on one task's range at a time (lane i takes SA[Sp + i], SA[Sp + 64 + i]), four tasks' loads in flight together
             {
                 unsigned long long need = __ballot(fuse_read && c && !inline_ok);
-                const uint32_t mydst = lread * 64 + (uint32_t)(incl - c - before);
+                const uint32_t mydst = lread * CL_ROW + (uint32_t)(incl - c - before);
                 while (need) {
                     uint32_t gsp[4], gc[4], gadd[4], gdst[4], gv[4];
 #pragma unroll
@@ -711,6 +712,9 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                     for (int t = 0; t < 4; t++) gv[t] = lane < gc[t] ? ix.sa[gsp[t] - 1 + lane] : 0u;
 #pragma unroll
                     for (int t = 0; t < 4; t++) if (lane < gc[t]) lp[gdst[t] + lane] = gv[t] + gadd[t];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)                                   // (a range of 65..128 rows)
+                        if (lane + 64 < gc[t]) lp[gdst[t] + 64 + lane] = ix.sa[gsp[t] - 1 + 64 + lane] + gadd[t];
                 }
             }
             // positions into the read's LDS row: lane q of the quad holds quarter q of the quad's four entries, i.e. SA values
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
             {
                 const int ql = (int)(lane & 3);
                 const uint32_t cw = fuse_read && inline_ok ? c : 0u;          // seeds of mine the quad writes
-                const uint32_t dsto = cw ? lread * 64 + (uint32_t)(incl - c - before) : 0u;
+                const uint32_t dsto = cw ? lread * CL_ROW + (uint32_t)(incl - c - before) : 0u;
 #define KT_QWRITE(T)                                                                                                   \
                 {                                                                                                      \
                     const uint32_t ct = quad_bcast<T>(cw), dt = quad_bcast<T>(dsto), at = quad_bcast<T>(nadd);         \
@@ -746,29 +750,78 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                 if (!((bf >> (j * maxT)) & 1ull)) continue;                                  // wave-uniform
                 const uint32_t rj = g * rw + j;
                 const uint32_t Pj = (uint32_t)__shfl((int)(uint32_t)P, (int)(j * maxT), 64), qj = (uint32_t)__shfl((int)qty, (int)(j * maxT), 64);
-                uint32_t p = lane < Pj ? lp[j * 64 + lane] : 0xffffffffu;
-                p = wave_sort_u32(p);
-                const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
-                const bool vl = lane < Pj;
-                const bool start = vl && (lane == 0 || p - prev > BWT_TOLERANCE);
-                const bool end = vl && (lane == Pj - 1 || next - p > BWT_TOLERANCE);
-                const unsigned long long smask = __ballot(start);
-                const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-                const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
-                const uint32_t pfirst = __shfl(p, s_i, 64);
                 const uint32_t nthr = 2 + qj / 7;                     // sga.erl:46
-                const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
-                const unsigned long long emask = __ballot(emit);
-                const uint32_t Kc = (uint32_t)__popcll(emask);
-                if (Kc <= CL_STAGE) {
-                    if (emit) {
-                        const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
-                        r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = p;
-                        r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = p - pfirst;
+                uint32_t *row = lp + j * CL_ROW;
+                if (Pj <= 64) {
+                    uint32_t p = lane < Pj ? row[lane] : 0xffffffffu;
+                    p = wave_sort_u32(p);
+                    const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
+                    const bool vl = lane < Pj;
+                    const bool start = vl && (lane == 0 || p - prev > BWT_TOLERANCE);
+                    const bool end = vl && (lane == Pj - 1 || next - p > BWT_TOLERANCE);
+                    const unsigned long long smask = __ballot(start);
+                    const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                    const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
+                    const uint32_t pfirst = __shfl(p, s_i, 64);
+                    const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
+                    const unsigned long long emask = __ballot(emit);
+                    const uint32_t Kc = (uint32_t)__popcll(emask);
+                    if (Kc <= CL_STAGE) {
+                        if (emit) {
+                            const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
+                            r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = p;
+                            r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = p - pfirst;
+                        }
+                        if (lane == 0) r_K[rj] = Kc;
+                    } else if (lane == 0) {                           // more clusters than the staging row holds: k_cluster_small redoes it
+                        r_P[rj] = Pj; r_qty[rj] = qj; nsmall++;
                     }
-                    if (lane == 0) r_K[rj] = Kc;
-                } else if (lane == 0) {                               // more clusters than the staging row holds: the cluster kernels redo it
-                    r_P[rj] = Pj; r_qty[rj] = qj; nsmall++;
+                } else {
+                    // 65..128 seeds: two per lane (element e = 64 q + lane).  Both halves sorted, then element i meets element
+                    // 127 - i (the smaller 64 stay in the low half), then each half -- bitonic now -- is merged.
+                    uint32_t p0 = row[lane], p1 = lane + 64 < Pj ? row[64 + lane] : 0xffffffffu;
+                    p0 = wave_sort_u32(p0); p1 = wave_sort_u32(p1);
+                    const uint32_t rv = (uint32_t)__shfl((int)p1, 63 - (int)lane, 64);
+                    const uint32_t lo = p0 < rv ? p0 : rv, hi = p0 < rv ? rv : p0;
+                    p0 = bitonic_merge<64, 32>(lo); p1 = bitonic_merge<64, 32>(hi);
+                    __builtin_amdgcn_wave_barrier();
+                    row[lane] = p0; row[64 + lane] = p1;
+                    __builtin_amdgcn_wave_barrier();
+                    // run starts and emit flags per half (ascending), the last run start carried across (as k_cluster_wave<2>)
+                    unsigned long long em[2];
+                    uint32_t s_of[2];
+                    uint32_t carry_s = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const uint32_t e = (uint32_t)(q * 64) + lane, pe = q ? p1 : p0;
+                        const uint32_t prev = e ? row[e - 1] : 0u, next = e + 1 < 128u ? row[e + 1] : 0xffffffffu;
+                        const bool vl = e < Pj;
+                        const bool start = vl && (e == 0 || pe - prev > BWT_TOLERANCE);
+                        const bool end = vl && (e == Pj - 1 || next - pe > BWT_TOLERANCE);
+                        const unsigned long long smask = __ballot(start);
+                        const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                        uint32_t s_e = carry_s;
+                        if (below) s_e = (uint32_t)(q * 64 + (63 - __clzll(below)));
+                        if (smask) carry_s = (uint32_t)(q * 64 + (63 - __clzll(smask)));
+                        s_of[q] = s_e;
+                        em[q] = __ballot(end && (e - s_e + 1 >= nthr));
+                    }
+                    const uint32_t Kc = (uint32_t)(__popcll(em[0]) + __popcll(em[1]));
+                    if (Kc <= CL_STAGE) {
+                        uint32_t above = 0;                           // output in descending position order
+#pragma unroll
+                        for (int q = 1; q >= 0; q--) {
+                            if ((em[q] >> lane) & 1ull) {
+                                const uint32_t pe = q ? p1 : p0;
+                                const uint32_t kk = above + (uint32_t)__popcll(lane == 63 ? 0ull : (em[q] >> (lane + 1)));
+                                r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = pe;
+                                r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = pe - row[s_of[q]];
+                            }
+                            above += (uint32_t)__popcll(em[q]);
+                        }
+                        if (lane == 0) r_K[rj] = Kc;
+                    } else if (lane == 0) { r_P[rj] = Pj; r_qty[rj] = qj; }          // ... k_cluster_wave<2> redoes it
+                    waveq_push(rq.m2, lane == 0 && Kc > CL_STAGE, rj, mid2q, &ctr->n_mid2);
                 }
             }
             __builtin_amdgcn_wave_barrier();
