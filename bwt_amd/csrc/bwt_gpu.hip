@@ -372,9 +372,9 @@ static int dev_scan(bwt_batch *b, const uint32_t *in, uint64_t *out, uint64_t n)
     int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8);
     if (rc) return rc;
     uint64_t *bs = b->scan_tmp.as<uint64_t>();
-    KLAUNCH(b, "scan", k_scan1, nb, SCAN_BLOCK, in, out, bs, n);
+    KLAUNCH(b, "scan", k_scan1, nb, SCAN_BLOCK, in, bs, n);
     KLAUNCH(b, "scan", k_scan2, 1, SCAN_BLOCK, bs, nb);
-    KLAUNCH(b, "scan", k_scan3, nb, SCAN_BLOCK, out, bs, n, nb);
+    KLAUNCH(b, "scan", k_scan3, nb, SCAN_BLOCK, in, out, bs, n, nb);
     return 0;
 }
 
@@ -578,10 +578,20 @@ static int stage_cluster(bwt_batch *b) {
         KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
                 b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>());
-    if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
     uint64_t total_seeds = 0;
-    HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    if ((rc = fetch_counters(b))) return rc;                                   // sync #1
+    if (b->fused) {
+        // the seed kernel clustered what it could: the per-read seed slices (seed_off, pos) are only needed if reads are left
+        if ((rc = fetch_counters(b))) return rc;                               // sync #1
+        if (b->hctr.n_small || b->hctr.n_mid2 || b->hctr.n_mid4 || b->hctr.n_big) {
+            if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
+            HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+        }
+    } else {
+        if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
+        HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = fetch_counters(b))) return rc;                               // sync #1
+    }
     if (b->hctr.err_flags & 1) return fail(BWT_EOVERFLOW, "a read produced more than 2^31 seeds");
     if (total_seeds > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 seeds: split it");
     if ((rc = b->pos.ensure(total_seeds * 4 + 16))) return rc;
@@ -668,7 +678,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     static const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
     if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
         io.dq = b->dq.as<uint32_t>();
-        KLAUNCH(b, "sw_prefilter", k_sw_prefilter, std::min<uint32_t>(cdiv(nc, 256), 2048), 256, io, (uint32_t)nc);
+        KLAUNCH(b, "sw_prefilter", k_sw_prefilter, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc);   // quad per candidate
     }
 
     // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and

@@ -110,30 +110,35 @@ __device__ __forceinline__ uint32_t bitonic_sort_upto(uint32_t p) {
 __device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) { return bitonic_sort_upto<64>(p); }
 
 // ------------------------------------------------------------------------------------------------
-// exclusive scan  u32 -> u64   (3 kernels: per-block, block sums, add back)
+// exclusive scan  u32 -> u64   (3 kernels: tile sums, scan of the sums, tile scans + offset: the input is read
+// twice, the output written once)
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                       uint64_t *__restrict__ bsum, uint64_t n) {
-    __shared__ uint64_t sh[SCAN_BLOCK];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t v[SCAN_ITEMS], s = 0;
+// sum of this block's 256 per-thread values in every thread's return; `excl` = sum of the threads before this one
+__device__ __forceinline__ uint64_t block_scan_u64(uint64_t s, uint64_t &excl) {
+    __shared__ uint64_t wsum[SCAN_BLOCK / 64];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t incl = s;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
-    sh[threadIdx.x] = s;
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t up = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += up; }
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
-        uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint64_t run = sh[threadIdx.x] - s;
+    uint64_t before = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
-    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+    for (int w = 0; w < SCAN_BLOCK / 64; w++) { const uint64_t t = wsum[w]; if ((uint32_t)w < wv) before += t; total += t; }
+    excl = before + incl - s;
+    return total;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict__ in, uint64_t *__restrict__ bsum, uint64_t n) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) s += base + k < n ? in[base + k] : 0u;
+    uint64_t excl;
+    const uint64_t total = block_scan_u64(s, excl);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 // single block: exclusive scan of bsum[0..nb) in place, total to bsum[nb]
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t nb) {
@@ -159,12 +164,18 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t n
     }
     if (threadIdx.x == 0) bsum[nb] = carry;
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(uint64_t *__restrict__ out, const uint64_t *__restrict__ bsum,
-                                                       uint64_t n, uint32_t nb) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                       const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) {
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    const uint64_t add = bsum[blockIdx.x];
+    uint32_t v[SCAN_ITEMS];
+    uint64_t s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] += add;
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    uint64_t excl;
+    (void)block_scan_u64(s, excl);
+    uint64_t run = bsum[blockIdx.x] + excl;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
 }
 
@@ -1559,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sw_prefilter: lane per candidate, on the bit-planes of reads and Ref1 only.
+// k_sw_prefilter: QUAD per candidate, on the bit-planes of reads and Ref1 only.
 //   * a base outside ACGT in the read or the window  -> fp64 queue (sigma may return 1.6);
 //   * the read matches the window exactly on some diagonal -> done: 2*Lq is the largest score any
 //     alignment of Lq bases can have (sigma <= 2, gaps cost), only a gap-free all-match diagonal reaches
@@ -1570,105 +1581,159 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
 //     the unique optimum, every cell on it ties or wins as up_left, and no column left of Lq reaches it;
 //     two mismatches -> done unless one of the two single-insertion detours (see the code) exists;
 //   * everything else -> DP queue (dense, so the DP kernels' lanes stay full).
+// Lane q of the quad takes the 32-base chunks q, q+4, ...: its plane words arrive with one 16-byte load (all four
+// planes), the word after it from the next lane by DPP (lane 3 loads it), so a candidate costs ~6 L2 requests instead
+// of 16; mismatch counts and positions meet in quad reductions.
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    return v;
+}
+__device__ __forceinline__ uint32_t quad_min(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = v < o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); return v < o ? v : o;
+}
+__device__ __forceinline__ uint32_t quad_max(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); return v > o ? v : o;
+}
+// all four planes of the 32 bases from bit position pos + 32 * ql (ql = lane in quad): word ql of the run that starts at
+// pos's word, completed by the next lane's word
+__device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ planes, uint64_t pos, int ql) {
+    const uint64_t w = (pos >> 5) + (uint64_t)ql;
+    const uint32_t sh = (uint32_t)pos & 31u;
+    const uint4 a = ((const uint4 *)planes)[w];
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (ql == 3) x = ((const uint4 *)planes)[w + 1];
+    uint4 b;                                                   // the next lane's word (quad_perm [1,2,3,3]); lane 3: its extra load
+    b.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.x, 0xF9, 0xF, 0xF, true); b.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.y, 0xF9, 0xF, 0xF, true);
+    b.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.z, 0xF9, 0xF, 0xF, true); b.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.w, 0xF9, 0xF, 0xF, true);
+    if (ql == 3) b = x;
+    uint4 r;
+    r.x = __builtin_amdgcn_alignbit(b.x, a.x, sh); r.y = __builtin_amdgcn_alignbit(b.y, a.y, sh);
+    r.z = __builtin_amdgcn_alignbit(b.z, a.z, sh); r.w = __builtin_amdgcn_alignbit(b.w, a.w, sh);
+    return r;
+}
 __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
     __shared__ uint32_t wq_[4][2][128];
     WaveQ qfp, qdp;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
     const uint32_t *qp = io.qplanes, *wp = io.wplanes;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t c0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); c0 < n_items; c0 += stride) {   // whole waves iterate together
-        const uint32_t c = c0 + (threadIdx.x & 63);
+    const int ql = (int)(threadIdx.x & 3);
+    const uint32_t stride = (gridDim.x * blockDim.x) >> 2;                  // candidates per sweep
+    const uint32_t first = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 2;
+    for (uint32_t c0 = first; c0 < n_items; c0 += stride) {                 // whole waves iterate together
+        const uint32_t c = c0 + ((threadIdx.x & 63) >> 2);
         int route = 0;                 // 0 nothing (idle / out of range / settled), 1 fp64 queue, 2 DP queue
-        if (c < n_items) {
-            const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
-            const int64_t wo = io.c_woff[c];
-            const uint64_t qo = io.c_qoff[c];
-            if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
-                io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
-            } else {
-                // one pass over read and window: bases outside ACGT anywhere, and (square window) the mismatches of the diagonal
-                uint32_t bad = 0, mism = 0, p1 = 0, p2 = 0;
-                const bool square = w == lq;
-                for (uint32_t i = 0; i < lq; i += 32) {
-                    const uint4 q4 = planes4(qp, qo + i);
-                    const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
-                    bad |= (q4.z | q4.w) & mk;
-                    if (square) {
-                        const uint4 w4 = planes4(wp, (uint64_t)wo + i);
-                        bad |= (w4.z | w4.w) & mk;
-                        const uint32_t e = ((q4.x ^ w4.x) | (q4.y ^ w4.y)) & mk;
-                        if (e) {
-                            if (!mism) p1 = i + (uint32_t)__ffs((int)e) - 1u;
-                            p2 = i + 31u - (uint32_t)__clz((int)e);
-                            mism += __popc(e);
-                        }
-                    }
-                }
-                if (!square)
-                    for (uint32_t i = 0; i < w; i += 32) {
-                        const uint4 w4 = planes4(wp, (uint64_t)wo + i);
-                        const uint32_t mk = w - i < 32 ? (1u << (w - i)) - 1u : 0xffffffffu;
-                        bad |= (w4.z | w4.w) & mk;
-                    }
-                if (bad) { io.c_status[c] = CS_NEED_FP; route = 1; }
-                else {
-                    bool done = false;
-                    int score = 2 * (int)lq;
-                    if (square) {
-                        // square window: one full diagonal with m mismatches at p1 <= p2, score 2*Lq - 3m.  Every other path
-                        // into a diagonal cell or into the last row holds u >= 1 insertions, and a run of g gap steps costs
-                        // g + 1: u >= 2 loses >= 7, u = 1 loses >= 4.  m <= 1 (loss <= 3): the diagonal is the unique optimum.
-                        // m = 2 (loss 6): only two kinds of path can reach it -- one insertion and otherwise all matches:
-                        //   (a) into a diagonal cell past p2: start one column in, ride diagonal +1 (q[k] = r[k+1]) for every
-                        //       k < t, insert q[t], t >= p2: exists iff the first f1 = #leading matches on diagonal +1 >= p2;
-                        //   (b) into the last row at column Lq-1 (a tie there would be the LEFTMOST maximum): main diagonal
-                        //       for k < t <= p1, insert q[t], then diagonal -1 (q[k] = r[k-1]) for every k > t: exists iff
-                        //       the highest mismatch on diagonal -1 sits at h <= p1.
-                        // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
-                        // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
-                        done = mism <= 1 && lq >= 8;
-                        if (mism == 2 && lq >= 8) {
-                            // diagonals +1 and -1 hold Lq-1 pairs each: bit i of e_up = (q[i] != r[i+1]), of e_dn = (q[i+1] != r[i])
-                            uint32_t f1 = lq - 1, h = 0;
-                            bool seen = false;
-                            for (uint32_t i = 0; i + 1 < lq; i += 32) {
-                                const uint4 q0 = planes4(qp, qo + i), q1 = planes4(qp, qo + 1 + i);
-                                const uint4 w0 = planes4(wp, (uint64_t)wo + i), w1 = planes4(wp, (uint64_t)wo + 1 + i);
-                                uint32_t eu = (q0.x ^ w1.x) | (q0.y ^ w1.y), ed = (q1.x ^ w0.x) | (q1.y ^ w0.y);
-                                if (lq - 1 - i < 32) { const uint32_t mk = (1u << (lq - 1 - i)) - 1u; eu &= mk; ed &= mk; }
-                                if (eu && !seen) { f1 = i + (uint32_t)__ffs((int)eu) - 1u; seen = true; }
-                                if (ed) h = i + 32u - (uint32_t)__clz((int)ed);          // k = bit + 1
-                            }
-                            done = !(f1 >= p2) && !(h <= p1);
-                        }
-                        score -= 3 * (int)mism;
-                    } else if (w > lq && w - lq <= 64) {
-                        for (uint32_t d = 0; d + lq <= w && !done; d++) {
-                            bool all = true;
-                            for (uint32_t i = 0; i < lq && all; i += 32) {
-                                const uint4 q4 = planes4(qp, qo + i), w4 = planes4(wp, (uint64_t)wo + d + i);
-                                uint32_t e = (q4.x ^ w4.x) | (q4.y ^ w4.y);
-                                if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
-                                all = e == 0;
-                            }
-                            done = all;
-                        }
-                    }
-                    if (!done) { io.c_status[c] = CS_PENDING; route = 2; }
-                    else {
-                        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
-                        int p = (int)io.cig_stride, len = 0;
-                        cig_emit(slot, p, len, lq, 'M');
-                        io.c_score[c] = score;
-                        io.c_ciglen[c] = (uint32_t)len;
-                        io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+        // quad-uniform from here on: the four lanes of a quad hold the same candidate
+        const bool have = c < n_items;
+        const uint32_t lq = have ? io.c_qlen[c] : 0u, w = have ? io.c_wlen[c] : 0u;
+        const int64_t wo = have ? io.c_woff[c] : 0;
+        const uint64_t qo = have ? io.c_qoff[c] : 0;
+        const bool oor = wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0;
+        const bool live = have && !oor;
+        if (have && oor && ql == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
+        const bool square = w == lq;
+        // one pass over read and window: bases outside ACGT anywhere, and (square window) the mismatches of the diagonal
+        uint32_t bad = 0, mism = 0, p1 = 0xffffffffu, p2 = 0;
+        const uint32_t lqmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live ? lq : 0u));
+        for (uint32_t i0 = 0; i0 < lqmax; i0 += 128) {                      // wave-uniform trip count, DPP inside
+            const uint32_t i = i0 + 32u * (uint32_t)ql;
+            const uint4 q4 = quad_planes4(qp, live ? qo + i0 : 0, ql);
+            const uint4 w4 = quad_planes4(wp, live && square ? (uint64_t)wo + i0 : 0, ql);
+            if (live && i < lq) {
+                const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
+                bad |= (q4.z | q4.w) & mk;
+                if (square) {
+                    bad |= (w4.z | w4.w) & mk;
+                    const uint32_t e = ((q4.x ^ w4.x) | (q4.y ^ w4.y)) & mk;
+                    if (e) {
+                        const uint32_t f = i + (uint32_t)__ffs((int)e) - 1u, l = i + 31u - (uint32_t)__clz((int)e);
+                        p1 = f < p1 ? f : p1; p2 = l > p2 ? l : p2;
+                        mism += __popc(e);
                     }
                 }
             }
         }
+        const uint32_t wmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live && !square ? w : 0u));
+        for (uint32_t i0 = 0; i0 < wmax; i0 += 128) {
+            const uint32_t i = i0 + 32u * (uint32_t)ql;
+            const uint4 w4 = quad_planes4(wp, live && !square ? (uint64_t)wo + i0 : 0, ql);
+            if (live && !square && i < w) {
+                const uint32_t mk = w - i < 32 ? (1u << (w - i)) - 1u : 0xffffffffu;
+                bad |= (w4.z | w4.w) & mk;
+            }
+        }
+        bad = quad_or(bad); mism = quad_sum(mism); p1 = quad_min(p1); p2 = quad_max(p2);
+        bool done = false;
+        int score = 2 * (int)lq;
+        const bool clean = live && !bad;
+        if (live && bad) { if (ql == 0) io.c_status[c] = CS_NEED_FP; route = 1; }
+        // square window: one full diagonal with m mismatches at p1 <= p2, score 2*Lq - 3m.  Every other path
+        // into a diagonal cell or into the last row holds u >= 1 insertions, and a run of g gap steps costs
+        // g + 1: u >= 2 loses >= 7, u = 1 loses >= 4.  m <= 1 (loss <= 3): the diagonal is the unique optimum.
+        // m = 2 (loss 6): only two kinds of path can reach it -- one insertion and otherwise all matches:
+        //   (a) into a diagonal cell past p2: start one column in, ride diagonal +1 (q[k] = r[k+1]) for every
+        //       k < t, insert q[t], t >= p2: exists iff the first f1 = #leading matches on diagonal +1 >= p2;
+        //   (b) into the last row at column Lq-1 (a tie there would be the LEFTMOST maximum): main diagonal
+        //       for k < t <= p1, insert q[t], then diagonal -1 (q[k] = r[k-1]) for every k > t: exists iff
+        //       the highest mismatch on diagonal -1 sits at h <= p1.
+        // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
+        // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
+        if (clean && square) { done = mism <= 1 && lq >= 8; score -= 3 * (int)mism; }
+        const bool two = clean && square && mism == 2 && lq >= 8;
+        if (__ballot(two)) {
+            // diagonals +1 and -1 hold Lq-1 pairs each: bit k of e_up = (q[k] != r[k+1]), of e_dn = (q[k+1] != r[k])
+            uint32_t f1 = 0xffffffffu, h = 0;
+            const uint32_t lm = __builtin_amdgcn_readfirstlane((int)wave_max_u32(two ? lq : 0u));
+            for (uint32_t i0 = 0; i0 + 1 < lm; i0 += 128) {
+                const uint32_t i = i0 + 32u * (uint32_t)ql;
+                const uint4 q0 = quad_planes4(qp, two ? qo + i0 : 0, ql), q1 = quad_planes4(qp, two ? qo + 1 + i0 : 0, ql);
+                const uint4 w0 = quad_planes4(wp, two ? (uint64_t)wo + i0 : 0, ql), w1 = quad_planes4(wp, two ? (uint64_t)wo + 1 + i0 : 0, ql);
+                if (two && i + 1 < lq) {
+                    uint32_t eu = (q0.x ^ w1.x) | (q0.y ^ w1.y), ed = (q1.x ^ w0.x) | (q1.y ^ w0.y);
+                    if (lq - 1 - i < 32) { const uint32_t mk = (1u << (lq - 1 - i)) - 1u; eu &= mk; ed &= mk; }
+                    if (eu) { const uint32_t f = i + (uint32_t)__ffs((int)eu) - 1u; f1 = f < f1 ? f : f1; }
+                    if (ed) { const uint32_t l = i + 32u - (uint32_t)__clz((int)ed); h = l > h ? l : h; }   // k = bit + 1
+                }
+            }
+            f1 = quad_min(f1); h = quad_max(h);
+            if (f1 == 0xffffffffu) f1 = lq - 1;
+            if (two) done = !(f1 >= p2) && !(h <= p1);
+        }
+        const bool slide = clean && !square && w > lq && w - lq <= 64;
+        if (__ballot(slide)) {
+            // exact match on some diagonal d = 0 .. W - Lq: lane q tries d = q, q+4, ... on its own (most diagonals fail in
+            // their first 32 bases); any hit settles the candidate -- {2Lq, "<Lq>M"} does not depend on which
+            uint32_t hit = 0;
+            if (slide)
+                for (uint32_t d = (uint32_t)ql; d + lq <= w && !hit; d += 4) {
+                    bool all = true;
+                    for (uint32_t i = 0; i < lq && all; i += 32) {
+                        const uint4 q4 = planes4(qp, qo + i), w4 = planes4(wp, (uint64_t)wo + d + i);
+                        uint32_t e = (q4.x ^ w4.x) | (q4.y ^ w4.y);
+                        if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                        all = e == 0;
+                    }
+                    if (all) hit = 1;
+                }
+            hit = quad_or(hit);
+            if (slide) done = hit != 0;
+        }
+        if (clean) {
+            if (!done) { if (ql == 0) io.c_status[c] = CS_PENDING; route = 2; }
+            else if (ql == 0) {
+                uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+                int p = (int)io.cig_stride, len = 0;
+                cig_emit(slot, p, len, lq, 'M');
+                io.c_score[c] = score;
+                io.c_ciglen[c] = (uint32_t)len;
+                io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+            }
+        }
         // the two queues, staged in LDS (one atomic per 64 entries)
-        waveq_push(qfp, route == 1, c, io.fpq, &io.ctr->fp_count);
-        waveq_push(qdp, route == 2, c, io.dq, &io.ctr->dq_count);
+        waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
+        waveq_push(qdp, route == 2 && ql == 0, c, io.dq, &io.ctr->dq_count);
     }
     waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
     waveq_drain(qdp, io.dq, &io.ctr->dq_count);
