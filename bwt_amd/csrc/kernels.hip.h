@@ -1955,6 +1955,29 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
             uint32_t *const wlo = pl + h * set_words, *const whi = wlo + PW * 64, *const qlo = wlo + 2 * PW * 64,
                            *const qhi = wlo + (2 * PW + QW) * 64;
             unsigned long long badmask = 0;
+            if (io.qplanes && io.wplanes) {
+                // the bit-planes of reads and Ref1 exist already (interleaved, k_read_planes): every lane takes its own
+                // candidate's words with independent 16-byte loads -- one memory latency for the whole prologue instead of a
+                // dependent round per candidate
+                if (state[h] == 0) {
+                    uint32_t bad = 0;
+                    for (uint32_t wd = 0; wd < PW; wd++) {
+                        if (32 * wd >= w[h]) break;
+                        const uint4 v = planes4(io.wplanes, (uint64_t)wo[h] + 32ull * wd);
+                        const uint32_t mk = w[h] - 32 * wd < 32 ? (1u << (w[h] - 32 * wd)) - 1u : 0xffffffffu;
+                        wlo[wd * 64 + lane] = v.x & mk; whi[wd * 64 + lane] = v.y & mk;
+                        bad |= (v.z | v.w) & mk;
+                    }
+#pragma unroll
+                    for (uint32_t wd = 0; wd < (uint32_t)QW; wd++) {
+                        const uint4 v = planes4(io.qplanes, qo[h] + 32ull * wd);
+                        const uint32_t mk = (uint32_t)LQ - 32 * wd < 32 ? (1u << ((uint32_t)LQ - 32 * wd)) - 1u : 0xffffffffu;
+                        qlo[wd * 64 + lane] = v.x & mk; qhi[wd * 64 + lane] = v.y & mk;
+                        bad |= (v.z | v.w) & mk;
+                    }
+                    if (bad) state[h] = 4;
+                }
+            } else
             for (int k = 0; k < 64; k++) {
                 const uint32_t kw = __shfl(state[h] == 0 ? w[h] : 0u, k, 64);
                 if (kw == 0) continue;
