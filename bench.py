@@ -295,7 +295,8 @@ def main():
         models = {
             "fm_lookup": ("k_seed_tasks", counts["n_reads"] * (length + 16) + (64 if kwide else 8) * counts["n_lookups"]
                           + 4 * counts["n_tasks"] + int(16 * counts["n_tasks"] * unfused) + 8 * counts["n_clusters"]),
-            "fm_search": ("k_search", 128 * counts["lf_steps"] + (0 if "fm_lookup" in per else io_terms)),
+            "fm_search": ("k_search_pending" if "fm_lookup" in per else "k_search",
+                          128 * counts["lf_steps"] + (0 if "fm_lookup" in per else io_terms)),
             "cluster_small": ("k_cluster_small", 4 * counts["sa_reads"] + 16 * counts["n_tasks"] + 8 * counts["n_clusters"]),
         }
         roofs = {}
