@@ -306,6 +306,12 @@ def main():
                 roofs[key] = {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(kname), "bytes_per_launch": nbytes,
                               "avg_launch_ms": per[key], "share_of_step": kt[key]["ms"] / total_ms}
+        if "fm_lookup" in roofs:
+            # random 64-byte reads are rated per line (profiles/r1/rand_access_microbench.txt: 47-55 G lines/s on this part,
+            # 4..16 bytes used per line or all 64 alike): one table line per task
+            glines = counts["n_lookups"] / (per["fm_lookup"] / 1e3) / 1e9
+            roofs["fm_lookup"]["random_lines"] = {"achieved_Glines_per_s": glines, "measured_ceiling_Glines_per_s": 47.0,
+                                                  "frac": glines / 47.0}
         if "sw_extend" in per:
             dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
             ops_per_cell = 7.4 if "sw_trace_pk" in per else 9.4      # score-only pass / the traced DP run on the whole DP queue
