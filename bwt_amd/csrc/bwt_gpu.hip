@@ -513,7 +513,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
             return rc;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(cdiv(n, 64 / maxT), 4), (uint64_t)cus * 8);   // wave per 64/maxT reads
+        const uint64_t want = cdiv(cdiv(n, 64 / maxT), 4);                      // wave per 64/maxT reads
 #define SEED_ARGS b->ix->d, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT, b->t_def.as<uint32_t>(),                  \
                   b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),               \
                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),       \
@@ -527,9 +527,25 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         }
         b->fused = fuse;
         b->rows_kept = !(fuse && lean);
-        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), grid, 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
-        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), grid, 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0);
-        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), grid, 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
+        // persistent waves: as many blocks as are resident at once
+        auto resident = [&](const void *kern) {
+            static const void *seen[4] = {nullptr, nullptr, nullptr, nullptr};
+            static int occ[4] = {0, 0, 0, 0};
+            int per_cu = 0;
+            for (int i = 0; i < 4 && !per_cu; i++) {
+                if (seen[i] == kern) per_cu = occ[i];
+                else if (!seen[i]) {
+                    per_cu = 8;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
+                    seen[i] = kern; occ[i] = per_cu;
+                }
+            }
+            if (!per_cu) per_cu = 8;
+            return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * std::max(1, std::min(per_cu, 8))));
+        };
+        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident((const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
+        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident((const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0);
+        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident((const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
         KLAUNCH(b, "fm_search", k_search_pending, search_grid(b, T, false), 256, SEED_ARGS, b->ctr.as<Counters>());
 #undef SEED_ARGS
         b->counts_done = true;

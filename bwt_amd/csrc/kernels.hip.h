@@ -90,10 +90,12 @@ __device__ __forceinline__ uint32_t bitonic_stage(uint32_t p) {
     else if constexpr (J == 2) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
     else if constexpr (J <= 16) o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)p, (J << 10) | 0x1f);         // lane ^ J inside 32
     else o = (uint32_t)__shfl_xor((int)p, J, 64);
-    const uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
+    // keep the smaller of (p, o) where the stage's mask says so, else the larger: take the partner's value iff
+    // (p < o) differs from the mask bit -- one compare into a lane mask, a scalar xor, one select (called by whole waves)
     constexpr unsigned long long M = bitonic_keep_min<K, J>();
+    const unsigned long long take = __ballot(p < o) ^ M;
     uint32_t r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(mx), "v"(mn), "s"(M));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(o), "s"(take));
     return r;
 }
 template <int K, int J>
