@@ -301,6 +301,7 @@ struct bwt_batch {
     DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend, r_cl, smallq;
     bool counts_done = false;          // the search stage already totalled the reads (k_seed_tasks)
     uint32_t n_small = 0;
+    uint32_t ulen = 0;                 // common read length of the batch, 0 if the lengths differ
     bool rows_kept = true;             // every read's task-table rows were written (not so after a lean fused run)
     bool fused = false;                // ... and clustered what it could (r_K zeroed, RQ_DONE reads staged in r_cl)
     // reads
@@ -452,12 +453,13 @@ extern "C" int bwt_batch_kernel_times(bwt_batch *b, char *names, uint32_t names_
 extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n) {
     if (!b || (!bases && n) || !off) return fail(BWT_EINVAL, "bwt_batch_set_reads: null argument");
     HIPCHK(hipSetDevice(b->device));
-    uint32_t maxlq = 0;
+    uint32_t maxlq = 0, minlq = 0xffffffffu;
     for (uint32_t i = 0; i < n; i++) {
         if (off[i + 1] < off[i]) return fail(BWT_EINVAL, "bwt_batch_set_reads: offsets must be non-decreasing");
         uint64_t l = off[i + 1] - off[i];
         if (l > 65535) return fail(BWT_EINVAL, "bwt_batch_set_reads: read longer than 65535 bases");
         maxlq = std::max<uint32_t>(maxlq, (uint32_t)l);
+        minlq = std::min<uint32_t>(minlq, (uint32_t)l);
     }
     const uint64_t total = n ? off[n] - off[0] : 0;
     int rc;
@@ -469,6 +471,7 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
     HIPCHK(hipMemcpyAsync(b->off.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
+    b->ulen = (n && minlq == maxlq) ? maxlq : 0;       // every read the same length: offsets are r * ulen (no offset load in the seed kernel)
     b->total_bases = total;
     b->done = 0; b->n_cand = 0; b->n_hits = 0; b->cig_bytes = 0;
     return 0;
@@ -543,9 +546,9 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
             if (!per_cu) per_cu = 8;
             return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * std::max(1, std::min(per_cu, 8))));
         };
-        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident((const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
-        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident((const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0);
-        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident((const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0);
+        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident((const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u);
+        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident((const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen);
+        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident((const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen);
         KLAUNCH(b, "fm_search", k_search_pending, search_grid(b, T, false), 256, SEED_ARGS, b->ctr.as<Counters>());
 #undef SEED_ARGS
         b->counts_done = true;

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                                      uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                      uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                      uint32_t *__restrict__ mid4q, uint32_t *__restrict__ r_K,
-                                                     uint32_t *__restrict__ r_cl, Counters *ctr, int lean) {
+                                                     uint32_t *__restrict__ r_cl, Counters *ctr, int lean, uint32_t ulen) {
     __shared__ uint32_t lds_[FUSE ? 4 * 8 * CL_ROW : 1];
     __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
     ReadQ rq;
@@ -580,9 +580,10 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         int len = 0;
         bool nword = false;
         if (valid) {
-            P0 = off[r];
+            if (ulen) P0 = (uint64_t)r * ulen;                    // reads of one length: no offset load in front of the plane loads
+            else P0 = off[r];
             if (!RAW) {
-                len = (int)(off[r + 1] - P0);
+                len = ulen ? (int)ulen : (int)(off[r + 1] - P0);
                 const int i = 32 * (int)slot;
                 if (i < len) {
                     uint32_t w = plane_bits(planes, RP_N, P0 + (uint64_t)i);
