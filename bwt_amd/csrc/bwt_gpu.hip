@@ -549,7 +549,11 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident((const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u);
         else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident((const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen);
         else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident((const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen);
-        KLAUNCH(b, "fm_search", k_search_pending, search_grid(b, T, false), 256, SEED_ARGS, b->ctr.as<Counters>());
+        {
+            ProfScope ps(b, "fm_search");
+            hipLaunchKernelGGL(k_search_pending, dim3(search_grid(b, T, false)), dim3(256), (size_t)4 * 64 * maxT * 2, b->stream, SEED_ARGS,
+                               b->ctr.as<Counters>());
+        }
 #undef SEED_ARGS
         b->counts_done = true;
     } else {

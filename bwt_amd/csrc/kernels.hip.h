@@ -851,9 +851,10 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
     }
 }
 
-// k_search_pending: the LF steps the table left over.  A wave scans 64 reads' r_pend words at a time; reads with work
-// are handed to its 16 quads, each quad takes its read's pending tasks in turn (from the (Sp, Ep, n) k_seed_tasks
-// stored, two 16-byte-per-lane block loads per step as in k_search), then totals the read.  No queue, no atomics.
+// k_search_pending: the LF steps the table left over.  A wave scans 64 reads' r_pend words at a time and lists their
+// pending tasks in LDS ((read of the chunk) << 6 | slot); its 16 quads take the tasks 16 at a time -- QUAD PER TASK, from
+// the (Sp, Ep, n) k_seed_tasks stored, two 16-byte-per-lane block loads per step as in k_search -- and add what each
+// task found to its read's LDS accumulators; then one lane per read totals the read.  No global queue, no global atomics.
 __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint32_t *__restrict__ planes,
                                                          const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
                                                          const uint32_t *__restrict__ t_def, uint32_t *__restrict__ t_sp,
@@ -863,11 +864,15 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                                                          uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                          uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                          uint32_t *__restrict__ mid4q, Counters *ctr) {
-    __shared__ uint32_t slot_[4][64];
+    extern __shared__ uint16_t pend_list_[];                      // 4 waves x 64 reads x maxT pending tasks (dynamic)
+    __shared__ unsigned long long accP_[4][64];
+    __shared__ uint32_t accQ_[4][64];                             // qty | crash << 31
     __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
     ReadQ rq;
     readq_init(rq, rq_ + (threadIdx.x >> 6) * READQ_LDS_WORDS);
-    uint32_t *slot = slot_[threadIdx.x >> 6];
+    uint16_t *list = pend_list_ + (size_t)(threadIdx.x >> 6) * 64 * maxT;
+    unsigned long long *accP = accP_[threadIdx.x >> 6];
+    uint32_t *accQ = accQ_[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63;
     const int ql = (int)(lane & 3);
     const uint32_t qi = lane >> 2;
@@ -879,65 +884,72 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
     for (uint32_t chunk = wave; (uint64_t)chunk * 64 < n; chunk += nwaves) {
         const uint32_t rl = chunk * 64 + lane;
         const unsigned long long mine = rl < n ? r_pend[rl] : 0ull;
-        const unsigned long long bal = __ballot(mine != 0);
-        if (!bal) continue;
-        const uint32_t nwork = (uint32_t)__popcll(bal);
-        if (mine) slot[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+        if (!__ballot(mine != 0)) continue;
+        // task list: lane l's tasks at [excl_l, excl_l + popc(mine_l))
+        uint32_t cntl = (uint32_t)__popcll(mine), incl = cntl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += up; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        {
+            uint32_t w = incl - cntl;
+            for (unsigned long long mm = mine; mm; mm &= mm - 1ull) list[w++] = (uint16_t)((lane << 6) | (uint32_t)(__ffsll((long long)mm) - 1));
+        }
+        accP[lane] = 0; accQ[lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t b0 = 0; b0 < nwork; b0 += 16) {
-            const bool have = b0 + qi < nwork;
-            const uint32_t src = have ? slot[b0 + qi] : 0u;
-            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)src, 64);
-            unsigned long long m = have ? ((unsigned long long)hi << 32) | lo : 0ull;
-            const uint32_t r = chunk * 64 + src;
-            unsigned long long P = 0;
-            uint32_t qty = 0, crash = 0;
-            if (have) { P = r_P[r]; const uint32_t q0 = r_qty[r]; qty = q0 & 0x3fffffffu; crash = q0 >> 31; }
-            const uint64_t tb = (uint64_t)r * maxT;
-            const uint64_t P0 = have ? off[r] : 0;
-            while (__ballot(m != 0)) {                            // quads step their tasks side by side
-                LfTask t;
-                t.task = tb; t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
-                t.check_at_limit = true; t.check = true; t.active = false;
-                const bool work = m != 0;
-                if (work) {
-                    const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
-                    m &= m - 1ull;
-                    t.task = tb + k;
-                    const int e = (int)(t_def[t.task] & 0xffffu);
-                    task_init(t, ix, planes, P0 + (uint64_t)e, e);
-                    const uint32_t n0 = (t_info[t.task] >> 8) & 0xffu;
-                    if (n0 > 1) { t.sp = t_sp[t.task]; t.ep = t_ep[t.task]; t.n = (int)n0; t.active = t.n < t.nlim; }
-                }
-                while (__ballot(t.active)) {
-                    if (t.active) {
-                        const uint32_t b1 = (t.sp - 1) / BWT_BLOCK_ROWS, b2 = (t.ep - 1) / BWT_BLOCK_ROWS;
-                        const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql], v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
-                        const uint32_t bi = 15u - (uint32_t)t.n;
-                        steps++;
-                        if (!lf_step(ix, ql, dblk, v1, v2, b1, b2, (t.lo16 >> bi) & 1u, (t.hi16 >> bi) & 1u, t.sp, t.ep)) {
-                            t.check = false; t.active = false;
-                        } else {
-                            t.n++;
-                            if (t.n >= t.nlim) { t.check = t.check_at_limit; t.active = false; }
-                        }
+        for (uint32_t b0 = 0; b0 < total; b0 += 16) {             // wave-uniform; quads step their tasks side by side
+            const bool work = b0 + qi < total;
+            const uint32_t ent = work ? list[b0 + qi] : 0u;
+            const uint32_t rloc = ent >> 6, k = ent & 63u;
+            const uint32_t r = chunk * 64 + rloc;
+            LfTask t;
+            t.task = (uint64_t)r * maxT + k; t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
+            t.check_at_limit = true; t.check = true; t.active = false;
+            if (work) {
+                const int e = (int)(t_def[t.task] & 0xffffu);
+                task_init(t, ix, planes, off[r] + (uint64_t)e, e);
+                const uint32_t n0 = (t_info[t.task] >> 8) & 0xffu;
+                if (n0 > 1) { t.sp = t_sp[t.task]; t.ep = t_ep[t.task]; t.n = (int)n0; t.active = t.n < t.nlim; }
+            }
+            while (__ballot(t.active)) {
+                if (t.active) {
+                    const uint32_t b1 = (t.sp - 1) / BWT_BLOCK_ROWS, b2 = (t.ep - 1) / BWT_BLOCK_ROWS;
+                    const uint4 v1 = ix.blocks[(uint64_t)b1 * 4 + ql], v2 = ix.blocks[(uint64_t)b2 * 4 + ql];
+                    const uint32_t bi = 15u - (uint32_t)t.n;
+                    steps++;
+                    if (!lf_step(ix, ql, dblk, v1, v2, b1, b2, (t.lo16 >> bi) & 1u, (t.hi16 >> bi) & 1u, t.sp, t.ep)) {
+                        t.check = false; t.active = false;
+                    } else {
+                        t.n++;
+                        if (t.n >= t.nlim) { t.check = t.check_at_limit; t.active = false; }
                     }
-                }
-                if (work) {
-                    LfTask f = t;
-                    uint32_t status = f.status;
-                    if (status == TS_SEEDS) {
-                        if (f.n >= f.nlim && f.check) f.check = f.check_at_limit;
-                        if (f.check && f.ep - f.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
-                        else if (f.n < BWT_MIN_LEN) status = TS_NO_SEEDS;
-                    }
-                    const uint32_t c = status == TS_SEEDS ? f.ep - f.sp + 1 : 0;
-                    if (ql == 0) { t_sp[f.task] = f.sp; t_ep[f.task] = f.ep; t_info[f.task] = status | ((uint32_t)f.n << 8); t_cnt[f.task] = c; }
-                    if (status == TS_SEEDS) { qty++; P += c; }
-                    else if (status == TS_CRASH) crash = 1;
                 }
             }
-            read_finish(have && ql == 0, r, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall, rq);
+            if (work && ql == 0) {
+                uint32_t status = t.status;
+                if (status == TS_SEEDS) {
+                    if (t.n >= t.nlim && t.check) t.check = t.check_at_limit;
+                    if (t.check && t.ep - t.sp > BWT_MAX_RANGE) status = TS_TOO_MANY;
+                    else if (t.n < BWT_MIN_LEN) status = TS_NO_SEEDS;
+                }
+                const uint32_t c = status == TS_SEEDS ? t.ep - t.sp + 1 : 0;
+                t_sp[t.task] = t.sp; t_ep[t.task] = t.ep; t_info[t.task] = status | ((uint32_t)t.n << 8); t_cnt[t.task] = c;
+                if (status == TS_SEEDS) { atomicAdd(&accP[rloc], (unsigned long long)c); atomicAdd(&accQ[rloc], 1u); }
+                else if (status == TS_CRASH) atomicOr(&accQ[rloc], RQ_CRASH);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // one lane per read: what k_seed_tasks had already counted + what the steps added
+        {
+            const bool have = mine != 0;
+            unsigned long long P = 0;
+            uint32_t qty = 0, crash = 0;
+            if (have) {
+                const uint32_t q0 = r_qty[rl], a = accQ[lane];
+                P = (unsigned long long)r_P[rl] + accP[lane];
+                qty = (q0 & 0x1fffffffu) + (a & 0x7fffffffu);
+                crash = (q0 >> 31) | (a >> 31);
+            }
+            read_finish(have, rl, P, qty, crash, maxT, r_P, r_qty, bigq, mid2q, mid4q, ctr, Psum, nsmall, rq);
         }
         __builtin_amdgcn_wave_barrier();
     }
