@@ -362,6 +362,34 @@ def test_repeat_genome_all_cluster_paths():
     ix.close()
 
 
+def test_table_modes_agree_at_scale():
+    """The suffix-interval table is a cache of LF steps: whatever its depth, and whether or not its top level
+    carries SA values (the seed kernel then clusters the reads itself), every output of a batch must be the same.
+    20 M-row index, 300 000 reads of both lengths with substitutions, indels and N -- too many for the CPU oracle,
+    so the modes are held against each other (the step-by-step mode K = 0 is the one the oracle tests pin)."""
+    from bwt_amd import lib
+    rng = np.random.default_rng(41)
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20_000_000, dtype=np.uint8)].tobytes()
+    ix = lib.Index.build(ref, shift=1)
+    for length, nreads, seed in ((100, 200_000, 3), (150, 100_000, 4)):
+        reads = (synth_reads(ref, nreads // 2, length, seed, max_subs=2) +
+                 synth_reads(ref, nreads // 4, length, seed + 10, indel_frac=0.6, max_subs=2) +
+                 synth_reads(ref, nreads // 4, length, seed + 20, n_frac=0.3, iupac_frac=0.05))
+        bases, off = lib.pack_reads(reads)
+        base = None
+        for mode in ((0, 0), (13, 0), (15, 0), (15, 1)):
+            ix.set_ktable(*mode)
+            out = ix.align_batch(bases, off)
+            if base is None:
+                base = out
+                assert int(out["hit_off"][-1]) > nreads // 3
+                continue
+            for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+                assert np.array_equal(np.asarray(out[k]), np.asarray(base[k])), (mode, length, k)
+            assert bytes(out["cigar"]) == bytes(base["cigar"]), (mode, length)
+    ix.close()
+
+
 def test_prefilter_shortcuts_on_low_complexity_pairs():
     """The extend stage skips the DP when (a) the read matches a window diagonal exactly, or (b) the window
     is square (W = Lq) and its diagonal has at most one mismatch.  Adversarial inputs for both claims:
