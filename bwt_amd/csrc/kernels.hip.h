@@ -2,11 +2,15 @@
 //
 // Reference functions restated here (paths relative to /root/reference):
 //   k_subreads        sga:skip_Ns/1,4 + the sub-read chain of sga:sga/9      src/sga.erl:18-34,69-76
-//   k_search          bwa:find_seeds/6,/5 + fmi:se_down/se_up in Occ form     src/bwa.erl:12-45, src/fmi.erl:25-39
+//   lf_step, k_search, k_search_pending
+//                     bwa:find_seeds/6,/5 + fmi:se_down/se_up in Occ form     src/bwa.erl:12-45, src/fmi.erl:25-39
+//   kt_build          the same steps, once per k-mer (suffix-interval table)
+//   k_seed_tasks      sub-reads + table lookups (+ clustering) per read       src/sga.erl:17-64, src/bwa.erl:12-45
 //   k_seed_list       fmi:get_seed_ends/4,5                                   src/fmi.erl:89-100
 //   k_cluster_*       sga:add_seeds/3 + sga:get_similar/2,7                   src/sga.erl:37-64
 //   k_candidates      window slice of worker_loop(running,..)                 src/worker_bwt.erl:86-90
-//   k_sw<MODE,LDSB>   sw:sw/3, build_tab, add_row2tab, sigma, get_CIGAR       src/sw.erl:47-202
+//   k_sw_prefilter, k_sw_pk<LQ,TRACE>, k_sw_score, k_sw<MODE,LDSB>
+//                     sw:sw/3, build_tab, add_row2tab, sigma, get_CIGAR       src/sw.erl:47-202
 //   k_hits_*          the Cigars fold (order, Pos) of worker_loop             src/worker_bwt.erl:84-97
 #pragma once
 #include <hip/hip_runtime.h>
@@ -1899,7 +1903,7 @@ __global__ __launch_bounds__(256) void k_sw_score(SwIO io, uint32_t n_items, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sw_score_pk<LQ>: the extend stage's workhorse for the common read lengths.  The extend stage is
+// k_sw_pk<LQ, TRACE>: the extend stage's workhorse for the common read lengths.  The extend stage is
 // integer-VALU bound (SQ counters: VALU active ~95 % of the kernel at 4 cycles per wave64 op), so this
 // version halves the instruction count per cell:
 //   * TWO alignments per lane, cells packed as 2 x i16 (4V+code each) -> v_pk_add/mad/max/min_i16
