@@ -114,6 +114,19 @@ __device__ __forceinline__ uint32_t bitonic_sort_upto(uint32_t p) {
     return bitonic_merge<K, K / 2>(p);
 }
 __device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) { return bitonic_sort_upto<64>(p); }
+// two independent sorts side by side: each is a chain of 21 dependent stages (10 of them LDS round trips), interleaved
+// the swizzle latency of one hides behind the VALU work of the other
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge2(uint32_t &a, uint32_t &b) {
+    a = bitonic_stage<K, J>(a); b = bitonic_stage<K, J>(b);
+    if constexpr (J > 1) bitonic_merge2<K, J / 2>(a, b);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_sort_upto2(uint32_t &a, uint32_t &b) {
+    if constexpr (K > 2) bitonic_sort_upto2<K / 2>(a, b);
+    bitonic_merge2<K, K / 2>(a, b);
+}
+__device__ __forceinline__ void wave_sort2_u32(uint32_t &a, uint32_t &b) { bitonic_sort_upto2<64>(a, b); }
 
 // ------------------------------------------------------------------------------------------------
 // exclusive scan  u32 -> u64   (3 kernels: tile sums, scan of the sums, tile scans + offset: the input is read
@@ -525,6 +538,39 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
     if (active) { Psum += P; nsmall += (P > 0 && P <= 64 && maxT <= 64) ? 1u : 0u; }   // nsmall: reads k_cluster_small has to take
 }
 
+#define RQ_DONE 0x20000000u
+#define CL_STAGE 4
+#define CL_ROW 128                                            // most seeds of a read the seed kernel clusters itself
+// get_similar on one sorted lane-per-seed register (P <= 64) and the read's clusters into its staging row (descending
+// position order); more than CL_STAGE clusters: the read goes back to k_cluster_small.  Whole waves.
+__device__ __forceinline__ void cl_emit64(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t rj, uint32_t *__restrict__ r_cl,
+                                          uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
+                                          uint32_t &nsmall) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nthr = 2 + qj / 7;                     // sga.erl:46
+    const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
+    const bool vl = lane < Pj;
+    const bool start = vl && (lane == 0 || p - prev > BWT_TOLERANCE);
+    const bool end = vl && (lane == Pj - 1 || next - p > BWT_TOLERANCE);
+    const unsigned long long smask = __ballot(start);
+    const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
+    const uint32_t pfirst = __shfl(p, s_i, 64);
+    const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
+    const unsigned long long emask = __ballot(emit);
+    const uint32_t Kc = (uint32_t)__popcll(emask);
+    if (Kc <= CL_STAGE) {
+        if (emit) {
+            const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
+            r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = p;
+            r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = p - pfirst;
+        }
+        if (lane == 0) r_K[rj] = Kc;
+    } else if (lane == 0) {                               // more clusters than the staging row holds: k_cluster_small redoes it
+        r_P[rj] = Pj; r_qty[rj] = qj; nsmall++;
+    }
+}
+
 // k_seed_tasks: the seed stage with the suffix-interval table.  A wave takes 64 / maxT reads at a time, lane = one
 // task slot of one read (so the five task-table columns are written as contiguous runs):
 //   * the slot's sub-read (sga:sga/9 + skip_Ns, as k_subreads): a read without N has its k-th sub-read end at
@@ -539,9 +585,6 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 //     RQ_DONE: no SA gather, no second pass over the task table.  Everything else takes the cluster kernels.
 //     lean: the task-table rows of such reads are not written at all (nothing reads them; bwt_batch_fetch_tasks refuses).
 // RAW: one task per "read", already in t_def (bwt_find_seeds_batch).  1 <= maxT <= 64.
-#define RQ_DONE 0x20000000u
-#define CL_STAGE 4
-#define CL_ROW 128                                            // most seeds of a read the seed kernel clusters itself
 template <bool RAW, bool FUSE>
 __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t *__restrict__ planes,
                                                      const uint64_t *__restrict__ off, uint32_t n, uint32_t maxT,
@@ -764,44 +807,42 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
             if (leader && fuse_read) { r_P[r] = 0; r_qty[r] = qty | RQ_DONE; Psum += P; }   // r_P: seeds still to be clustered
             __builtin_amdgcn_wave_barrier();
             const unsigned long long bf = __ballot(leader && fuse_read);                   // bit seg0 of every read to cluster
-            for (uint32_t j = 0; j < rw; j++) {
-                if (!((bf >> (j * maxT)) & 1ull)) continue;                                  // wave-uniform
+            // reads of up to 64 seeds are sorted two at a time (two independent chains of stages), the rest one by one
+            uint32_t held = 0xffffffffu;                              // a read of <= 64 seeds waiting for its partner
+            for (uint32_t j = 0; j <= rw; j++) {
+                const bool last = j == rw;
+                if (!last && !((bf >> (j * maxT)) & 1ull)) continue;                          // wave-uniform
+                uint32_t Pj = 0, qj = 0;
+                if (!last) { Pj = (uint32_t)__shfl((int)(uint32_t)P, (int)(j * maxT), 64); qj = (uint32_t)__shfl((int)qty, (int)(j * maxT), 64); }
+                if (last || Pj <= 64) {
+                    if (!last && held == 0xffffffffu) { held = j; continue; }
+                    if (held == 0xffffffffu) continue;                // (last, nothing waiting)
+                    const uint32_t ja = held;
+                    const uint32_t Pa = (uint32_t)__shfl((int)(uint32_t)P, (int)(ja * maxT), 64), qa = (uint32_t)__shfl((int)qty, (int)(ja * maxT), 64);
+                    uint32_t pa = lane < Pa ? lp[ja * CL_ROW + lane] : 0xffffffffu;
+                    if (last) {
+                        pa = wave_sort_u32(pa);
+                        cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
+                    } else {
+                        uint32_t pb = lane < Pj ? lp[j * CL_ROW + lane] : 0xffffffffu;
+                        wave_sort2_u32(pa, pb);
+                        cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
+                        cl_emit64(pb, Pj, qj, g * rw + j, r_cl, r_K, r_P, r_qty, nsmall);
+                    }
+                    held = 0xffffffffu;
+                    continue;
+                }
                 const uint32_t rj = g * rw + j;
-                const uint32_t Pj = (uint32_t)__shfl((int)(uint32_t)P, (int)(j * maxT), 64), qj = (uint32_t)__shfl((int)qty, (int)(j * maxT), 64);
                 const uint32_t nthr = 2 + qj / 7;                     // sga.erl:46
                 uint32_t *row = lp + j * CL_ROW;
-                if (Pj <= 64) {
-                    uint32_t p = lane < Pj ? row[lane] : 0xffffffffu;
-                    p = wave_sort_u32(p);
-                    const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
-                    const bool vl = lane < Pj;
-                    const bool start = vl && (lane == 0 || p - prev > BWT_TOLERANCE);
-                    const bool end = vl && (lane == Pj - 1 || next - p > BWT_TOLERANCE);
-                    const unsigned long long smask = __ballot(start);
-                    const unsigned long long below = smask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-                    const int s_i = 63 - __clzll(below | 1ull);          // lane of this run's first element
-                    const uint32_t pfirst = __shfl(p, s_i, 64);
-                    const bool emit = end && (lane - (uint32_t)s_i + 1 >= nthr);
-                    const unsigned long long emask = __ballot(emit);
-                    const uint32_t Kc = (uint32_t)__popcll(emask);
-                    if (Kc <= CL_STAGE) {
-                        if (emit) {
-                            const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
-                            r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = p;
-                            r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = p - pfirst;
-                        }
-                        if (lane == 0) r_K[rj] = Kc;
-                    } else if (lane == 0) {                           // more clusters than the staging row holds: k_cluster_small redoes it
-                        r_P[rj] = Pj; r_qty[rj] = qj; nsmall++;
-                    }
-                } else {
+                {
                     // 65..128 seeds: two per lane (element e = 64 q + lane).  Both halves sorted, then element i meets element
                     // 127 - i (the smaller 64 stay in the low half), then each half -- bitonic now -- is merged.
                     uint32_t p0 = row[lane], p1 = lane + 64 < Pj ? row[64 + lane] : 0xffffffffu;
-                    p0 = wave_sort_u32(p0); p1 = wave_sort_u32(p1);
+                    wave_sort2_u32(p0, p1);
                     const uint32_t rv = (uint32_t)__shfl((int)p1, 63 - (int)lane, 64);
-                    const uint32_t lo = p0 < rv ? p0 : rv, hi = p0 < rv ? rv : p0;
-                    p0 = bitonic_merge<64, 32>(lo); p1 = bitonic_merge<64, 32>(hi);
+                    p1 = p0 < rv ? rv : p0; p0 = p0 < rv ? p0 : rv;
+                    bitonic_merge2<64, 32>(p0, p1);
                     __builtin_amdgcn_wave_barrier();
                     row[lane] = p0; row[64 + lane] = p1;
                     __builtin_amdgcn_wave_barrier();
