@@ -30,19 +30,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
     return v;
 }
-// queue append with ONE atomic per wave: the lanes whose `pred` holds get consecutive slots.
-// Must be reached by every active lane of the wave that could append in this iteration (the ballot covers
-// the currently active lanes only, so divergent callers still work: each divergent group does its own atomic).
-__device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (!m) return 0;
-    const uint32_t lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
 // A wave-private LDS staging buffer (128 u32) in front of a global queue: pushes gather in LDS and take queue space 64
 // entries at a time -- one same-address atomic per 64 entries instead of one per wave-iteration (they run at ~88 per us,
 // which a kernel that queues most of its items would spend tens of ms on).  push/drain are reached by whole waves.
