@@ -529,8 +529,8 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 #define CL_STAGE 4
 #define CL_ROW 128                                            // most seeds of a read the seed kernel clusters itself
 // get_similar on one sorted lane-per-seed register (P <= 64) and the read's clusters into its staging row (descending
-// position order); more than CL_STAGE clusters: the read goes back to k_cluster_small.  Whole waves.
-__device__ __forceinline__ void cl_emit64(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t rj, uint32_t *__restrict__ r_cl,
+// position order); more than CL_STAGE clusters: the read goes back to k_cluster_small (returns true).  Whole waves.
+__device__ __forceinline__ bool cl_emit64(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t rj, uint32_t *__restrict__ r_cl,
                                           uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                           uint32_t &nsmall) {
     const uint32_t lane = threadIdx.x & 63;
@@ -556,6 +556,7 @@ __device__ __forceinline__ void cl_emit64(uint32_t p, uint32_t Pj, uint32_t qj, 
     } else if (lane == 0) {                               // more clusters than the staging row holds: k_cluster_small redoes it
         r_P[rj] = Pj; r_qty[rj] = qj; nsmall++;
     }
+    return Kc > CL_STAGE;
 }
 
 // k_seed_tasks: the seed stage with the suffix-interval table.  A wave takes 64 / maxT reads at a time, lane = one
@@ -807,14 +808,20 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                     const uint32_t ja = held;
                     const uint32_t Pa = (uint32_t)__shfl((int)(uint32_t)P, (int)(ja * maxT), 64), qa = (uint32_t)__shfl((int)qty, (int)(ja * maxT), 64);
                     uint32_t pa = lane < Pa ? lp[ja * CL_ROW + lane] : 0xffffffffu;
+                    // a read that goes back to the cluster kernels needs its task-table rows after all (lean mode left them
+                    // out): its lanes still hold them
+                    bool fba, fbb = false;
                     if (last) {
                         pa = wave_sort_u32(pa);
-                        cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
+                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
                     } else {
                         uint32_t pb = lane < Pj ? lp[j * CL_ROW + lane] : 0xffffffffu;
                         wave_sort2_u32(pa, pb);
-                        cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
-                        cl_emit64(pb, Pj, qj, g * rw + j, r_cl, r_K, r_P, r_qty, nsmall);
+                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
+                        fbb = cl_emit64(pb, Pj, qj, g * rw + j, r_cl, r_K, r_P, r_qty, nsmall);
+                    }
+                    if (lean && valid && ((fba && lread == ja) || (fbb && lread == j))) {
+                        t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
                     }
                     held = 0xffffffffu;
                     continue;
@@ -867,6 +874,9 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                         }
                         if (lane == 0) r_K[rj] = Kc;
                     } else if (lane == 0) { r_P[rj] = Pj; r_qty[rj] = qj; }          // ... k_cluster_wave<2> redoes it
+                    if (Kc > CL_STAGE && lean && valid && lread == j) {                 // (its rows: see above)
+                        t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
+                    }
                     waveq_push(rq.m2, lane == 0 && Kc > CL_STAGE, rj, mid2q, &ctr->n_mid2);
                 }
             }

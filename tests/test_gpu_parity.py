@@ -362,6 +362,33 @@ def test_repeat_genome_all_cluster_paths():
     ix.close()
 
 
+@pytest.mark.parametrize("length", [64, 72, 96, 128, 200, 256, 511])
+def test_wide_table_read_lengths(gpu_index, orc_fm, ref_bytes, ktable_depth, length):
+    """The fused seed + cluster kernel packs 64 / maxT reads into a wave pass (maxT = length div 8 sub-reads per read):
+    8 reads of 64 bp down to one read of 511 bp, and 65..128 seeds per read for the longer ones."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    ktable_depth("15w")
+    ref1 = E.make_ref1(ref_bytes)
+    reads = synth_reads(ref_bytes, 60, length, 900 + length, max_subs=2) + \
+        synth_reads(ref_bytes, 20, length, 950 + length, n_frac=0.5, indel_frac=0.3)
+    bases, off = lib.pack_reads(reads)
+    out = gpu_index.align_batch(bases, off)
+    for i, q in enumerate(reads):
+        a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+        try:
+            exp = orc.align_read(orc_fm, ref1, q)
+        except RuntimeError:
+            assert out["read_status"][i] == -1 and a == b
+            continue
+        if exp is None:
+            assert out["read_status"][i] == 1 and a == b, (length, i)
+            continue
+        got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+                int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
+        assert got == exp, (length, i, q)
+
+
 def test_table_modes_agree_at_scale():
     """The suffix-interval table is a cache of LF steps: whatever its depth, and whether or not its top level
     carries SA values (the seed kernel then clusters the reads itself), every output of a batch must be the same.
