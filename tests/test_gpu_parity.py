@@ -362,16 +362,17 @@ def test_repeat_genome_all_cluster_paths():
     ix.close()
 
 
-@pytest.mark.parametrize("length", [64, 72, 96, 128, 200, 256, 511])
+@pytest.mark.parametrize("length", [16, 40, 64, 72, 96, 128, 200, 256, 511])
 def test_wide_table_read_lengths(gpu_index, orc_fm, ref_bytes, ktable_depth, length):
     """The fused seed + cluster kernel packs 64 / maxT reads into a wave pass (maxT = length div 8 sub-reads per read):
-    8 reads of 64 bp down to one read of 511 bp, and 65..128 seeds per read for the longer ones."""
+    8 reads of 64 bp down to one read of 511 bp, and 65..128 seeds per read for the longer ones; reads shorter than
+    64 bp (fewer than 8 sub-reads) take the table but the separate cluster kernels."""
     from bwt_amd import lib
     from oracle import orc, erl_literal as E
     ktable_depth("15w")
     ref1 = E.make_ref1(ref_bytes)
     reads = synth_reads(ref_bytes, 60, length, 900 + length, max_subs=2) + \
-        synth_reads(ref_bytes, 20, length, 950 + length, n_frac=0.5, indel_frac=0.3)
+        synth_reads(ref_bytes, 20, length, 950 + length, n_frac=0.5, indel_frac=0.3 if length >= 32 else 0.0)
     bases, off = lib.pack_reads(reads)
     out = gpu_index.align_batch(bases, off)
     for i, q in enumerate(reads):
@@ -404,7 +405,7 @@ def test_table_modes_agree_at_scale():
                  synth_reads(ref, nreads // 4, length, seed + 20, n_frac=0.3, iupac_frac=0.05))
         bases, off = lib.pack_reads(reads)
         base = None
-        for mode in ((0, 0), (13, 0), (15, 0), (15, 1)):
+        for mode in ((0, 0), (13, 0), (12, 1), (15, 0), (15, 1)):
             ix.set_ktable(*mode)
             out = ix.align_batch(bases, off)
             if base is None:
@@ -414,6 +415,43 @@ def test_table_modes_agree_at_scale():
             for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
                 assert np.array_equal(np.asarray(out[k]), np.asarray(base[k])), (mode, length, k)
             assert bytes(out["cigar"]) == bytes(base["cigar"]), (mode, length)
+    ix.close()
+
+
+def test_table_modes_agree_on_repeats():
+    """Same property on a genome full of repeats (copies of segments, tandem repeats, homopolymer runs): reads with
+    hundreds of seeds and many clusters, i.e. every fall-back out of the fused seed kernel (more clusters than its
+    staging row, more than 128 seeds, ranges that do not come with the table entry) under the lean single-call run."""
+    from bwt_amd import lib
+    rng = np.random.default_rng(77)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 1_500_000, dtype=np.uint8)].tobytes())
+    for _ in range(300):                                   # copies of 200..600 bp segments, 2..15 times
+        L = int(rng.integers(200, 600)); src = int(rng.integers(0, len(g) - L))
+        seg = bytes(g[src:src + L])
+        for _ in range(int(rng.integers(2, 16))):
+            d = int(rng.integers(0, len(g) - L)); g[d:d + L] = seg
+    for _ in range(200):                                   # tandem repeats and homopolymers
+        L = int(rng.integers(50, 300)); d = int(rng.integers(0, len(g) - L))
+        unit = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 7))).tolist())
+        g[d:d + L] = (unit * (L // len(unit) + 1))[:L]
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=1)
+    for length in (100, 150):
+        reads = synth_reads(ref, 30_000, length, 5 + length, max_subs=2) + \
+            synth_reads(ref, 10_000, length, 6 + length, indel_frac=0.5, n_frac=0.1)
+        bases, off = lib.pack_reads(reads)
+        base = None
+        for mode in ((0, 0), (12, 0), (15, 0), (15, 1)):
+            ix.set_ktable(*mode)
+            out = ix.align_batch(bases, off)
+            if base is None:
+                base = out
+                continue
+            for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+                assert np.array_equal(np.asarray(out[k]), np.asarray(base[k])), (mode, length, k)
+            assert bytes(out["cigar"]) == bytes(base["cigar"]), (mode, length)
+        nh = np.diff(np.asarray(base["hit_off"]).astype(np.int64))
+        assert (nh > 4).sum() > 100                       # reads with more hits than the staging row holds
     ix.close()
 
 
