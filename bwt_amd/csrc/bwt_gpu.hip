@@ -626,7 +626,7 @@ static int stage_cluster(bwt_batch *b) {
             unsigned int *cnt = &b->ctr.as<Counters>()->n_small;           // recounted by the listing kernel
             HIPCHK(hipMemsetAsync(cnt, 0, 4, b->stream));
             KLAUNCH(b, "cluster_small", k_collect_small, std::min<uint32_t>(cdiv(n, 256), 256), 256, n, b->r_P.as<uint32_t>(),
-                    b->r_qty.as<uint32_t>(), b->smallq.as<uint32_t>(), cnt);
+                    b->r_qty.as<uint32_t>(), b->smallq.as<uint32_t>(), cnt, b->hctr.n_small, b->ctr.as<Counters>());
             KLAUNCH(b, "cluster_small", k_cluster_small, cdiv((uint64_t)b->hctr.n_small * 64, 256), 256, b->ix->d, b->hctr.n_small, maxT,
                     b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                     b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
@@ -655,7 +655,8 @@ static int stage_cluster(bwt_batch *b) {
     if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
     uint64_t ncand = 0;
     HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));                                   // sync #2
+    if ((rc = fetch_counters(b))) return rc;                                   // sync #2
+    if (b->hctr.err_flags & 8) return fail(BWT_EHIP, "internal: cluster queue count mismatch");
     if (ncand > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 candidates: split it");
     b->n_cand = ncand;
     const size_t nc = (size_t)ncand + 1;

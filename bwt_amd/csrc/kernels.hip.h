@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_read_counts(uint32_t n, uint32_t maxT, 
 // (same-address atomics run at ~88 per us: one per wave-iteration would cost more than the clustering).
 __global__ __launch_bounds__(256) void k_collect_small(uint32_t n, const uint32_t *__restrict__ r_P,
                                                         const uint32_t *__restrict__ r_qty, uint32_t *__restrict__ queue,
-                                                        unsigned int *count) {
+                                                        unsigned int *count, uint32_t cap, Counters *ctr) {
     __shared__ uint32_t buf_[4][128];
     uint32_t *buf = buf_[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63;
@@ -1079,7 +1079,8 @@ __global__ __launch_bounds__(256) void k_collect_small(uint32_t n, const uint32_
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(count, nout);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (lane < nout) queue[base + lane] = buf[lane];
+            if (lane < nout && base + lane < cap) queue[base + lane] = buf[lane];
+            if (lane == 0 && base + nout > cap) atomicOr(&ctr->err_flags, 8ull);      // more reads than were counted: never expected
             const uint32_t rest = lane + 64 < have ? buf[lane + 64] : 0u;
             __builtin_amdgcn_wave_barrier();
             if (lane + 64 < have) buf[lane] = rest;
