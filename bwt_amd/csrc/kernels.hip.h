@@ -1697,8 +1697,9 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
         const uint32_t lqmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live ? lq : 0u));
         for (uint32_t i0 = 0; i0 < lqmax; i0 += 128) {                      // wave-uniform trip count, DPP inside
             const uint32_t i = i0 + 32u * (uint32_t)ql;
-            const uint4 q4 = quad_planes4(qp, live ? qo + i0 : 0, ql);
-            const uint4 w4 = quad_planes4(wp, live && square ? (uint64_t)wo + i0 : 0, ql);
+            const bool in = live && i0 < lq;                               // (a shorter read of the wave: stay inside its planes)
+            const uint4 q4 = quad_planes4(qp, in ? qo + i0 : 0, ql);
+            const uint4 w4 = quad_planes4(wp, in && square ? (uint64_t)wo + i0 : 0, ql);
             if (live && i < lq) {
                 const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
                 bad |= (q4.z | q4.w) & mk;
@@ -1716,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
         const uint32_t wmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live && !square ? w : 0u));
         for (uint32_t i0 = 0; i0 < wmax; i0 += 128) {
             const uint32_t i = i0 + 32u * (uint32_t)ql;
-            const uint4 w4 = quad_planes4(wp, live && !square ? (uint64_t)wo + i0 : 0, ql);
+            const uint4 w4 = quad_planes4(wp, live && !square && i0 < w ? (uint64_t)wo + i0 : 0, ql);
             if (live && !square && i < w) {
                 const uint32_t mk = w - i < 32 ? (1u << (w - i)) - 1u : 0xffffffffu;
                 bad |= (w4.z | w4.w) & mk;
@@ -1746,8 +1747,9 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
             const uint32_t lm = __builtin_amdgcn_readfirstlane((int)wave_max_u32(two ? lq : 0u));
             for (uint32_t i0 = 0; i0 + 1 < lm; i0 += 128) {
                 const uint32_t i = i0 + 32u * (uint32_t)ql;
-                const uint4 q0 = quad_planes4(qp, two ? qo + i0 : 0, ql), q1 = quad_planes4(qp, two ? qo + 1 + i0 : 0, ql);
-                const uint4 w0 = quad_planes4(wp, two ? (uint64_t)wo + i0 : 0, ql), w1 = quad_planes4(wp, two ? (uint64_t)wo + 1 + i0 : 0, ql);
+                const bool in = two && i0 + 1 < lq;
+                const uint4 q0 = quad_planes4(qp, in ? qo + i0 : 0, ql), q1 = quad_planes4(qp, in ? qo + 1 + i0 : 0, ql);
+                const uint4 w0 = quad_planes4(wp, in ? (uint64_t)wo + i0 : 0, ql), w1 = quad_planes4(wp, in ? (uint64_t)wo + 1 + i0 : 0, ql);
                 if (two && i + 1 < lq) {
                     uint32_t eu = (q0.x ^ w1.x) | (q0.y ^ w1.y), ed = (q1.x ^ w0.x) | (q1.y ^ w0.y);
                     if (lq - 1 - i < 32) { const uint32_t mk = (1u << (lq - 1 - i)) - 1u; eu &= mk; ed &= mk; }
