@@ -1657,7 +1657,7 @@ __device__ __forceinline__ uint32_t quad_max(uint32_t v) {
 }
 // all four planes of the 32 bases from bit position pos + 32 * ql (ql = lane in quad): word ql of the run that starts at
 // pos's word, completed by the next lane's word
-__device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ planes, uint64_t pos, int ql) {
+__device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ planes, uint64_t pos, int ql, uint32_t &lo1, uint32_t &hi1) {
     const uint64_t w = (pos >> 5) + (uint64_t)ql;
     const uint32_t sh = (uint32_t)pos & 31u;
     const uint4 a = ((const uint4 *)planes)[w];
@@ -1670,7 +1670,14 @@ __device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ plane
     uint4 r;
     r.x = __builtin_amdgcn_alignbit(b.x, a.x, sh); r.y = __builtin_amdgcn_alignbit(b.y, a.y, sh);
     r.z = __builtin_amdgcn_alignbit(b.z, a.z, sh); r.w = __builtin_amdgcn_alignbit(b.w, a.w, sh);
+    // the code planes one base further on (the same two words: no second load for the neighbouring diagonal)
+    lo1 = sh == 31 ? b.x : __builtin_amdgcn_alignbit(b.x, a.x, sh + 1);
+    hi1 = sh == 31 ? b.y : __builtin_amdgcn_alignbit(b.y, a.y, sh + 1);
     return r;
+}
+__device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ planes, uint64_t pos, int ql) {
+    uint32_t lo1, hi1;
+    return quad_planes4(planes, pos, ql, lo1, hi1);
 }
 __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
     __shared__ uint32_t wq_[4][2][128];
@@ -1693,13 +1700,16 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
         if (have && oor && ql == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
         const bool square = w == lq;
         // one pass over read and window: bases outside ACGT anywhere, and (square window) the mismatches of the diagonal
-        uint32_t bad = 0, mism = 0, p1 = 0xffffffffu, p2 = 0;
+        // (square window) also the first mismatch f1 of diagonal +1 (q[k] against r[k+1]) and the last one, h, of diagonal -1
+        // (q[k+1] against r[k]): the two-mismatch case below needs them, and they come out of the words loaded here
+        uint32_t bad = 0, mism = 0, p1 = 0xffffffffu, p2 = 0, f1 = 0xffffffffu, h = 0;
         const uint32_t lqmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live ? lq : 0u));
         for (uint32_t i0 = 0; i0 < lqmax; i0 += 128) {                      // wave-uniform trip count, DPP inside
             const uint32_t i = i0 + 32u * (uint32_t)ql;
             const bool in = live && i0 < lq;                               // (a shorter read of the wave: stay inside its planes)
-            const uint4 q4 = quad_planes4(qp, in ? qo + i0 : 0, ql);
-            const uint4 w4 = quad_planes4(wp, in && square ? (uint64_t)wo + i0 : 0, ql);
+            uint32_t qlo1, qhi1, wlo1, whi1;
+            const uint4 q4 = quad_planes4(qp, in ? qo + i0 : 0, ql, qlo1, qhi1);
+            const uint4 w4 = quad_planes4(wp, in && square ? (uint64_t)wo + i0 : 0, ql, wlo1, whi1);
             if (live && i < lq) {
                 const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
                 bad |= (q4.z | q4.w) & mk;
@@ -1710,6 +1720,12 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
                         const uint32_t f = i + (uint32_t)__ffs((int)e) - 1u, l = i + 31u - (uint32_t)__clz((int)e);
                         p1 = f < p1 ? f : p1; p2 = l > p2 ? l : p2;
                         mism += __popc(e);
+                    }
+                    if (i + 1 < lq) {                                       // the Lq-1 pairs of the neighbouring diagonals
+                        const uint32_t mk1 = lq - 1 - i < 32 ? (1u << (lq - 1 - i)) - 1u : 0xffffffffu;
+                        const uint32_t eu = ((q4.x ^ wlo1) | (q4.y ^ whi1)) & mk1, ed = ((qlo1 ^ w4.x) | (qhi1 ^ w4.y)) & mk1;
+                        if (eu) { const uint32_t f = i + (uint32_t)__ffs((int)eu) - 1u; f1 = f < f1 ? f : f1; }
+                        if (ed) { const uint32_t l = i + 32u - (uint32_t)__clz((int)ed); h = l > h ? l : h; }   // k = bit + 1
                     }
                 }
             }
@@ -1740,26 +1756,10 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
         // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
         // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
         if (clean && square) { done = mism <= 1 && lq >= 8; score -= 3 * (int)mism; }
-        const bool two = clean && square && mism == 2 && lq >= 8;
-        if (__ballot(two)) {
-            // diagonals +1 and -1 hold Lq-1 pairs each: bit k of e_up = (q[k] != r[k+1]), of e_dn = (q[k+1] != r[k])
-            uint32_t f1 = 0xffffffffu, h = 0;
-            const uint32_t lm = __builtin_amdgcn_readfirstlane((int)wave_max_u32(two ? lq : 0u));
-            for (uint32_t i0 = 0; i0 + 1 < lm; i0 += 128) {
-                const uint32_t i = i0 + 32u * (uint32_t)ql;
-                const bool in = two && i0 + 1 < lq;
-                const uint4 q0 = quad_planes4(qp, in ? qo + i0 : 0, ql), q1 = quad_planes4(qp, in ? qo + 1 + i0 : 0, ql);
-                const uint4 w0 = quad_planes4(wp, in ? (uint64_t)wo + i0 : 0, ql), w1 = quad_planes4(wp, in ? (uint64_t)wo + 1 + i0 : 0, ql);
-                if (two && i + 1 < lq) {
-                    uint32_t eu = (q0.x ^ w1.x) | (q0.y ^ w1.y), ed = (q1.x ^ w0.x) | (q1.y ^ w0.y);
-                    if (lq - 1 - i < 32) { const uint32_t mk = (1u << (lq - 1 - i)) - 1u; eu &= mk; ed &= mk; }
-                    if (eu) { const uint32_t f = i + (uint32_t)__ffs((int)eu) - 1u; f1 = f < f1 ? f : f1; }
-                    if (ed) { const uint32_t l = i + 32u - (uint32_t)__clz((int)ed); h = l > h ? l : h; }   // k = bit + 1
-                }
-            }
+        if (clean && square && mism == 2 && lq >= 8) {
             f1 = quad_min(f1); h = quad_max(h);
             if (f1 == 0xffffffffu) f1 = lq - 1;
-            if (two) done = !(f1 >= p2) && !(h <= p1);
+            done = !(f1 >= p2) && !(h <= p1);
         }
         const bool slide = clean && !square && w > lq && w - lq <= 64;
         if (__ballot(slide)) {
