@@ -316,7 +316,8 @@ def main():
             dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
             ops_per_cell = 7.4 if "sw_trace_pk" in per else 9.4      # score-only pass / the traced DP run on the whole DP queue
             ops = dp_cells * ops_per_cell / (per["sw_extend"] / 1e3) / 1e12
-            roofs["sw_extend"] = {"kernel": "k_sw_pk", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS,
+            roofs["sw_extend"] = {"kernel": "k_sw_wave (short DP queue: latency, not throughput)" if counts["n_dp"] <= 32768 else "k_sw_pk",
+                                  "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS,
                                   "unit": "Tlane-op/s", "frac": ops / VALU_PEAK_TOPS, "traffic": traffic.get("k_sw"),
                                   "cells_per_launch": dp_cells, "valu_lane_ops_per_cell": ops_per_cell, "avg_launch_ms": per["sw_extend"],
                                   "share_of_step": kt["sw_extend"]["ms"] / total_ms}

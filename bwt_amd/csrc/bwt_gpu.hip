@@ -733,24 +733,33 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             ProfScope ps(b, "sw_extend");
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   (uint32_t *)nullptr, 0u);
+                                   (uint32_t *)nullptr, 0u, 0u);
             else
                 hipLaunchKernelGGL((k_sw_pk<150, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   (uint32_t *)nullptr, 0u);
+                                   (uint32_t *)nullptr, 0u, 0u);
         }
         // packed traceback pass over the alignments that are not the plain diagonal: per-wave direction slab
         const uint32_t ndg = (max_lq + 7) / 8, w1 = wcap + 1;
         const uint64_t per_wave_pk = (uint64_t)w1 * ndg * 64 * 4;
         uint32_t tblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (4ull << 30) / (per_wave_pk * 4)));
         if ((rc = b->slab_dir_pk.ensure((uint64_t)tblocks * 4 * per_wave_pk))) return rc;
+        // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
+        // lane-per-alignment work would run a handful of waves for the full serial length of a DP
+        const char *env_wv = getenv("BWT_SW_WAVE");               // experiments / tests: 0 = packed kernels only (read per call)
+        const uint32_t wv_dwords = (max_w >> 4) + 1, wv_w1 = max_w + 1;
+        const uint64_t wv_lds = ((uint64_t)wv_w1 + (uint64_t)max_lq * wv_dwords) * 4 * 4;        // 4 waves per block
+        const uint32_t wv_thresh = (trace_all && wv_lds <= 60 * 1024 && !(env_wv && env_wv[0] == '0')) ? 32768u : 0u;
         {
             ProfScope ps(b, trace_all ? "sw_extend" : "sw_trace_pk");
+            if (wv_thresh)
+                hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),
+                                   dim3(256), (size_t)wv_lds, b->stream, io, wv_thresh, wv_w1, wv_dwords, max_lq);
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   b->slab_dir_pk.as<uint32_t>(), w1);
+                                   b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
             else
                 hipLaunchKernelGGL((k_sw_pk<150, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   b->slab_dir_pk.as<uint32_t>(), w1);
+                                   b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
         }
     } else if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
         static const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");

@@ -1978,7 +1978,7 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
 //                alignments per dword, [column][row group][lane] in a per-wave HBM slab) and walks the traceback.
 template <int LQ, bool TRACE>
 __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32_t wcap, uint32_t *__restrict__ slab_dir,
-                                               uint32_t maxW1) {
+                                               uint32_t maxW1, uint32_t skip_upto) {
     constexpr int QW = (LQ + 31) / 32, NG = (LQ + 15) / 16, NDG = (LQ + 7) / 8;   // NDG: direction dwords per column
     extern __shared__ uint32_t lds_sw[];
     const uint32_t lane = threadIdx.x & 63;
@@ -1990,6 +1990,7 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 
     const uint32_t *const queue = TRACE ? io.tq2 : io.dq;
     if (TRACE) n_items = io.ctr->tq2_count; else if (io.dq) n_items = io.ctr->dq_count;
+    if (n_items <= skip_upto) return;                            // (a short queue: k_sw_wave took it)
     uint32_t *const dirs = TRACE ? slab_dir + (uint64_t)wave * maxW1 * NDG * 64 + lane : nullptr;   // [(j*NDG + g)*64]
     for (uint32_t g = wave; (uint64_t)g * 128 < n_items; g += nwaves) {
         uint32_t cc[2], lq[2], w[2];
@@ -2195,6 +2196,117 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
             io.c_ciglen[c] = (uint32_t)len;
             io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sw_wave: a WAVE per alignment, for DP queues too short to fill the chip with lane-per-alignment work (after the
+// prefilter a batch of clean reads leaves a few hundred candidates: the packed kernels then run a handful of waves for
+// the full serial length of a DP, ~0.5 ms).  Same cells as k_sw (packed 4V + code, ties up_left > up > left, gap cost by
+// the neighbour's stored direction), evaluated along anti-diagonals: lane t owns query row i0 + t of a 64-row strip and
+// at step k the cell of column k - t; the value of the row above and the window base arrive from lane t - 1, the
+// boundary row between strips and the 2-bit directions (16 columns per word) live in LDS.  Traceback by lane 0.
+// Runs only when the DP queue holds at most `thresh` candidates (k_sw_pk takes the longer queues); the queue holds clean
+// ACGT candidates only (k_sw_prefilter filled it).
+__global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint32_t maxW1, uint32_t dwords, uint32_t max_lq) {
+    extern __shared__ uint32_t lds_wv[];
+    const uint32_t n_total = io.ctr->dq_count;
+    if (n_total == 0 || n_total > thresh) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t *bl = lds_wv + (size_t)(threadIdx.x >> 6) * (maxW1 + (size_t)max_lq * dwords);    // boundary row [j]
+    uint32_t *dirs = bl + maxW1;                                                                  // [row][j >> 4]
+    for (uint32_t item = wave; item < n_total; item += nwaves) {
+        const uint32_t c = io.dq[item];
+        const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
+        const int64_t wo = io.c_woff[c];
+        if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
+            if (lane == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
+            continue;
+        }
+        if (w + 1 > maxW1 || lq > max_lq) {                      // (sized by the batch maxima: not expected) -> generic trace kernel
+            if (lane == 0) { io.c_status[c] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c; }
+            continue;
+        }
+        const uint8_t *q = io.qbuf + io.c_qoff[c];
+        const uint8_t *rw = io.rbuf + wo;
+        for (uint32_t j = lane; j <= w; j += 64) bl[j] = DIR_UNDEF;           // row 0: {0, undef}
+        __builtin_amdgcn_wave_barrier();
+        int best = -(int)(lq + 1) * 4 + DIR_UP;                               // V(Lq, 0)
+        uint32_t bestj = 0;
+        const uint32_t ns = (lq + 63) / 64;
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t i0 = s * 64, i = i0 + lane;                         // 0-based query row of this lane
+            const bool rowok = i < lq;
+            const uint32_t qc = rowok ? q[i] : 0xffu;
+            int h = -(int)(i + 2) * 4 + DIR_UP;                                // column 0 of my row
+            // value of the row above at the column before mine (the diagonal input): column 0 of that row
+            int d = lane == 0 ? (s == 0 ? (int)DIR_UNDEF : -(int)(i0 + 1) * 4 + DIR_UP) : -(int)(i + 1) * 4 + DIR_UP;
+            uint32_t rc = 0, dirw = 0;
+            uint32_t wch = lane < w ? rw[lane] : 0u;                            // window bases 64 at a time, one per lane
+            for (uint32_t k = 1; k <= w + 63; k++) {
+                // lane 0 takes the next window base, the others inherit the base and the value of the lane above
+                const uint32_t kb = k - 1;
+                if (kb && (kb & 63u) == 0) wch = kb + lane < w ? rw[kb + lane] : 0u;
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)wch, (int)(kb & 63u));
+                const uint32_t rc_up = (uint32_t)__shfl_up((int)rc, 1, 64);
+                int u = __shfl_up(h, 1, 64);
+                rc = lane == 0 ? nb : rc_up;
+                const uint32_t j = k - lane;                                    // my column at this step
+                if (lane == 0) u = (int)bl[k <= w ? k : 0];
+                const bool on = rowok && j >= 1 && j <= w;
+                if (on) {
+                    const int sig = (qc == rc) ? 7 : -5;                        // 4*sigma - 1
+                    const int cd = (d | 3) + sig;                               // 4(Vul+sigma) + up_left
+                    const int cl = h + (int)(int8_t)(0xF5F6F7FCu >> ((h & 3) * 8));     // {-4,-9,-10,-11}
+                    const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));     // {-7,-4,-9,-10}
+                    int hn = cd > cl ? cd : cl;
+                    hn = hn > cu ? hn : cu;
+                    dirw |= (uint32_t)(hn & 3) << (2 * (j & 15u));
+                    if ((j & 15u) == 15u || j == w) { dirs[(size_t)i * dwords + (j >> 4)] = dirw; dirw = 0; }
+                    h = hn;
+                    if (lane == 63) bl[j] = (uint32_t)hn;                       // boundary row for the next strip
+                    if (i == lq - 1 && (hn >> 2) > (best >> 2)) { best = hn; bestj = j; }   // leftmost maximum of the last row
+                }
+                d = u;                                                          // the row above at my column: next step's diagonal
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int ll = (int)((lq - 1) & 63u);                                   // lane that owns the last row
+        best = __builtin_amdgcn_readlane(best, ll);
+        bestj = (uint32_t)__builtin_amdgcn_readlane((int)bestj, ll);
+        if (lane == 0) {
+            // sw.erl:69 after the last row: no_match iff RowMax < -2*(Lq div 2) + 2*Lq
+            const int thr = -2 * (int)(lq / 2) + 2 * (int)lq;
+            const int score = best >> 2;
+            if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; }
+            else {
+                uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+                int p = (int)io.cig_stride, len = 0;
+                // traceback (sw.erl:116-160): from the leftmost maximum of the last row up to row 0
+                uint32_t ti = lq, tj = bestj;
+                int runop = -1; uint32_t runlen = 0;
+                for (;;) {
+                    int code = -1;
+                    if (ti > 0) {
+                        if (tj == 0) code = DIR_UP;
+                        else code = (int)((dirs[(size_t)(ti - 1) * dwords + (tj >> 4)] >> (2 * (tj & 15u))) & 3u);
+                    }
+                    if (code == runop) { runlen++; }
+                    else {
+                        if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
+                        runop = code; runlen = 1;
+                    }
+                    if (code < 0) break;
+                    if (code == DIR_UL) { ti--; tj--; } else if (code == DIR_UP) ti--; else tj--;
+                }
+                io.c_score[c] = score;
+                io.c_ciglen[c] = (uint32_t)len;
+                io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -256,12 +256,15 @@ def test_bench_gather_path_single_rank():
     assert line["n_gpus"] == 1 and line["roofline"]["frac"] > 0
 
 
+@pytest.mark.parametrize("wave_dp", ["1", "0"])          # short DP queues: wave-per-alignment kernel / packed kernels
 @pytest.mark.parametrize("length", [100, 150])
-def test_align_uniform_length_fast_path(gpu_index, orc_fm, ref_bytes, length):
-    """Batches of one read length take the packed-i16 extend kernel (k_sw_score_pk<100|150>): substitutions
-    stay on it (diagonal shortcut), indels go through the trace pass, N goes to the fp64 pass."""
+def test_align_uniform_length_fast_path(gpu_index, orc_fm, ref_bytes, length, wave_dp, monkeypatch):
+    """Batches of one read length take the packed-i16 extend kernels (k_sw_pk<100|150>) or, for a short DP queue,
+    the wave-per-alignment kernel (k_sw_wave): substitutions are settled by the prefilter, indels run the traced DP,
+    N goes to the fp64 pass."""
     from bwt_amd import lib
     from oracle import orc, erl_literal as E
+    monkeypatch.setenv("BWT_SW_WAVE", wave_dp)
     ref1 = E.make_ref1(ref_bytes)
     reads = (synth_reads(ref_bytes, 1500, length, 61 + length, max_subs=3) +
              synth_reads(ref_bytes, 700, length, 62 + length, indel_frac=1.0) +
