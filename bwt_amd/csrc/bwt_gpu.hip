@@ -301,6 +301,7 @@ struct bwt_batch {
     DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend, r_cl, smallq;
     bool counts_done = false;          // the search stage already totalled the reads (k_seed_tasks)
     uint32_t n_small = 0;
+    uint32_t wave_upto = 0;            // DP queues up to this size went to k_sw_wave in the last extend stage
     uint32_t ulen = 0;                 // common read length of the batch, 0 if the lengths differ
     bool rows_kept = true;             // every read's task-table rows were written (not so after a lean fused run)
     bool fused = false;                // ... and clustered what it could (r_K zeroed, RQ_DONE reads staged in r_cl)
@@ -698,11 +699,25 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_status = b->c_status.as<int32_t>(); io.c_score = b->c_score.as<int32_t>();
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
-    io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes;
+    io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.wave_upto = 0;
     static const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
     if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
         io.dq = b->dq.as<uint32_t>();
         KLAUNCH(b, "sw_prefilter", k_sw_prefilter, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc);   // quad per candidate
+    }
+
+    // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
+    // lane-per-alignment work would run a handful of waves for the full serial length of a DP
+    const char *env_wv = getenv("BWT_SW_WAVE");                   // experiments / tests: 0 = lane-per-alignment kernels only (read per call)
+    const uint32_t wv_dwords = (max_w >> 4) + 1, wv_w1 = max_w + 1;
+    const uint64_t wv_lds = ((uint64_t)wv_w1 + (uint64_t)max_lq * wv_dwords) * 4 * 4;            // 4 waves per block
+    const uint32_t wv_thresh = (io.dq && wv_lds <= 60 * 1024 && !(env_wv && env_wv[0] == '0')) ? 32768u : 0u;
+    io.wave_upto = wv_thresh;
+    b->wave_upto = wv_thresh;
+    if (wv_thresh) {
+        ProfScope ps(b, "sw_extend");
+        hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),
+                           dim3(256), (size_t)wv_lds, b->stream, io, wv_thresh, wv_w1, wv_dwords, max_lq);
     }
 
     // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and
@@ -733,27 +748,18 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             ProfScope ps(b, "sw_extend");
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   (uint32_t *)nullptr, 0u, 0u);
+                                   (uint32_t *)nullptr, 0u, wv_thresh);
             else
                 hipLaunchKernelGGL((k_sw_pk<150, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   (uint32_t *)nullptr, 0u, 0u);
+                                   (uint32_t *)nullptr, 0u, wv_thresh);
         }
         // packed traceback pass over the alignments that are not the plain diagonal: per-wave direction slab
         const uint32_t ndg = (max_lq + 7) / 8, w1 = wcap + 1;
         const uint64_t per_wave_pk = (uint64_t)w1 * ndg * 64 * 4;
         uint32_t tblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (4ull << 30) / (per_wave_pk * 4)));
         if ((rc = b->slab_dir_pk.ensure((uint64_t)tblocks * 4 * per_wave_pk))) return rc;
-        // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
-        // lane-per-alignment work would run a handful of waves for the full serial length of a DP
-        const char *env_wv = getenv("BWT_SW_WAVE");               // experiments / tests: 0 = packed kernels only (read per call)
-        const uint32_t wv_dwords = (max_w >> 4) + 1, wv_w1 = max_w + 1;
-        const uint64_t wv_lds = ((uint64_t)wv_w1 + (uint64_t)max_lq * wv_dwords) * 4 * 4;        // 4 waves per block
-        const uint32_t wv_thresh = (trace_all && wv_lds <= 60 * 1024 && !(env_wv && env_wv[0] == '0')) ? 32768u : 0u;
         {
             ProfScope ps(b, trace_all ? "sw_extend" : "sw_trace_pk");
-            if (wv_thresh)
-                hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),
-                                   dim3(256), (size_t)wv_lds, b->stream, io, wv_thresh, wv_w1, wv_dwords, max_lq);
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
                                    b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
@@ -882,6 +888,8 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
         counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
         counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
+        // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
+        if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
         counts->n_dp = b->hctr.dq_count; counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
     }
     return 0;

@@ -1460,6 +1460,7 @@ struct SwIO {
     uint32_t *dq;              // queue of candidates that need the DP at all (filled by k_sw_prefilter)
     uint32_t *tq2;             // traceback queue of the packed kernels (same read length, window <= cap)
     const uint32_t *qplanes, *wplanes;   // bit-planes over qbuf / rbuf (k_read_planes layout)
+    uint32_t wave_upto;        // a DP queue of at most this many candidates is k_sw_wave's: the score kernels leave it alone
     Counters *ctr;
 };
 
@@ -1484,6 +1485,7 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
     double *bndv = FP ? slab_bndv + (uint64_t)wave * maxW1 * 64 + lane : nullptr;
     uint32_t *dirs = DIRS ? slab_dir + (uint64_t)wave * max_strips * maxW1 * 64 + lane : nullptr;  // [(s*maxW1+j)*64]
     const uint32_t n_total = MODE == SW_FP ? io.ctr->fp_count : MODE == SW_TRACE ? io.ctr->tq_count : io.dq ? io.ctr->dq_count : n_items;
+    if (MODE == SW_SCORE && io.dq && n_total <= io.wave_upto) return;
 
     for (uint32_t g = wave; (uint64_t)g * 64 < n_total; g += nwaves) {
         const uint32_t item = g * 64 + lane;
@@ -1821,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_sw_score(SwIO io, uint32_t n_items, uin
     uint32_t *const wlo = pl, *const whi = pl + PW * 64, *const qlo = pl + 2 * PW * 64, *const qhi = pl + (2 * PW + QW) * 64;
     uint16_t *bl = (uint16_t *)(pl + (2 * PW + 2 * QW) * 64) + lane;        // boundary row [j*64]
 
-    if (io.dq) n_items = io.ctr->dq_count;
+    if (io.dq) { n_items = io.ctr->dq_count; if (n_items <= io.wave_upto) return; }
     for (uint32_t g = wave; (uint64_t)g * 64 < n_items; g += nwaves) {
         const uint32_t item = g * 64 + lane;
         const uint32_t c = item < n_items ? (io.dq ? io.dq[item] : item) : 0;
