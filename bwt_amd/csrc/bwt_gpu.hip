@@ -715,7 +715,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.wave_upto = wv_thresh;
     b->wave_upto = wv_thresh;
     if (wv_thresh) {
-        ProfScope ps(b, "sw_extend");
+        ProfScope ps(b, "sw_wave");
         hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),
                            dim3(256), (size_t)wv_lds, b->stream, io, wv_thresh, wv_w1, wv_dwords, max_lq);
     }
