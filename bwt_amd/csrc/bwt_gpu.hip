@@ -370,6 +370,10 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 
 // exclusive scan in[0..n) (u32) -> out[0..n] (u64, out[n] = total)
 static int dev_scan(bwt_batch *b, const uint32_t *in, uint64_t *out, uint64_t n) {
+    if (n <= SCAN_TILE) {                                   // one tile: one launch
+        KLAUNCH(b, "scan", k_scan_one, 1, SCAN_BLOCK, in, out, n);
+        return 0;
+    }
     const uint32_t nb = std::max<uint32_t>(1, cdiv(n, SCAN_TILE));
     int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8);
     if (rc) return rc;

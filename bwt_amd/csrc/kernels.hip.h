@@ -185,6 +185,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
 }
 
+// ... and when everything fits one tile (batches of up to 2048 reads: the size a worker's message has): one launch
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_one(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n) {
+    const uint64_t base = (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    uint64_t excl;
+    const uint64_t total = block_scan_u64(s, excl);
+    uint64_t run = excl;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) out[n] = total;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_subreads: one lane per read.  Enumerates the sub-reads sga:sga/9 will search:
 //   {Skip,Qseq1} = skip_Ns(Qseq); search Qseq1; Qseq <- first (len(Qseq1)-8) bases; Shift += 8+Skip.
