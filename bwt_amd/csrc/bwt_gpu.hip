@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -68,6 +70,7 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
         }
     }
     if (K != 0 && (K < KT_MIN || K > BWT_MAX_LEN)) return fail(BWT_EINVAL, "bwt_index_set_ktable: K must be 0 or 8..15");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);        // waits for running batches; none starts while the table is swapped
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->d.ktab = nullptr; ix->d.ktw = nullptr; ix->d.kt_k = 0;
@@ -293,6 +296,7 @@ struct bwt_batch {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int occ_seed[3] = {0, 0, 0};       // resident blocks per CU of the three k_seed_tasks instances (queried once per batch)
     // inputs
     uint32_t n = 0, maxT = 0, max_lq = 0;
     uint64_t total_bases = 0;
@@ -388,9 +392,13 @@ extern "C" int bwt_batch_create(bwt_index *ix, bwt_batch **out) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_batch_create: null argument");
     HIPCHK(hipSetDevice(ix->device));
     bwt_batch *b = new bwt_batch();
-    b->ix = ix; b->device = ix->device; b->stream = ix->stream;
+    b->ix = ix; b->device = ix->device;
+    // its own stream: batches of different host threads on one index do not serialise (or free each other's buffers)
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete b; return fail(BWT_EHIP, "hipStreamCreate failed"); }
+    b->own_stream = true;
     int rc = b->ctr.ensure(sizeof(Counters));
-    if (rc) { delete b; return rc; }
+    if (rc) { bwt_batch_destroy(b); return rc; }
     *out = b;
     return 0;
 }
@@ -527,7 +535,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),       \
                   b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>()
         // with SA values in the table's top level (and 8..64 sub-reads per read) the seed kernel clusters what it can itself
-        static const char *env_f = getenv("BWT_SEED_FUSE");
+        const char *env_f = getenv("BWT_SEED_FUSE");
         const bool fuse = !raw && b->ix->d.ktw && maxT >= 8 && !(env_f && env_f[0] == '0');
         if (fuse) {
             if ((rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->r_cl.ensure((size_t)n * 8 * CL_STAGE + 16))) return rc;
@@ -536,24 +544,18 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         b->fused = fuse;
         b->rows_kept = !(fuse && lean);
         // persistent waves: as many blocks as are resident at once
-        auto resident = [&](const void *kern) {
-            static const void *seen[4] = {nullptr, nullptr, nullptr, nullptr};
-            static int occ[4] = {0, 0, 0, 0};
-            int per_cu = 0;
-            for (int i = 0; i < 4 && !per_cu; i++) {
-                if (seen[i] == kern) per_cu = occ[i];
-                else if (!seen[i]) {
-                    per_cu = 8;
-                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
-                    seen[i] = kern; occ[i] = per_cu;
-                }
+        auto resident = [&](int which, const void *kern) {
+            int &per_cu = b->occ_seed[which];
+            if (!per_cu) {
+                per_cu = 8;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 8; }
+                per_cu = std::max(1, std::min(per_cu, 8));
             }
-            if (!per_cu) per_cu = 8;
-            return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * std::max(1, std::min(per_cu, 8))));
+            return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
         };
-        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident((const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u);
-        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident((const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen);
-        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident((const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen);
+        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u);
+        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen);
+        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident(2, (const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen);
         {
             ProfScope ps(b, "fm_search");
             hipLaunchKernelGGL(k_search_pending, dim3(search_grid(b, T, false)), dim3(256), (size_t)4 * 64 * maxT * 2, b->stream, SEED_ARGS,
@@ -565,7 +567,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         if (!raw)
             KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT,
                     b->t_def.as<uint32_t>());
-        static const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
+        const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
         const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
         KLAUNCH(b, "fm_search", (u2 ? k_search<2> : k_search<1>), search_grid(b, T, u2), 256, b->ix->d, b->rplanes.as<uint32_t>(),
                 b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
@@ -704,7 +706,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
     io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.wave_upto = 0;
-    static const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
+    const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
     if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
         io.dq = b->dq.as<uint32_t>();
         KLAUNCH(b, "sw_prefilter", k_sw_prefilter, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc);   // quad per candidate
@@ -727,12 +729,12 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and
     // non-diagonal alignments go on to the trace pass.  LDS per wave: planes + (wcap+1) x 128 B.
     const bool fits16 = 4ull * (2ull * max_lq + max_w + 4) < 32000ull;
-    static const char *env_lds = getenv("BWT_SW_LDS");          // experiments: 0 forces the HBM boundary slab
+    const char *env_lds = getenv("BWT_SW_LDS");          // experiments: 0 forces the HBM boundary slab
     const uint32_t wcap = std::min<uint32_t>(max_w, 254), lqcap = std::min<uint32_t>(max_lq, 254);
     const uint32_t pwords = 2 * ((wcap + 31) / 32) + 2 * ((lqcap + 31) / 32);
     const uint64_t lds_wave = ((uint64_t)pwords * 64 + ((uint64_t)(wcap + 1) * 64 + 1) / 2) * 4;
     const uint64_t lds_bytes = lds_wave * 4;
-    static const char *env_pk = getenv("BWT_SW_PK");            // experiments: 0 disables the packed-i16 kernels
+    const char *env_pk = getenv("BWT_SW_PK");            // experiments: 0 disables the packed-i16 kernels
     const bool pk_ok = (max_lq == 100 || max_lq == 150) && !(env_pk && env_pk[0] == '0') && !(env_lds && env_lds[0] == '0');
     if (pk_ok) {
         // two alignments per lane, whole query column in registers; LDS holds only the bit-planes
@@ -743,7 +745,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         // After the prefilter the DP queue holds hardly any plain diagonal (those with <= 2 mismatches in a square window are
         // gone): a score-only pass would hand most of it on to the traced pass anyway (measured, 150 bp reads with indels:
         // 14.7 + 17.6 ms against 26.8 ms for tracing everything), so the traced DP runs on the DP queue directly.
-        static const char *env_ta = getenv("BWT_SW_TRACE_ALL");     // experiments: 0 = score pass first
+        const char *env_ta = getenv("BWT_SW_TRACE_ALL");     // experiments: 0 = score pass first
         const bool trace_all = io.dq && !(env_ta && env_ta[0] == '0');
         if (trace_all) {
             io.tq2 = io.dq;
@@ -772,7 +774,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
                                    b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
         }
     } else if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
-        static const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");
+        const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
         if (env_bpc) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(env_bpc));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * per_cu);
@@ -781,7 +783,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         ProfScope ps(b, "sw_extend");
         hipLaunchKernelGGL(k_sw_score, dim3(blocks), dim3(256), (size_t)lds_bytes, b->stream, io, (uint32_t)nc, wcap, lqcap);
     } else {
-        static const char *env_wpc = getenv("BWT_SW_WAVES_PER_CU");
+        const char *env_wpc = getenv("BWT_SW_WAVES_PER_CU");
         const uint32_t wpc = env_wpc ? (uint32_t)atoi(env_wpc) : 8;
         uint64_t waves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * wpc);
         waves = std::max<uint64_t>(4, std::min<uint64_t>(waves, (4ull << 30) / ((uint64_t)maxW1 * 256)) / 4 * 4);
@@ -869,6 +871,7 @@ static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, 
 
 extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts) {
     if (!b || !b->ix) return fail(BWT_EINVAL, "bwt_batch_run: batch has no index");
+    std::shared_lock<std::shared_mutex> lk(b->ix->mu);     // the index arrays stay put while the kernels run
     HIPCHK(hipSetDevice(b->device));
     int rc;
     if (stages & (BWT_STAGE_SEARCH | BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
@@ -996,6 +999,7 @@ extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const u
     if (rc) return rc;
     struct Guard { bwt_batch *b; ~Guard() { bwt_batch_destroy(b); } } g{b};
     if ((rc = bwt_batch_set_reads(b, bases, off, n))) return rc;
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
     // every sub-read is its own task here: one task slot per "read", defined directly
     b->maxT = 1;
     const uint64_t T = n;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <shared_mutex>
 #include <string>
 #include "kernels_index.h"
 #include "../../include/bwt_gpu.h"
@@ -29,16 +30,17 @@ struct DevBuf {
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError();      // the failed attempt with slack is not an error of the batch: clear the sticky code
             e = hipMalloc(&p, bytes);
             want = bytes;
-            if (e != hipSuccess) { p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+            if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
         }
         cap = want;
         return 0;
     }
     int exact(size_t bytes) {           // no slack: for the big index arrays
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(BWT_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
         cap = bytes;
         return 0;
     }
@@ -53,7 +55,11 @@ struct bwt_index {
     uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
     int32_t shift = 0;
     uint64_t ref1_len = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // index-level work only (table build, RefSeq gathers); every batch has its own stream
+    // Threading contract (include/bwt_gpu.h): any number of threads may run *_batch calls / their own bwt_batch on one
+    // index at a time (shared lock while kernels read the index); bwt_index_set_ktable swaps device arrays under the
+    // exclusive lock.
+    mutable std::shared_mutex mu;
 };
 
 // builds the Ref1 bit-planes of an index whose ref1 buffer is resident (used by both constructors)

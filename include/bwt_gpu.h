@@ -13,6 +13,13 @@
  *     repeated with larger buffers (two-call pattern: pass capacity 0 first to size).
  *   - reads are concatenated ASCII bytes; `off` has n+1 entries, read i = bases[off[i] .. off[i+1]).
  *   - there is NO CPU fallback: every *_batch function runs HIP kernels on `device`.
+ *   - threading: a bwt_index may be used by any number of host threads at once -- every host-buffer entry point
+ *     (bwt_find_seeds_batch, bwt_sga_batch, bwt_align_batch, bwt_sw_batch, bwt_ref1_*) works on a private batch with
+ *     its own HIP stream and does its own hipSetDevice, and holds the index's shared lock while kernels read it;
+ *     bwt_index_set_ktable takes the exclusive lock (it waits for running batches).  A bwt_batch / bwt_pipe /
+ *     bwt_fastq handle is NOT re-entrant: one call at a time per handle (use one handle per thread, or a lock
+ *     around it as c_src/bwt_nif.c does).  bwt_index_close must not race with anything else on that index.
+ *     bwt_last_error() is per thread.
  */
 #ifndef BWT_GPU_H
 #define BWT_GPU_H
@@ -142,6 +149,24 @@ int bwt_ref1_read(const bwt_index *idx, uint64_t off, uint64_t len, uint8_t *out
  * (capacity out_cap bytes; out_off[n+1] receives the offsets; BWT_ENOSPC reports the total in *needed) */
 int bwt_ref1_gather(const bwt_index *idx, const int64_t *win_off, const int32_t *win_len, uint64_t n,
                     uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint64_t *needed);
+
+/* ------------------------------------------------------------------ a-12: seeds.erl
+ * seeds:generate_fs(Qsec, Len, Defects) (src/seeds.erl:11-85) writes the module `fs`: one matches/Len clause per way
+ * of spending exactly Defects edits (mutation, insertion, deletion; edited positions are `_`) on the first Len+Defects
+ * bases of Qsec, and fs:find_seeds(Ref_Seq), a greedy scan (hit at N -> record N, go on at N+Len; miss -> N+1) that
+ * returns the 1-based hit positions newest first.
+ *   bwt_seeds_generate_fs  the text of fs.erl, byte for byte what the generator's io:format calls print (host only);
+ *   bwt_fs_find_seeds      what fs:find_seeds/1 of that module returns for `ref` -- on the GPU: the clause set is
+ *                          evaluated as one small NFA per window start, the greedy scan replayed over the marked starts;
+ *   bwt_fs_find_seeds_index the same over the bases of a resident index's chunk (the .ref bytes).
+ * 2 <= Len <= 1024 (the generator itself crashes on 0 and 1), Defects <= 4, qlen >= Len+Defects (a shorter query
+ * makes the generated file uncompilable), ref_len < 2^32-256.  BWT_ENOSPC reports the count in *needed. */
+int bwt_seeds_generate_fs(const uint8_t *qsec, uint32_t qlen, uint32_t len, uint32_t defects, char *text,
+                          uint64_t cap, uint64_t *needed);
+int bwt_fs_find_seeds(int device, const uint8_t *qsec, uint32_t qlen, uint32_t len, uint32_t defects,
+                      const uint8_t *ref, uint64_t ref_len, int64_t *pos, uint64_t cap, uint64_t *needed);
+int bwt_fs_find_seeds_index(const bwt_index *idx, const uint8_t *qsec, uint32_t qlen, uint32_t len, uint32_t defects,
+                            int64_t *pos, uint64_t cap, uint64_t *needed);
 
 /* ------------------------------------------------------------------ 8f-2: FASTQ ingest
  * fastq:read_seqs/2 (src/fastq.erl:5-40) on a memory-mapped file, straight into the packed batch layout:

@@ -17,6 +17,7 @@
  *   src/sga.erl:17-76              sga loop, add_seeds, get_similar, skip_Ns
  *   src/sw.erl:47-202              sw, build_tab, add_row2tab, get_CIGAR, sigma
  *   src/worker_bwt.erl:54-55,84-97 window slicing and the per-read fold
+ *   src/seeds.erl:11-85            generate_fs patterns and the generated fs:find_seeds/1
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -405,4 +406,92 @@ int orc_make_I(const uint8_t *L, uint32_t n, uint32_t Pc, uint32_t Pg, uint32_t 
         occ[c]++;
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * seeds:generate_fs/3 (src/seeds.erl:11-85) and the module `fs` it writes, restated literally:
+ * the patterns are enumerated by the same depth-first recursion (gen_pattern/5, :51-62, in the order
+ * mutation, insertion, deletion, match) and kept as explicit item strings, and fs:find_seeds/1 slides over the reference exactly as the generated
+ * clauses do (seeds.erl:24-41): last window -> test once; a hit records N and jumps Len, a miss
+ * advances by one; the accumulator is built by prepending (descending positions).
+ * Pattern item: 0..255 = that byte, 256 = `_`. */
+typedef struct { uint16_t *v; size_t n, cap; int len; int err; } patset;
+
+/* acc[0..nacc) = the accumulator in the order its items were prepended (acc[nacc-1] is the head of the Erlang list) */
+static void pat_emit(patset *ps, const uint16_t *acc, int nacc, const uint8_t *rest, int nrest) {
+    /* seeds.erl:51-55: N = Len - length(Acc), Tail = sublist(SubQsec, N), Sequence = reverse(Tail) ++ Acc;
+     * print_pattern/2 (:65-74) folds Sequence back into reading order = reverse(Acc) ++ Tail */
+    int ntail = ps->len - nacc;
+    if (ntail > nrest) { ps->err = 1; return; }            /* a shorter clause: fs.erl would not compile (head mismatch) */
+    if (ps->n + (size_t)ps->len > ps->cap) {
+        size_t nc = ps->cap ? ps->cap * 2 : 1024;
+        while (nc < ps->n + (size_t)ps->len) nc *= 2;
+        uint16_t *p = (uint16_t *)realloc(ps->v, nc * sizeof(uint16_t));
+        if (!p) { ps->err = 2; return; }
+        ps->v = p; ps->cap = nc;
+    }
+    uint16_t *o = ps->v + ps->n;
+    for (int i = 0; i < nacc; i++) o[i] = acc[i];
+    for (int i = 0; i < ntail; i++) o[nacc + i] = rest[i];
+    ps->n += (size_t)ps->len;
+}
+
+static void gen_pattern(patset *ps, uint16_t *acc, int nacc, const uint8_t *rest, int nrest, int defects) {
+    if (ps->err) return;
+    if (defects == 0) {                                                     /* seeds.erl:51 */
+        pat_emit(ps, acc, nacc, rest, nrest);
+        return;
+    }
+    if (nrest > 0 && nacc < ps->len) {                                      /* seeds.erl:57 */
+        acc[nacc] = 256; gen_pattern(ps, acc, nacc + 1, rest + 1, nrest - 1, defects - 1);   /* mutation  :58 */
+        acc[nacc] = 256; gen_pattern(ps, acc, nacc + 1, rest, nrest, defects - 1);           /* insertion :59 */
+        gen_pattern(ps, acc, nacc, rest + 1, nrest - 1, defects - 1);                        /* deletion  :60 */
+        acc[nacc] = rest[0]; gen_pattern(ps, acc, nacc + 1, rest + 1, nrest - 1, defects);   /* match     :61 */
+    }
+    /* seeds.erl:62: anything else -> ok */
+}
+
+/* patterns of generate_fs(Qsec, Len, Defects) in generation order; returns the count, -1 = would not compile, -2 = nomem.
+ * *out (count x len items) is malloc'ed */
+long orc_fs_patterns(const uint8_t *qsec, int qlen, int len, int defects, uint16_t **out) {
+    if (len < 1 || len > 255 || defects < 0) return -1;
+    patset ps = {0, 0, 0, len, 0};
+    uint16_t acc[512];
+    int nsub = qlen < len + defects ? qlen : len + defects;                 /* lists:sublist(Qsec, Len+Defects) :43 */
+    gen_pattern(&ps, acc, 0, qsec, nsub, defects);
+    if (ps.err) { free(ps.v); return ps.err == 1 ? -1 : -2; }
+    *out = ps.v;
+    return (long)(ps.n / (size_t)len);
+}
+void orc_free(void *p) { free(p); }
+
+static int fs_matches(const uint16_t *pats, long npat, int len, const uint8_t *w) {
+    for (long k = 0; k < npat; k++) {                                       /* clause order; first true wins */
+        const uint16_t *p = pats + (size_t)k * (size_t)len;
+        int ok = 1;
+        for (int i = 0; i < len && ok; i++) ok = p[i] == 256 || p[i] == w[i];
+        if (ok) return 1;
+    }
+    return 0;                                                               /* the final matches(_,...,_) -> false */
+}
+
+/* fs:find_seeds/1 on ref[0..n): 1-based positions, newest first.  returns the count (may exceed cap; only cap written) */
+long orc_fs_find_seeds(const uint16_t *pats, long npat, int len, const uint8_t *ref, long n, int64_t *out, long cap) {
+    long cnt = 0, i = 0;
+    int64_t N = 1;
+    /* collect ascending, reverse at the end (= prepending) */
+    while (n - i >= len) {
+        if (n - i == len) {                                                  /* seeds.erl:26-30: exactly Len left */
+            if (fs_matches(pats, npat, len, ref + i)) { if (cnt < cap) out[cnt] = N; cnt++; }
+            break;
+        }
+        if (fs_matches(pats, npat, len, ref + i)) {                          /* :33-35 */
+            if (cnt < cap) out[cnt] = N;
+            cnt++;
+            N += len; i += len;
+        } else { N += 1; i += 1; }                                           /* :36 */
+    }
+    long m = cnt < cap ? cnt : cap;
+    for (long a = 0, b = m - 1; a < b; a++, b--) { int64_t t = out[a]; out[a] = out[b]; out[b] = t; }
+    return cnt;
 }

@@ -696,3 +696,63 @@ def master_cigar_line(name, chromosome, pos, cigar_value, cigar_rate, refseq):
     if cigar_rate < 265:
         return None
     return "\n%s      %s      %d      %s      %d      %s\n" % (name, chromosome, pos, cigar_value, cigar_rate, refseq)
+
+
+# ------------------------------------------------------------------------------------------------
+# seeds:generate_fs/3 (src/seeds.erl:11-85) and the module `fs` it writes, list for list.
+
+def seeds_patterns(qsec, length, defects):
+    """The argument patterns of the generated matches/Len clauses in generation order: lists of `length` items,
+    a base (int) or None for `_`.  Raises ErlCrash where a clause of another arity would be printed (the generated
+    file then has a head mismatch and does not compile)."""
+    sub = list(qsec[:length + defects])                      # seeds.erl:43
+    out = []
+
+    def gen(acc, rest, d):                                   # acc: Erlang list, head first
+        if d == 0:                                           # seeds.erl:51-55
+            n = length - len(acc)
+            tail = rest[:n]
+            seq = list(reversed(tail)) + acc
+            out.append(list(reversed(seq)))                  # print_pattern/2 folds it back into reading order (:65-74)
+            return
+        if rest and len(acc) < length:                       # seeds.erl:57
+            s, more = rest[0], rest[1:]
+            gen([None] + acc, more, d - 1)                   # mutation  :58
+            gen([None] + acc, rest, d - 1)                   # insertion :59
+            gen(acc, more, d - 1)                            # deletion  :60
+            gen([s] + acc, more, d)                          # match     :61
+        # seeds.erl:62: ok
+
+    gen([], sub, defects)
+    if any(len(p) != length for p in out):
+        raise ErlCrash("fs.erl: head mismatch (a clause of arity /= Len)")
+    return out
+
+
+def fs_find_seeds(pats, ref_seq):
+    """fs:find_seeds/1 as generated (seeds.erl:24-41): the clause for exactly Len remaining items tests once;
+    otherwise a hit records N and continues Len further on, a miss one further on; Acc is built by prepending."""
+    length = len(pats[0]) if pats else 0
+    ref = list(ref_seq)
+
+    def matches(win):
+        for p in pats:                                       # clause order
+            if all(c is None or c == w for c, w in zip(p, win)):
+                return True
+        return False                                         # matches(_,...,_) -> false
+
+    acc, n, i = [], 1, 0
+    while length:
+        left = len(ref) - i
+        if left == length:                                   # find_seeds(Acc,N,[X1..XLen])
+            if matches(ref[i:]):
+                acc.insert(0, n)
+            break
+        if left > length:                                    # find_seeds(Acc,N,[X1..XLen|Ref_Seq])
+            if matches(ref[i:i + length]):
+                acc.insert(0, n); n += length; i += length
+            else:
+                n += 1; i += 1
+            continue
+        break                                                # find_seeds(Acc,_,_) -> Acc
+    return acc

@@ -124,3 +124,30 @@ def batch(fm, ref1, bases, off, mode, nthreads):
                     off.ctypes.data_as(C.c_void_p), C.c_uint32(len(off) - 1), mode, nthreads,
                     out.ctypes.data_as(C.c_void_p))
     return tuple(int(x) for x in out)
+
+
+def fs_patterns(qsec, length, defects):
+    """Patterns of seeds:generate_fs(Qsec, Len, Defects) in generation order (items: byte, or 256 for `_`) as an
+    (npat, length) u16 array; raises ValueError where the generated fs.erl would not compile."""
+    qsec = bytes(qsec)
+    lib().orc_fs_patterns.restype = C.c_long
+    p = C.c_void_p()
+    n = lib().orc_fs_patterns(qsec, len(qsec), int(length), int(defects), C.byref(p))
+    if n < 0:
+        raise ValueError("generate_fs(%r, %d, %d): the generated module would not compile" % (qsec, length, defects))
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(n * length,)).copy().reshape(n, length) if n else \
+        np.zeros((0, length), np.uint16)
+    lib().orc_free(p)
+    return out
+
+
+def fs_find_seeds(pats, ref):
+    """fs:find_seeds/1 of the generated module on `ref`: 1-based positions, newest first."""
+    pats = np.ascontiguousarray(pats, np.uint16)
+    ref = bytes(ref)
+    lib().orc_fs_find_seeds.restype = C.c_long
+    cap = len(ref) // max(1, pats.shape[1]) + 2
+    out = np.empty(cap, np.int64)
+    n = lib().orc_fs_find_seeds(pats.ctypes.data_as(C.c_void_p), C.c_long(pats.shape[0]), int(pats.shape[1]), ref,
+                                C.c_long(len(ref)), out.ctypes.data_as(C.c_void_p), C.c_long(cap))
+    return out[:n].tolist()

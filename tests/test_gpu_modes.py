@@ -1,0 +1,125 @@
+"""GPU tests of the library's execution modes and of its threading contract (include/bwt_gpu.h):
+every experiment switch (read per call) must give the oracle's answers, and several host threads may
+run batches on ONE index at the same time (the NIF's dirty-scheduler case)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import synth_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def hits_of(out, i):
+    a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+    return [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
+             int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
+
+
+def check_against_oracle(out, reads, orc_fm, ref1):
+    from oracle import orc
+    nh = 0
+    for i, q in enumerate(reads):
+        try:
+            exp = orc.align_read(orc_fm, ref1, q)
+        except RuntimeError:
+            assert out["read_status"][i] == -1
+            continue
+        if exp is None:
+            assert out["read_status"][i] == 1 and out["hit_off"][i] == out["hit_off"][i + 1]
+            continue
+        assert hits_of(out, i) == exp, (i, q)
+        nh += len(exp)
+    return nh
+
+
+MODES = [{"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
+         {"BWT_SW_TRACE_ALL": "0", "BWT_SW_WAVE": "0"}, {"BWT_SW_WAVE": "0", "BWT_SW_PREFILTER": "0"},
+         {"BWT_SEARCH_ILP": "2"}]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: ",".join("%s=%s" % kv for kv in m.items()))
+@pytest.mark.parametrize("K", ["15w", 0])
+def test_experiment_switches_keep_parity(gpu_index, orc_fm, ref_bytes, monkeypatch, mode, K):
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    for k, v in mode.items():
+        monkeypatch.setenv(k, v)
+    wide = isinstance(K, str)
+    gpu_index.set_ktable(15 if wide else K, 1 if wide else 0)
+    try:
+        ref1 = E.make_ref1(ref_bytes)
+        reads = (synth_reads(ref_bytes, 500, 100, 301, max_subs=3) + synth_reads(ref_bytes, 250, 100, 302, indel_frac=1.0) +
+                 synth_reads(ref_bytes, 80, 100, 303, n_frac=1.0))
+        bases, off = lib.pack_reads(reads)
+        out = gpu_index.align_batch(bases, off)
+        assert check_against_oracle(out, reads, orc_fm, ref1) > 300
+    finally:
+        gpu_index.set_ktable(-1)
+
+
+def test_concurrent_batches_on_one_index(gpu_index, orc_fm, ref_bytes):
+    """Four host threads, each with its own batches (own HIP stream) on the same index, several rounds each: every
+    result equals the oracle's (ctypes releases the GIL inside the library calls, so the calls really overlap)."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    sets = [synth_reads(ref_bytes, 600 + 150 * t, 100 if t % 2 == 0 else 150, 400 + t, indel_frac=0.2, n_frac=0.05) for t in range(4)]
+    packed = [lib.pack_reads(s) for s in sets]
+    results = [[None] * 3 for _ in range(4)]
+    errors = []
+
+    def work(t):
+        try:
+            for rnd in range(3):
+                if rnd == 1:
+                    results[t][rnd] = gpu_index.align_batch(*packed[t])          # host-buffer entry point (own batch per call)
+                else:
+                    b = lib.Batch(gpu_index)
+                    b.set_reads(*packed[t])
+                    b.run(lib.STAGE_EXTEND)
+                    results[t][rnd] = b.fetch_hits()
+                    b.destroy()
+        except Exception as e:                                                    # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    for t in range(4):
+        for rnd in range(3):
+            assert check_against_oracle(results[t][rnd], sets[t], orc_fm, ref1) > 200
+
+
+def test_set_ktable_waits_for_running_batches(gpu_index, orc_fm, ref_bytes):
+    """bwt_index_set_ktable takes the index's exclusive lock: called while another thread runs batches it neither
+    corrupts their results nor crashes."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = synth_reads(ref_bytes, 800, 100, 501)
+    packed = lib.pack_reads(reads)
+    outs, errors = [], []
+
+    def runner():
+        try:
+            for _ in range(6):
+                outs.append(gpu_index.align_batch(*packed))
+        except Exception as e:                                                    # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=runner)
+    t.start()
+    try:
+        for K, wide in ((9, 0), (15, 1), (12, 0), (0, 0)):
+            gpu_index.set_ktable(K, wide)
+    finally:
+        t.join()
+        gpu_index.set_ktable(-1)
+    assert not errors, errors
+    for out in outs:
+        assert check_against_oracle(out, reads, orc_fm, ref1) > 300
