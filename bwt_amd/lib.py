@@ -17,6 +17,7 @@ EXPORTS = [
     "bwt_batch_run", "bwt_batch_profile", "bwt_batch_kernel_times", "bwt_batch_hits_to_device",
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
     "bwt_build_index", "bwt_index_save", "bwt_index_export", "bwt_fastq_open", "bwt_fastq_close", "bwt_fastq_read_seqs", "bwt_ref1_gather",
+    "bwt_seeds_generate_fs", "bwt_fs_find_seeds", "bwt_fs_find_seeds_index",
 ]
 
 
@@ -251,6 +252,46 @@ class Index:
             rc, out = call(int(need[0]), int(need[1]))
         _chk(rc)
         return out
+
+
+def seeds_generate_fs(qsec, length, defects):
+    """bwt_seeds_generate_fs: the text of fs.erl as seeds:generate_fs/3 writes it (bytes)."""
+    q = np.frombuffer(bytes(qsec), np.uint8)
+    need = C.c_uint64(0)
+    rc = load().bwt_seeds_generate_fs(_p(q), C.c_uint32(len(q)), C.c_uint32(length), C.c_uint32(defects), None, C.c_uint64(0),
+                                      C.byref(need))
+    if rc != ENOSPC:
+        _chk(rc)
+    buf = C.create_string_buffer(need.value)
+    _chk(load().bwt_seeds_generate_fs(_p(q), C.c_uint32(len(q)), C.c_uint32(length), C.c_uint32(defects), buf,
+                                      C.c_uint64(need.value), C.byref(need)))
+    return buf.raw[:need.value]
+
+
+def fs_find_seeds(qsec, length, defects, ref=None, index=None, device=0):
+    """fs:find_seeds/1 of the module generate_fs(qsec, length, defects) writes, on `ref` (host bytes) or on the chunk of
+    a resident index: 1-based positions, newest first (int64 array)."""
+    q = np.frombuffer(bytes(qsec), np.uint8)
+    need = C.c_uint64(0)
+    if index is None:
+        r = ref if isinstance(ref, np.ndarray) else np.frombuffer(bytes(ref), np.uint8)
+        r = np.ascontiguousarray(r, np.uint8)
+
+        def call(out, cap):
+            return load().bwt_fs_find_seeds(int(device), _p(q), C.c_uint32(len(q)), C.c_uint32(length), C.c_uint32(defects),
+                                            _p(r), C.c_uint64(len(r)), _p(out), C.c_uint64(cap), C.byref(need))
+    else:
+        def call(out, cap):
+            return load().bwt_fs_find_seeds_index(index.h, _p(q), C.c_uint32(len(q)), C.c_uint32(length),
+                                                  C.c_uint32(defects), _p(out), C.c_uint64(cap), C.byref(need))
+    rc = call(None, 0)
+    if rc == ENOSPC:
+        out = np.empty(need.value, np.int64)
+        rc = call(out, len(out))
+        _chk(rc)
+        return out
+    _chk(rc)
+    return np.empty(0, np.int64)
 
 
 def sw_batch(q, qoff, r, roff, device=0):

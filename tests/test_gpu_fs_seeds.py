@@ -1,0 +1,72 @@
+"""GPU parity of the generated module fs (seeds.erl): bwt_fs_find_seeds (clause set as an NFA per window
+start + replay of the greedy scan) against the oracle's explicit clause list and literal scan."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fs_find_seeds_random_cases():
+    from bwt_amd import lib
+    from oracle import orc
+    rng = np.random.default_rng(7)
+    nonempty = 0
+    for trial in range(120):
+        L = int(rng.integers(2, 14)); D = int(rng.integers(0, 4))
+        alpha = list(b"ACGT") if trial % 3 else list(b"AC")            # a poor alphabet makes dense, overlapping hits
+        q = bytes(rng.choice(alpha, L + D + int(rng.integers(0, 4))).tolist())
+        n = int(rng.integers(0, 3000))
+        ref = bytearray(rng.choice(alpha + ([ord("N")] if trial % 5 == 0 else []), n).tolist())
+        for _ in range(int(rng.integers(0, 6))):                         # plant copies of the query, some edited
+            if n > L + D + 2:
+                p = int(rng.integers(0, n - L - D))
+                w = bytearray(q[:L + D])
+                if rng.random() < 0.5:
+                    w[int(rng.integers(0, L))] = int(rng.choice(alpha))
+                ref[p:p + len(w)] = w
+        ref = bytes(ref[:n])
+        exp = orc.fs_find_seeds(orc.fs_patterns(q, L, D), ref)
+        got = lib.fs_find_seeds(q, L, D, ref=ref).tolist()
+        assert got == exp, (q, L, D, ref[:60])
+        nonempty += bool(exp)
+    assert nonempty > 60
+
+
+def test_fs_find_seeds_edge_lengths():
+    from bwt_amd import lib
+    from oracle import orc
+    q = b"ACGTACGT"
+    for ref in [b"", b"ACG", b"ACGT", b"ACGTA", b"ACGTACGT", b"A" * 70, b"ACGT" * 40]:
+        for L, D in [(4, 0), (4, 1), (4, 2), (6, 2), (5, 3)]:
+            assert lib.fs_find_seeds(q, L, D, ref=ref).tolist() == orc.fs_find_seeds(orc.fs_patterns(q, L, D), ref), (ref, L, D)
+
+
+def test_fs_find_seeds_on_the_resident_chunk(gpu_index, ref_bytes):
+    """over the bundled contig (189 789 bases) straight from HBM, Len 20, two defects: every true occurrence of the
+    query region is found, and the whole list equals the oracle's literal scan"""
+    from bwt_amd import lib, seeds
+    from oracle import orc
+    q = ref_bytes[5000:5030]
+    fs = seeds.Fs(q, 20, 2)
+    got = fs.find_seeds(gpu_index)
+    assert got == lib.fs_find_seeds(q, 20, 2, ref=ref_bytes).tolist()
+    pats = orc.fs_patterns(q, 20, 2)
+    assert got == orc.fs_find_seeds(pats, ref_bytes)
+    assert 5001 in got
+
+
+def test_fs_large_len_and_tiles():
+    """Len above the usual seed sizes, a reference spanning many tiles and blocks, plants across tile borders"""
+    from bwt_amd import lib
+    from oracle import orc
+    rng = np.random.default_rng(11)
+    ref = bytearray(rng.choice(list(b"ACGT"), 300_000).tolist())
+    q = bytes(ref[70_000:70_000 + 130])
+    for p in (1, 960, 2047, 65_530, 299_000, 300_000 - 128):
+        ref[p:p + 128] = q[:128]
+    ref[2047 + 50] = ord("N")                                       # one mutation inside a plant
+    ref = bytes(ref)
+    got = lib.fs_find_seeds(q, 128, 1, ref=ref).tolist()
+    assert got == orc.fs_find_seeds(orc.fs_patterns(q, 128, 1), ref)
+    for p in (1, 960, 2047, 65_530, 70_000, 299_000, 300_000 - 128):
+        assert p + 1 in got
