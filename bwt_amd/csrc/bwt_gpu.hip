@@ -296,7 +296,8 @@ struct bwt_batch {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int occ_seed[3] = {0, 0, 0};       // resident blocks per CU of the three k_seed_tasks instances (queried once per batch)
+    int occ_seed[4] = {0, 0, 0, 0};    // resident blocks per CU of the three k_seed_tasks instances and k_seed_fast (queried once per batch)
+    DevBuf gq;                         // groups k_seed_fast handed back
     // inputs
     uint32_t n = 0, maxT = 0, max_lq = 0;
     uint64_t total_bases = 0;
@@ -430,7 +431,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
-                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq};
+                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -553,9 +554,23 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
             }
             return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
         };
-        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u);
-        else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen);
-        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident(2, (const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen);
+        // Batches of one read length with the full-depth wide table: k_seed_fast takes the ordinary groups of reads and hands
+        // the others back as a list for k_seed_tasks (results are k_seed_tasks' either way).  Up to 14 sub-reads per read:
+        // longer reads mostly hold more than the 64 seeds the fast kernel sorts.
+        const char *env_fast = getenv("BWT_SEED_FAST");             // experiments / tests: 0 = general kernel only
+        const bool fast = fuse && lean && b->ulen && b->ix->d.kt_k == BWT_MAX_LEN && maxT <= 14 && !(env_fast && env_fast[0] == '0');
+        const uint32_t *nolist = nullptr;
+        const unsigned int *nocount = nullptr;
+        if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u, nolist, nocount);
+        else if (fast) {
+            if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
+            KLAUNCH(b, "fm_lookup", k_seed_fast, resident(3, (const void *)k_seed_fast), 256, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
+                    b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
+                    b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
+            KLAUNCH(b, "fm_lookup_rest", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), 1, b->ulen,
+                    (const uint32_t *)b->gq.as<uint32_t>(), (const unsigned int *)&b->ctr.as<Counters>()->n_gq);
+        } else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen, nolist, nocount);
+        else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident(2, (const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen, nolist, nocount);
         {
             ProfScope ps(b, "fm_search");
             hipLaunchKernelGGL(k_search_pending, dim3(search_grid(b, T, false)), dim3(256), (size_t)4 * 64 * maxT * 2, b->stream, SEED_ARGS,
@@ -898,6 +913,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
         if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
         counts->n_dp = b->hctr.dq_count; counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
+        counts->n_handed_back = b->hctr.n_gq;
     }
     return 0;
 }

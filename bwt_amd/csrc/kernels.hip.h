@@ -597,7 +597,8 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                                      uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                      uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                      uint32_t *__restrict__ mid4q, uint32_t *__restrict__ r_K,
-                                                     uint32_t *__restrict__ r_cl, Counters *ctr, int lean, uint32_t ulen) {
+                                                     uint32_t *__restrict__ r_cl, Counters *ctr, int lean, uint32_t ulen,
+                                                     const uint32_t *__restrict__ glist, const unsigned int *__restrict__ gcount) {
     __shared__ uint32_t lds_[FUSE ? 4 * 8 * CL_ROW : 1];
     __shared__ uint32_t rq_[4 * READQ_LDS_WORDS];
     ReadQ rq;
@@ -611,10 +612,12 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
     const unsigned long long segmask = maxT == 64 ? ~0ull : ((1ull << maxT) - 1ull);
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t groups = (n + rw - 1) / rw;
+    // glist != null: only the groups k_seed_fast handed back (it wrote nothing for them)
+    const uint32_t groups = glist ? *gcount : (n + rw - 1) / rw;
     uint32_t live = 0, looked = 0, nsmall = 0;
     unsigned long long Psum = 0;
-    for (uint32_t g = wave; g < groups; g += nwaves) {
+    for (uint32_t gi = wave; gi < groups; gi += nwaves) {
+        const uint32_t g = glist ? glist[gi] : gi;
         const uint32_t r = g * rw + lread;
         const bool valid = lread < rw && r < n;
         LfTask tk;
@@ -905,6 +908,243 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         atomicAdd(&ctr->kt_lookups, k);
         atomicAdd(&ctr->sa_reads, s);
         if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_seed_fast: k_seed_tasks<false, true> in lean mode, cut down to the ordinary read -- every read of the batch has the
+// same length (ulen), the table is K = 15 with SA values in its top level, and in the group of 64 / maxT reads a wave
+// takes per pass
+//   * no read holds a base outside ACGT (the windows [e-16, e) of a read's sub-reads cover the whole read),
+//   * every table entry fits (no KT_OVF), every seed list came with its entry (<= 14 seeds, top level),
+//   * every read has at most 64 seeds and at most CL_STAGE clusters.
+// A group that fails any of these is handed back untouched -- its index goes to gq and k_seed_tasks runs on that list
+// afterwards -- so the results are k_seed_tasks' by construction; this kernel only has to be right on what it keeps.
+// What it saves over the general kernel (which sits at the VALU issue limit): the sub-read chain and the N-plane loads
+// (e = ulen - 8 slot is a lane constant), the u64 prefix sum (one packed u32 DPP scan gives seeds-before-me, P and Qty),
+// the quad broadcasts that fetch a lane's own entry (the entries go through an LDS transpose: four 16-byte writes, then
+// every lane reads its own slot), the predicated word-by-word seed stores (each lane copies its own seeds), get_similar
+// on lane masks in SGPRs (run starts by one ballot; run lengths, the emit test and the cluster count are scalar ops; only
+// the one or two emitted clusters touch the VALU again), no task-table rows, one store of the group's results at the end.
+#define SF_ROW 64
+__device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);    // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);    // row_bcast:31 into rows 2, 3
+    return v;
+}
+// the (wave-uniform) value v into lane `idx` of a register
+__device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t idx, uint32_t v) {
+    return (threadIdx.x & 63u) == idx ? v : old;
+}
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge3(uint32_t &a, uint32_t &b, uint32_t &c) {
+    a = bitonic_stage<K, J>(a); b = bitonic_stage<K, J>(b); c = bitonic_stage<K, J>(c);
+    if constexpr (J > 1) bitonic_merge3<K, J / 2>(a, b, c);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_sort_upto3(uint32_t &a, uint32_t &b, uint32_t &c) {
+    if constexpr (K > 2) bitonic_sort_upto3<K / 2>(a, b, c);
+    bitonic_merge3<K, K / 2>(a, b, c);
+}
+// get_similar (sga.erl:42-64) on one sorted lane-per-seed register, on lane masks: p ascending in lanes [0, Pj), 0xffffffff
+// above.  The read's clusters (descending position) go to lanes 8 j .. 8 j + Kc - 1 of (cv0, cv1) = (S, D); returns Kc.
+__device__ __forceinline__ uint32_t sf_emit(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t j, uint32_t &cv0, uint32_t &cv1) {
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xF, 0xF, false);      // wave_shr:1
+    const unsigned long long vmask = Pj >= 64 ? ~0ull : ((1ull << Pj) - 1ull);
+    const unsigned long long sm = (__ballot(p - prev > BWT_TOLERANCE) | 1ull) & vmask;       // run starts (lane 0 always)
+    unsigned long long em = ((sm >> 1) | (1ull << (Pj - 1))) & vmask;                        // run ends: the lane before a start, the last
+    const uint32_t nthr = 2 + qj / 7;                                                        // sga.erl:46
+    const unsigned long long A = ~sm;
+    unsigned long long ok = A;                                                               // lane e ends a run of >= nthr <=> no start in (e - nthr + 1, e]
+    for (uint32_t k = 1; k + 1 < nthr; k++) ok &= A << k;
+    em &= ok;
+    const uint32_t Kc = (uint32_t)__popcll(em);
+    if (Kc > CL_STAGE) return Kc;
+    uint32_t kk = 0;
+    while (em) {
+        const int e = 63 - __clzll((long long)em);
+        em &= ~(1ull << e);
+        const int s0 = 63 - __clzll((long long)(sm & ((2ull << e) - 1ull)));
+        const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)p, e), pf = (uint32_t)__builtin_amdgcn_readlane((int)p, s0);
+        cv0 = set_lane(cv0, 8 * j + kk, pe);
+        cv1 = set_lane(cv1, 8 * j + kk, pe - pf);
+        kk++;
+    }
+    return Kc;
+}
+
+__global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
+                                                    uint32_t ulen, unsigned long long *__restrict__ r_pend,
+                                                    uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
+                                                    uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_cl,
+                                                    uint32_t *__restrict__ gq, Counters *ctr) {
+    __shared__ uint4 stag_[4 * 64 * 4];                          // per wave: 64 task slots x four 16-byte quarters
+    __shared__ uint32_t rows_[4 * 8 * SF_ROW];                   // per wave: a row of seeds per read of the pass
+    __shared__ uint32_t gq_[4 * 128];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint4 *stag = stag_ + wv * 256;
+    uint32_t *rows = rows_ + wv * 8 * SF_ROW;
+    WaveQ q;
+    q.buf = gq_ + wv * 128; q.have = 0;
+    const uint32_t rw = 64u / maxT;
+    const uint32_t lread = lane / maxT, slot = lane - lread * maxT, seg0 = lread * maxT;
+    const uint32_t ql = lane & 3u;
+    // lane constants of the slot: sub-read end, step limit = table level, bits of the 16-base window that belong to the read
+    const int e = (int)ulen - (int)(BWT_MIN_LEN * slot) >= BWT_MIN_LEN ? (int)ulen - (int)(BWT_MIN_LEN * slot) : 0;
+    const int m = e < BWT_MAX_LEN ? e : BWT_MAX_LEN;
+    const uint32_t kmask = (1u << m) - 1u, ksh = 16u - (uint32_t)m;
+    const uint32_t inread = e >= 16 ? 0xffffu : ((0xffffu << (16 - e)) & 0xffffu);
+    const bool wide = m == BWT_MAX_LEN;
+    const uint64_t loff = kt_level_off(m > KT_MIN ? m : KT_MIN);
+    const uint32_t shsk = BWT_MIN_LEN * slot;
+    const int hi_l = (int)(((seg0 + maxT - 1) & 63u) << 2), lo_l = (int)(((seg0 - 1) & 63u) << 2);
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t groups = (n + rw - 1) / rw;
+    uint32_t live = 0;
+    unsigned long long Psum = 0;
+    for (uint32_t g = wave; g < groups; g += nwaves) {
+        const uint32_t r = g * rw + lread;
+        const bool valid = lread < rw && r < n;
+        const bool act = valid && e > 0;
+        const uint64_t endp = (uint64_t)r * ulen + (uint64_t)e;
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (act && endp >= 16) w = planes4(planes, endp - 16);
+        const uint32_t key = ((w.x >> ksh) & kmask) | (((w.y >> ksh) & kmask) << m);
+        bool abn = act && (endp < 16 || ((w.z | w.w) & inread) != 0);
+        // the table reads: lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
+        const uint32_t aw = act && wide ? 1u : 0u;
+        uint4 Q0 = make_uint4(0, 0, 0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0;
+        { const uint32_t kt = quad_bcast<0>(key); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<1>(key); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<2>(key); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        unsigned long long nent = 0;
+        if (act && !wide) nent = ix.ktab[loff + key];
+        live += (uint32_t)__popcll(__ballot(act));
+        // transpose through LDS: afterwards slot t of the staging area holds the whole entry of lane t
+        const uint32_t qb = (lane & ~3u) * 4 + ql;
+        stag[qb] = Q0; stag[qb + 4] = Q1; stag[qb + 8] = Q2; stag[qb + 12] = Q3;
+        __builtin_amdgcn_wave_barrier();
+        uint4 own = stag[lane * 4];
+        if (!wide) { own.x = (uint32_t)nent; own.y = (uint32_t)(nent >> 32); }
+        const uint32_t wd = own.y & KT_OVF, nn = own.y >> 28;
+        // bwa.erl:31-45 at the end of the search: the range check applies unless a step came back not_found (n < m)
+        const bool seeds = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
+        const uint32_t c = seeds ? wd + 1u : 0u;
+        abn = abn || (act && wd == KT_OVF) || (seeds && (!wide || c > KT_INLINE));
+        if (__ballot(abn)) {                                           // hand the group back
+            __builtin_amdgcn_wave_barrier();
+            waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
+            live -= (uint32_t)__popcll(__ballot(act));
+            continue;
+        }
+        const uint32_t nadd = nn + shsk;                               // N + Shift (sga.erl:32,37-39; nothing skipped)
+        // one packed scan: low half = seeds, high half = sub-reads that returned a seed list (Qty)
+        const uint32_t v = c | (seeds ? 0x10000u : 0u);
+        const uint32_t incl = dpp_scan_incl_u32(v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(hi_l, (int)incl);
+        const uint32_t lo = seg0 ? (uint32_t)__builtin_amdgcn_ds_bpermute(lo_l, (int)incl) : 0u;
+        const uint32_t Pq = hi - lo, P = Pq & 0xffffu, qty = Pq >> 16;
+        const uint32_t dst = (incl - v - lo) & 0xffffu;
+        const bool fuse_read = valid && qty >= 2 && P > 0;             // sga.erl:42-43
+        if (__ballot(fuse_read && P > SF_ROW)) {
+            __builtin_amdgcn_wave_barrier();
+            waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
+            live -= (uint32_t)__popcll(__ballot(act));
+            continue;
+        }
+        // every lane copies its own seeds (+ N + Shift) into its read's row
+        {
+            uint32_t *row = rows + lread * SF_ROW + dst;
+            const uint32_t cw = fuse_read ? c : 0u;
+            if (cw > 0) row[0] = own.z + nadd;
+            if (cw > 1) row[1] = own.w + nadd;
+            if (__ballot(cw > 2)) {
+                const uint4 t = stag[lane * 4 + 1];
+                if (cw > 2) row[2] = t.x + nadd;
+                if (cw > 3) row[3] = t.y + nadd;
+                if (cw > 4) row[4] = t.z + nadd;
+                if (cw > 5) row[5] = t.w + nadd;
+                if (__ballot(cw > 6)) {
+                    const uint4 t2 = stag[lane * 4 + 2];
+                    if (cw > 6) row[6] = t2.x + nadd;
+                    if (cw > 7) row[7] = t2.y + nadd;
+                    if (cw > 8) row[8] = t2.z + nadd;
+                    if (cw > 9) row[9] = t2.w + nadd;
+                    if (__ballot(cw > 10)) {
+                        const uint4 t3 = stag[lane * 4 + 3];
+                        if (cw > 10) row[10] = t3.x + nadd;
+                        if (cw > 11) row[11] = t3.y + nadd;
+                        if (cw > 12) row[12] = t3.z + nadd;
+                        if (cw > 13) row[13] = t3.w + nadd;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // sort + get_similar, up to three reads side by side (independent chains of 21 stages)
+        unsigned long long bf = __ballot(fuse_read && slot == 0);        // bit seg0 of every read to cluster
+        uint32_t cv0 = 0xffffffffu, cv1 = 0, kcv = 0;
+        unsigned long long Pgrp = 0;
+        bool over = false;
+        uint32_t left = (uint32_t)__popcll(bf);
+        while (left) {
+            const uint32_t take = left == 1 ? 1u : (left == 2 || left == 4) ? 2u : 3u;
+            uint32_t jj[3], Pj[3], qj[3], pp[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                jj[t] = 0; Pj[t] = 1; qj[t] = 0; pp[t] = 0xffffffffu;
+                if ((uint32_t)t < take) {
+                    const int b = __ffsll((long long)bf) - 1;
+                    bf &= bf - 1ull;
+                    jj[t] = (uint32_t)b / maxT;
+                    Pj[t] = (uint32_t)__builtin_amdgcn_readlane((int)P, b);
+                    qj[t] = (uint32_t)__builtin_amdgcn_readlane((int)qty, b);
+                    pp[t] = lane < Pj[t] ? rows[jj[t] * SF_ROW + lane] : 0xffffffffu;
+                    Pgrp += Pj[t];
+                }
+            }
+            if (take == 1) pp[0] = wave_sort_u32(pp[0]);
+            else if (take == 2) wave_sort2_u32(pp[0], pp[1]);
+            else bitonic_sort_upto3<64>(pp[0], pp[1], pp[2]);
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if ((uint32_t)t < take) {
+                    const uint32_t Kc = sf_emit(pp[t], Pj[t], qj[t], jj[t], cv0, cv1);
+                    over = over || Kc > CL_STAGE;
+                    kcv = set_lane(kcv, jj[t] * maxT, Kc);
+                }
+            left -= take;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (over) {                                                    // a read with more clusters than its staging row holds
+            waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
+            live -= (uint32_t)__popcll(__ballot(act));
+            continue;
+        }
+        Psum += Pgrp;
+        // the group's results
+        if (cv0 != 0xffffffffu) {
+            uint32_t *dstp = r_cl + ((uint64_t)g * rw + (lane >> 3)) * (2 * CL_STAGE) + 2 * (lane & 7u);
+            dstp[0] = cv0; dstp[1] = cv1;
+        }
+        if (valid && slot == 0) {
+            r_pend[r] = 0ull;
+            r_P[r] = 0;
+            r_qty[r] = qty | (fuse_read ? RQ_DONE : 0u);
+            if (fuse_read) r_K[r] = kcv;
+        }
+    }
+    waveq_drain(q, gq, &ctr->n_gq);
+    if (lane == 0 && (live | Psum)) {
+        atomicAdd(&ctr->n_tasks, (unsigned long long)live);
+        atomicAdd(&ctr->kt_lookups, (unsigned long long)live);
+        atomicAdd(&ctr->sa_reads, Psum);
     }
 }
 

@@ -137,5 +137,6 @@ __device__ __forceinline__ uint4 planes4(const uint32_t *__restrict__ planes, ui
 struct Counters {          // device-side work counters (roofline accounting)
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags, kt_lookups;
     unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, n_small;
+    unsigned int n_gq, pad_;   // groups k_seed_fast handed back to k_seed_tasks
 };
 

@@ -123,3 +123,49 @@ def test_set_ktable_waits_for_running_batches(gpu_index, orc_fm, ref_bytes):
     assert not errors, errors
     for out in outs:
         assert check_against_oracle(out, reads, orc_fm, ref1) > 300
+
+
+def test_fast_seed_kernel_against_general_and_oracle(monkeypatch):
+    """k_seed_fast (uniform read length, K = 15 wide table) on a synthetic index where it keeps nearly every group, with
+    reads that make it hand groups back (N, IUPAC, repeats with many seeds / clusters): same hit tables as the general
+    kernel alone, and the oracle's answers."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(91)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3_000_000, dtype=np.uint8)].tobytes())
+    seg = bytes(g[1000:1300])
+    for k in range(1, 9):                                            # a 300-bp repeat in 9 copies: reads from it have ~9 clusters
+        g[200_000 * k:200_000 * k + 300] = seg
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=3)
+    try:
+        ix.set_ktable(15, 1)
+        L, SA = ix.export()
+        ptr, shift = ix.meta()
+        ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+        ref1 = E.make_ref1(ref)
+        reads = (synth_reads(ref, 4000, 100, 601, max_subs=2) + synth_reads(ref, 300, 100, 602, indel_frac=1.0) +
+                 synth_reads(ref, 100, 100, 603, n_frac=1.0) + synth_reads(ref, 60, 100, 604, iupac_frac=1.0) +
+                 [ref[1000 + 7 * i:1100 + 7 * i] for i in range(25)] + [ref[:100], ref[5:105], ref[-100:]])
+        order = rng.permutation(len(reads))
+        reads = [reads[i] for i in order]
+        packed = lib.pack_reads(reads)
+        outs = {}
+        for fast in ("1", "0"):
+            monkeypatch.setenv("BWT_SEED_FAST", fast)
+            b = lib.Batch(ix)
+            b.set_reads(*packed)
+            c = b.run(lib.STAGE_EXTEND)
+            outs[fast] = (b.fetch_hits(), c)
+            b.destroy()
+        c1, c0 = outs["1"][1], outs["0"][1]
+        groups = (len(reads) + 4) // 5
+        assert c0["n_handed_back"] == 0 and 0 < c1["n_handed_back"] < groups // 3      # most groups stay with the fast kernel
+        for k in ("n_tasks", "n_lookups", "sa_reads", "n_clusters", "n_hits", "cigar_bytes", "sw_cells"):
+            assert c1[k] == c0[k], k
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(outs["1"][0][k], outs["0"][0][k]), k
+        assert outs["1"][0]["cigar"] == outs["0"][0]["cigar"]
+        assert check_against_oracle(outs["1"][0], reads, ofm, ref1) > 3500
+    finally:
+        ix.close()
