@@ -11,6 +11,9 @@
  *   index_meta(Index) -> {Pc,Pg,Pt,Last,Shift}
  *   align_batch(Index, [{Name, Seq}]) ->
  *        [{Name, nothing | {error, Reason} | [{{Score,Cigar}, Pos, RefSeq}]}]      (reference list order)
+ *        | {error, enomem} | {error, {Code, Text}}
+ * Thread safety: calls on the same Index term are serialised by a mutex in the resource (the resident batch is not
+ * re-entrant); calls on different Index terms, and everything below the batch in libbwtgpu, run concurrently.
  * align_batch (bwt_batch_set_reads + bwt_batch_run + bwt_batch_fetch_hits) replaces the two per-read calls of worker_bwt.erl (sga:sga/6 at :76, sw:sw/2 at :92)
  * and runs on a dirty IO scheduler (a batch of 200 reads x 10 lists takes well over 1 ms).
  */
@@ -20,12 +23,17 @@
 #include "bwt_gpu.h"
 
 static ErlNifResourceType *INDEX_RT;
-typedef struct { bwt_index *ix; bwt_batch *batch; } index_res;   /* one resident batch per index handle */
+/* One resident batch per index handle (its device buffers are reused from call to call).  A bwt_batch is not
+ * re-entrant (include/bwt_gpu.h, threading), and BEAM may run align_batch for the same Index term on several
+ * dirty schedulers at once: `lock` serialises them.  Different Index terms run concurrently. */
+typedef struct { bwt_index *ix; bwt_batch *batch; ErlNifMutex *lock; } index_res;
 
 static void index_dtor(ErlNifEnv *env, void *obj) {
+    index_res *r = (index_res *)obj;
     (void)env;
-    bwt_batch_destroy(((index_res *)obj)->batch);
-    bwt_index_close(((index_res *)obj)->ix);
+    if (r->batch) bwt_batch_destroy(r->batch);
+    if (r->ix) bwt_index_close(r->ix);
+    if (r->lock) enif_mutex_destroy(r->lock);
 }
 
 static int load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
@@ -62,8 +70,11 @@ static ERL_NIF_TERM nif_index_open(ErlNifEnv *env, int argc, const ERL_NIF_TERM 
     int rc = bwt_index_open(fm, ref, dev, &ix);
     if (rc) return mk_error(env, rc);
     index_res *r = enif_alloc_resource(INDEX_RT, sizeof *r);
+    if (!r) { bwt_index_close(ix); return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "enomem")); }
     r->ix = ix; r->batch = NULL;
-    if ((rc = bwt_batch_create(ix, &r->batch))) { enif_release_resource(r); return mk_error(env, rc); }
+    r->lock = enif_mutex_create("bwt_index_batch");
+    if (!r->lock) { enif_release_resource(r); return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "enomem")); }
+    if ((rc = bwt_batch_create(ix, &r->batch))) { ERL_NIF_TERM e = mk_error(env, rc); enif_release_resource(r); return e; }
     ERL_NIF_TERM t = enif_make_resource(env, r);
     enif_release_resource(r);
     return enif_make_tuple2(env, enif_make_atom(env, "ok"), t);
@@ -79,83 +90,113 @@ static ERL_NIF_TERM nif_index_meta(ErlNifEnv *env, int argc, const ERL_NIF_TERM 
                             enif_make_uint(env, m[3]), enif_make_int(env, (int32_t)m[4]));
 }
 
+/* every buffer of one align_batch call; freed in one place */
+typedef struct {
+    ERL_NIF_TERM *names; uint64_t *off; uint8_t *bases; int32_t *rstat; uint64_t *hoff;
+    int32_t *score, *wlen; int64_t *pos, *woff; uint64_t *coff; char *cig; uint8_t *wins; uint64_t *woffs;
+} call_bufs;
+static void bufs_free(call_bufs *b) {
+    free(b->names); free(b->off); free(b->bases); free(b->rstat); free(b->hoff); free(b->score); free(b->wlen);
+    free(b->pos); free(b->woff); free(b->coff); free(b->cig); free(b->wins); free(b->woffs);
+}
+static ERL_NIF_TERM enomem(ErlNifEnv *env, call_bufs *b) {
+    bufs_free(b);
+    return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "enomem"));
+}
+
 static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
     index_res *r;
     unsigned n;
+    call_bufs B;
     (void)argc;
+    memset(&B, 0, sizeof B);
     if (!enif_get_resource(env, argv[0], INDEX_RT, (void **)&r) || !enif_get_list_length(env, argv[1], &n))
         return enif_make_badarg(env);
     /* copy names and sequences (lists of bytes or binaries: iolists) into one staging buffer */
-    ERL_NIF_TERM *names = malloc(sizeof(ERL_NIF_TERM) * (n ? n : 1));
-    uint64_t *off = malloc(sizeof(uint64_t) * (n + 1));
     size_t cap = 256 * (size_t)(n ? n : 1), used = 0;
-    uint8_t *bases = malloc(cap);
+    B.names = malloc(sizeof(ERL_NIF_TERM) * (n ? n : 1));
+    B.off = malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    B.bases = malloc(cap);
+    B.rstat = malloc(sizeof(int32_t) * (n ? n : 1));
+    B.hoff = malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    if (!B.names || !B.off || !B.bases || !B.rstat || !B.hoff) return enomem(env, &B);
     ERL_NIF_TERM head, tail = argv[1];
     unsigned i = 0;
-    off[0] = 0;
+    B.off[0] = 0;
     while (enif_get_list_cell(env, tail, &head, &tail)) {
         const ERL_NIF_TERM *tp;
         int ar;
         ErlNifBinary bin;
-        if (!enif_get_tuple(env, head, &ar, &tp) || ar != 2 || !enif_inspect_iolist_as_binary(env, tp[1], &bin)) {
-            free(names); free(off); free(bases);
+        if (i >= n || !enif_get_tuple(env, head, &ar, &tp) || ar != 2 || !enif_inspect_iolist_as_binary(env, tp[1], &bin)) {
+            bufs_free(&B);
             return enif_make_badarg(env);
         }
-        if (used + bin.size > cap) { cap = (used + bin.size) * 2; bases = realloc(bases, cap); }
-        memcpy(bases + used, bin.data, bin.size);
+        if (used + bin.size > cap) {
+            size_t ncap = (used + bin.size) * 2;
+            uint8_t *nb = realloc(B.bases, ncap);
+            if (!nb) return enomem(env, &B);
+            B.bases = nb; cap = ncap;
+        }
+        memcpy(B.bases + used, bin.data, bin.size);
         used += bin.size;
-        names[i] = tp[0];
-        off[++i] = used;
+        B.names[i] = tp[0];
+        B.off[++i] = used;
     }
-    int32_t *rstat = malloc(sizeof(int32_t) * (n ? n : 1));
-    uint64_t *hoff = malloc(sizeof(uint64_t) * (n + 1));
+    if (i != n) { bufs_free(&B); return enif_make_badarg(env); }       /* improper list */
     uint64_t need[2] = {0, 0};
     /* resident-batch interface: upload, run the three stages once, then size and fetch the hit tables
-     * (bwt_align_batch's two-call pattern would run the pipeline twice).  One call at a time per handle. */
-    int rc = bwt_batch_set_reads(r->batch, bases, off, n);
+     * (bwt_align_batch's two-call pattern would run the pipeline twice).  The handle's batch is used under its lock. */
+    int nomem = 0;
+    enif_mutex_lock(r->lock);
+    int rc = bwt_batch_set_reads(r->batch, B.bases, B.off, n);
     if (!rc) rc = bwt_batch_run(r->batch, BWT_STAGE_EXTEND, NULL);
-    int32_t *score = NULL, *wlen = NULL; int64_t *pos = NULL, *woff = NULL; uint64_t *coff = NULL; char *cig = NULL;
     if (!rc) {
-        rc = bwt_batch_fetch_hits(r->batch, rstat, hoff, 0, 0, 0, 0, 0, 0, 0, 0, need);
+        rc = bwt_batch_fetch_hits(r->batch, B.rstat, B.hoff, 0, 0, 0, 0, 0, 0, 0, 0, need);
         if (rc == BWT_ENOSPC || rc == 0) {
-            score = malloc(4 * (need[0] + 1)); wlen = malloc(4 * (need[0] + 1));
-            pos = malloc(8 * (need[0] + 1)); woff = malloc(8 * (need[0] + 1));
-            coff = malloc(8 * (need[0] + 2)); cig = malloc(need[1] + 1);
-            rc = bwt_batch_fetch_hits(r->batch, rstat, hoff, score, pos, woff, wlen, coff, cig, need[0], need[1], need);
+            B.score = malloc(4 * (need[0] + 1)); B.wlen = malloc(4 * (need[0] + 1));
+            B.pos = malloc(8 * (need[0] + 1)); B.woff = malloc(8 * (need[0] + 1));
+            B.coff = malloc(8 * (need[0] + 2)); B.cig = malloc(need[1] + 1);
+            if (!B.score || !B.wlen || !B.pos || !B.woff || !B.coff || !B.cig) nomem = 1;
+            else rc = bwt_batch_fetch_hits(r->batch, B.rstat, B.hoff, B.score, B.pos, B.woff, B.wlen, B.coff, B.cig, need[0], need[1], need);
         }
     }
-    /* RefSeq of every hit in one device gather */
-    uint8_t *wins = NULL; uint64_t *woffs = NULL;
+    enif_mutex_unlock(r->lock);
+    if (nomem) return enomem(env, &B);
+    /* RefSeq of every hit in one device gather (index-level call: thread-safe, no batch involved) */
     if (!rc && need[0]) {
         uint64_t tot = 0;
-        woffs = malloc(8 * (need[0] + 1));
-        rc = bwt_ref1_gather(r->ix, woff, wlen, need[0], NULL, 0, woffs, &tot);
-        if (rc == BWT_ENOSPC) { wins = malloc(tot + 1); rc = bwt_ref1_gather(r->ix, woff, wlen, need[0], wins, tot, woffs, &tot); }
+        B.woffs = malloc(8 * (need[0] + 1));
+        if (!B.woffs) return enomem(env, &B);
+        rc = bwt_ref1_gather(r->ix, B.woff, B.wlen, need[0], NULL, 0, B.woffs, &tot);
+        if (rc == BWT_ENOSPC) {
+            B.wins = malloc(tot + 1);
+            if (!B.wins) return enomem(env, &B);
+            rc = bwt_ref1_gather(r->ix, B.woff, B.wlen, need[0], B.wins, tot, B.woffs, &tot);
+        }
     }
     ERL_NIF_TERM out = enif_make_list(env, 0);
     if (rc) out = mk_error(env, rc);
     else {
         for (i = n; i-- > 0;) {                       /* build the list back to front */
             ERL_NIF_TERM v;
-            if (rstat[i] == 1) v = enif_make_atom(env, "nothing");
-            else if (rstat[i] == -1) v = enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "bad_base"));
-            else if (rstat[i] == -2) v = enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "window_out_of_range"));
+            if (B.rstat[i] == 1) v = enif_make_atom(env, "nothing");
+            else if (B.rstat[i] == -1) v = enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "bad_base"));
+            else if (B.rstat[i] == -2) v = enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "window_out_of_range"));
             else {
                 v = enif_make_list(env, 0);
-                for (uint64_t h = hoff[i + 1]; h-- > hoff[i];) {
-                    const uint8_t *win = wins + woffs[h];
-                    ERL_NIF_TERM sc = enif_make_tuple2(env, enif_make_int(env, score[h]),
-                        enif_make_string_len(env, cig + coff[h], (size_t)(coff[h + 1] - coff[h]), ERL_NIF_LATIN1));
-                    ERL_NIF_TERM t = enif_make_tuple3(env, sc, enif_make_int64(env, pos[h]),
-                        enif_make_string_len(env, (char *)win, (size_t)wlen[h], ERL_NIF_LATIN1));
+                for (uint64_t h = B.hoff[i + 1]; h-- > B.hoff[i];) {
+                    const uint8_t *win = B.wins + B.woffs[h];
+                    ERL_NIF_TERM sc = enif_make_tuple2(env, enif_make_int(env, B.score[h]),
+                        enif_make_string_len(env, B.cig + B.coff[h], (size_t)(B.coff[h + 1] - B.coff[h]), ERL_NIF_LATIN1));
+                    ERL_NIF_TERM t = enif_make_tuple3(env, sc, enif_make_int64(env, B.pos[h]),
+                        enif_make_string_len(env, (const char *)win, (size_t)B.wlen[h], ERL_NIF_LATIN1));
                     v = enif_make_list_cell(env, t, v);
                 }
             }
-            out = enif_make_list_cell(env, enif_make_tuple2(env, names[i], v), out);
+            out = enif_make_list_cell(env, enif_make_tuple2(env, B.names[i], v), out);
         }
     }
-    free(names); free(off); free(bases); free(rstat); free(hoff);
-    free(score); free(wlen); free(pos); free(woff); free(coff); free(cig); free(wins); free(woffs);
+    bufs_free(&B);
     return out;
 }
 
