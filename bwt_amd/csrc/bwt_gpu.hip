@@ -564,9 +564,19 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u, nolist, nocount);
         else if (fast) {
             if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
+            uint32_t *dbgp = nullptr, dbg_g = 0;
+            if (const char *eg = getenv("BWT_SEED_DBG_GROUP")) { dbg_g = (uint32_t)atoi(eg); HIPCHK(hipMalloc(&dbgp, 4096 * 2)); HIPCHK(hipMemset(dbgp, 0xee, 4096 * 2)); }
             KLAUNCH(b, "fm_lookup", k_seed_fast, resident(3, (const void *)k_seed_fast), 256, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
                     b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
-                    b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
+                    b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>(), dbgp, dbg_g);
+            if (dbgp) {
+                std::vector<uint32_t> h(1024);
+                HIPCHK(hipMemcpyAsync(h.data(), dbgp, 4096, hipMemcpyDeviceToHost, b->stream));
+                HIPCHK(hipStreamSynchronize(b->stream));
+                const char *nm[] = {"c", "dst", "P", "qty", "seed0", "own.y", "key", "incl", "sorted0", "sorted1", "sorted2", "sorted3", "sorted4"};
+                for (int k = 0; k < 13; k++) { fprintf(stderr, "%s:", nm[k]); for (int i = 0; i < 64; i++) fprintf(stderr, " %x", h[64 * k + i]); fprintf(stderr, "\n"); }
+                (void)hipFree(dbgp);
+            }
             KLAUNCH(b, "fm_lookup_rest", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), 1, b->ulen,
                     (const uint32_t *)b->gq.as<uint32_t>(), (const unsigned int *)&b->ctr.as<Counters>()->n_gq);
         } else if (fuse) KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), lean ? 1 : 0, b->ulen, nolist, nocount);
@@ -905,6 +915,9 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         b->done |= BWT_STAGE_EXTEND;
     }
     if ((rc = fetch_counters(b))) return rc;
+    if (getenv("BWT_DEBUG_HANDBACK") && b->hctr.n_gq)
+        fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u groups: non-ACGT %u, table overflow %u, seeds below top level %u, >14 seeds in a task %u, >64 seeds in a read %u, >%d clusters %u\n",
+                b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[2], b->hctr.why[3], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
     if (counts) {
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
@@ -990,6 +1003,26 @@ extern "C" int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t
         return rc;
     HIPCHK(hipStreamSynchronize(b->stream));
     for (uint64_t i = 0; i < b->n_hits; i++) { if (score) score[i] = rec[i].score; if (pos) pos[i] = rec[i].pos; }
+    return 0;
+}
+
+extern "C" int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, bwt_hit_rec *hits, int64_t *win_off,
+                                        int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t hit_cap, uint64_t cig_cap,
+                                        uint64_t needed[2]) {
+    static_assert(sizeof(bwt_hit_rec) == sizeof(HitRec), "bwt_hit_rec is the device record");
+    if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits_raw: extend stage not run");
+    HIPCHK(hipSetDevice(b->device));
+    if (needed) { needed[0] = b->n_hits; needed[1] = b->cig_bytes; }
+    if ((hits || win_off || win_len || cig_off) && b->n_hits > hit_cap) return fail(BWT_ENOSPC, "hit capacity too small");
+    if (cigar && b->cig_bytes > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
+    if (!read_status && !hit_off && !hits && !win_off && !win_len && !cig_off && !cigar) return b->n_hits || b->cig_bytes ? BWT_ENOSPC : 0;
+    int rc;
+    if ((rc = d2h(b, read_status, b->r_status, b->n)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1)) ||
+        (rc = d2h(b, (HitRec *)hits, b->h_rec, b->n_hits)) || (rc = d2h(b, win_off, b->h_woff, b->n_hits)) ||
+        (rc = d2h(b, win_len, b->h_wlen, b->n_hits)) || (rc = d2h(b, cig_off, b->h_cigoff, b->n_hits + 1)) ||
+        (rc = d2h(b, cigar, b->h_cig, b->cig_bytes)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
 

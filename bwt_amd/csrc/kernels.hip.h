@@ -84,10 +84,10 @@ __device__ __forceinline__ uint32_t bitonic_stage(uint32_t p) {
     // keep the smaller of (p, o) where the stage's mask says so, else the larger: take the partner's value iff
     // (p < o) differs from the mask bit -- one compare into a lane mask, a scalar xor, one select (called by whole waves)
     constexpr unsigned long long M = bitonic_keep_min<K, J>();
+    // (the select takes the lane mask through inverse_ballot, not inline asm: the compiler has to see the VALU write to
+    // place the wait states a following DPP read of the result needs)
     const unsigned long long take = __ballot(p < o) ^ M;
-    uint32_t r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(o), "s"(take));
-    return r;
+    return __builtin_amdgcn_inverse_ballot_w64(take) ? o : p;
 }
 template <int K, int J>
 __device__ __forceinline__ uint32_t bitonic_merge(uint32_t p) {
@@ -953,7 +953,11 @@ __device__ __forceinline__ void bitonic_sort_upto3(uint32_t &a, uint32_t &b, uin
 // get_similar (sga.erl:42-64) on one sorted lane-per-seed register, on lane masks: p ascending in lanes [0, Pj), 0xffffffff
 // above.  The read's clusters (descending position) go to lanes 8 j .. 8 j + Kc - 1 of (cv0, cv1) = (S, D); returns Kc.
 __device__ __forceinline__ uint32_t sf_emit(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t j, uint32_t &cv0, uint32_t &cv1) {
-    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xF, 0xF, false);      // wave_shr:1
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xF, 0xF, false);            // wave_shr:1
+    // Keep the shift a plain v_mov_b32_dpp: folded into the subtraction (v_subrev_u32_dpp d, p, p wave_shr:1) this part
+    // returns prev - p instead of p - prev (measured, scripts/dpp_probe.hip) -- every lane after an equal or larger
+    // neighbour would then count as a run start.
+    asm volatile("" : "+v"(prev));
     const unsigned long long vmask = Pj >= 64 ? ~0ull : ((1ull << Pj) - 1ull);
     const unsigned long long sm = (__ballot(p - prev > BWT_TOLERANCE) | 1ull) & vmask;       // run starts (lane 0 always)
     unsigned long long em = ((sm >> 1) | (1ull << (Pj - 1))) & vmask;                        // run ends: the lane before a start, the last
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                     uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_cl,
-                                                    uint32_t *__restrict__ gq, Counters *ctr) {
+                                                    uint32_t *__restrict__ gq, Counters *ctr, uint32_t *dbg, uint32_t dbg_g) {
     __shared__ uint4 stag_[4 * 64 * 4];                          // per wave: 64 task slots x four 16-byte quarters
     __shared__ uint32_t rows_[4 * 8 * SF_ROW];                   // per wave: a row of seeds per read of the pass
     __shared__ uint32_t gq_[4 * 128];
@@ -1005,9 +1009,14 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t groups = (n + rw - 1) / rw;
-    uint32_t live = 0;
+    uint32_t live = 0, why = 0, why2 = 0;                          // why: hand-backs by reason (packed counts, flushed when a byte fills)
     unsigned long long Psum = 0;
     for (uint32_t g = wave; g < groups; g += nwaves) {
+        if (((why | why2) & 0x80808080u) && lane == 0) {
+            atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);
+            atomicAdd(&ctr->why[3], why >> 24); atomicAdd(&ctr->why[4], why2 & 0xffffu); atomicAdd(&ctr->why[5], why2 >> 16);
+        }
+        if ((why | why2) & 0x80808080u) { why = 0; why2 = 0; }
         const uint32_t r = g * rw + lread;
         const bool valid = lread < rw && r < n;
         const bool act = valid && e > 0;
@@ -1015,7 +1024,8 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         uint4 w = make_uint4(0, 0, 0, 0);
         if (act && endp >= 16) w = planes4(planes, endp - 16);
         const uint32_t key = ((w.x >> ksh) & kmask) | (((w.y >> ksh) & kmask) << m);
-        bool abn = act && (endp < 16 || ((w.z | w.w) & inread) != 0);
+        const bool abn0 = act && (endp < 16 || ((w.z | w.w) & inread) != 0);
+        bool abn = abn0;
         // the table reads: lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
         const uint32_t aw = act && wide ? 1u : 0u;
         uint4 Q0 = make_uint4(0, 0, 0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0;
@@ -1038,6 +1048,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t c = seeds ? wd + 1u : 0u;
         abn = abn || (act && wd == KT_OVF) || (seeds && (!wide || c > KT_INLINE));
         if (__ballot(abn)) {                                           // hand the group back
+            why += __ballot(abn0) ? 1u : __ballot(act && wd == KT_OVF) ? 1u << 8 : __ballot(seeds && !wide) ? 1u << 16 : 1u << 24;
             __builtin_amdgcn_wave_barrier();
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
             live -= (uint32_t)__popcll(__ballot(act));
@@ -1048,11 +1059,18 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t v = c | (seeds ? 0x10000u : 0u);
         const uint32_t incl = dpp_scan_incl_u32(v);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(hi_l, (int)incl);
-        const uint32_t lo = seg0 ? (uint32_t)__builtin_amdgcn_ds_bpermute(lo_l, (int)incl) : 0u;
+        // (unconditional: a bpermute under a divergent branch reads 0 from the lanes that are switched off)
+        const uint32_t lo_any = (uint32_t)__builtin_amdgcn_ds_bpermute(lo_l, (int)incl);
+        const uint32_t lo = seg0 ? lo_any : 0u;
         const uint32_t Pq = hi - lo, P = Pq & 0xffffu, qty = Pq >> 16;
         const uint32_t dst = (incl - v - lo) & 0xffffu;
         const bool fuse_read = valid && qty >= 2 && P > 0;             // sga.erl:42-43
+        if (dbg && g == dbg_g) {
+            dbg[lane] = c; dbg[64 + lane] = dst; dbg[128 + lane] = P; dbg[192 + lane] = qty; dbg[256 + lane] = own.z + nadd;
+            dbg[320 + lane] = own.y; dbg[384 + lane] = key; dbg[448 + lane] = incl;
+        }
         if (__ballot(fuse_read && P > SF_ROW)) {
+            why2 += 1u;
             __builtin_amdgcn_wave_barrier();
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
             live -= (uint32_t)__popcll(__ballot(act));
@@ -1112,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             if (take == 1) pp[0] = wave_sort_u32(pp[0]);
             else if (take == 2) wave_sort2_u32(pp[0], pp[1]);
             else bitonic_sort_upto3<64>(pp[0], pp[1], pp[2]);
+            if (dbg && g == dbg_g) { dbg[512 + 64 * jj[0] + lane] = pp[0]; if (take > 1) dbg[512 + 64 * jj[1] + lane] = pp[1]; if (take > 2) dbg[512 + 64 * jj[2] + lane] = pp[2]; }
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if ((uint32_t)t < take) {
@@ -1123,6 +1142,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         }
         __builtin_amdgcn_wave_barrier();
         if (over) {                                                    // a read with more clusters than its staging row holds
+            why2 += 1u << 16;
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
             live -= (uint32_t)__popcll(__ballot(act));
             continue;
@@ -1141,6 +1161,10 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         }
     }
     waveq_drain(q, gq, &ctr->n_gq);
+    if (lane == 0 && (why | why2)) {
+        atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);
+        atomicAdd(&ctr->why[3], why >> 24); atomicAdd(&ctr->why[4], why2 & 0xffffu); atomicAdd(&ctr->why[5], why2 >> 16);
+    }
     if (lane == 0 && (live | Psum)) {
         atomicAdd(&ctr->n_tasks, (unsigned long long)live);
         atomicAdd(&ctr->kt_lookups, (unsigned long long)live);

@@ -18,6 +18,8 @@ EXPORTS = [
     "bwt_batch_fetch_tasks", "bwt_batch_fetch_clusters", "bwt_batch_fetch_hits", "bwt_fm_check", "bwt_fm_rewrite",
     "bwt_build_index", "bwt_index_save", "bwt_index_export", "bwt_fastq_open", "bwt_fastq_close", "bwt_fastq_read_seqs", "bwt_ref1_gather",
     "bwt_seeds_generate_fs", "bwt_fs_find_seeds", "bwt_fs_find_seeds_index",
+    "bwt_batch_fetch_hits_raw", "bwt_pipe_create", "bwt_pipe_destroy", "bwt_pipe_acquire", "bwt_pipe_submit", "bwt_pipe_wait",
+    "bwt_pipe_release",
 ]
 
 
@@ -42,6 +44,16 @@ class BatchCounts(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+HIT_REC = np.dtype([("read", np.uint32), ("score", np.int32), ("pos", np.int64)])
+
+
+class PipeResult(C.Structure):
+    _fields_ = [("slot", C.c_uint32), ("n_reads", C.c_uint32), ("status", C.c_int32), ("n_hits", C.c_uint64),
+                ("cigar_bytes", C.c_uint64), ("read_status", C.c_void_p), ("hit_off", C.c_void_p), ("hits", C.c_void_p),
+                ("win_off", C.c_void_p), ("win_len", C.c_void_p), ("cig_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("counts", BatchCounts)]
+
+
 _lib = None
 
 
@@ -60,6 +72,7 @@ def load():
     lib.bwt_index_close.restype = None
     lib.bwt_fastq_close.restype = None
     lib.bwt_batch_destroy.restype = None
+    lib.bwt_pipe_destroy.restype = None
     lib.bwt_constants.restype = None
     _lib = lib
     return lib
@@ -392,3 +405,59 @@ class Batch:
                                          _p(cig), C.c_uint64(nh), C.c_uint64(cb), need))
         return dict(read_status=rs, hit_off=hoff, score=score, pos=pos, win_off=woff, win_len=wlen, cig_off=coff,
                     cigar=cig.tobytes())
+
+
+
+def _view(ptr, count, dtype):
+    """numpy view of `count` items of library-owned (pinned) memory"""
+    if not count:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class Pipe:
+    """bwt_pipe: `depth` slots with pinned host buffers; H2D, kernels and D2H of consecutive batches overlap."""
+
+    def __init__(self, index, depth=3):
+        self.index = index
+        self.h = C.c_void_p()
+        _chk(load().bwt_pipe_create(index.h, C.c_uint32(depth), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            load().bwt_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def acquire(self, bases_cap, reads_cap):
+        """-> (slot, bases u8 view, off u64 view) of a free slot's pinned input buffers, or None when all are busy."""
+        pb = C.c_void_p(); po = C.c_void_p(); slot = C.c_uint32(0)
+        rc = load().bwt_pipe_acquire(self.h, C.c_uint64(bases_cap), C.c_uint32(reads_cap), C.byref(pb), C.byref(po), C.byref(slot))
+        if rc == ENOSPC:
+            return None
+        _chk(rc)
+        return slot.value, _view(pb.value, bases_cap, np.uint8), _view(po.value, reads_cap + 1, np.uint64)
+
+    def submit(self, slot, n_reads):
+        _chk(load().bwt_pipe_submit(self.h, C.c_uint32(slot), C.c_uint32(n_reads)))
+
+    def wait(self):
+        """The oldest submitted batch -> dict of views into the slot's pinned result buffers (valid until release(slot))."""
+        r = PipeResult()
+        _chk(load().bwt_pipe_wait(self.h, C.byref(r)))
+        n, nh = r.n_reads, int(r.n_hits)
+        hits = _view(r.hits, nh, HIT_REC)
+        return dict(slot=r.slot, n_reads=n, read_status=_view(r.read_status, n, np.int32), hit_off=_view(r.hit_off, n + 1, np.uint64),
+                    hits=hits, score=hits["score"] if nh else np.zeros(0, np.int32), pos=hits["pos"] if nh else np.zeros(0, np.int64),
+                    win_off=_view(r.win_off, nh, np.int64), win_len=_view(r.win_len, nh, np.int32),
+                    cig_off=_view(r.cig_off, nh + 1, np.uint64), cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8).tobytes(),
+                    counts=r.counts.as_dict())
+
+    def release(self, slot):
+        _chk(load().bwt_pipe_release(self.h, C.c_uint32(slot)))

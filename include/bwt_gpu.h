@@ -222,6 +222,47 @@ int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, 
                          int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off,
                          char *cigar, uint64_t hit_cap, uint64_t cig_cap, uint64_t needed[2]);
 
+/* the hit tables as they sit in HBM, copied without any host-side reshaping: hits[h] = {read, score, pos} (the 16-byte
+ * record that is also gathered over RCCL).  Any output pointer may be NULL (skipped); with pinned destination buffers
+ * the copies run at full DMA speed.  BWT_ENOSPC + needed = {hits, cigar bytes} when a capacity is too small. */
+typedef struct { uint32_t read; int32_t score; int64_t pos; } bwt_hit_rec;
+int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, bwt_hit_rec *hits, int64_t *win_off,
+                             int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t hit_cap, uint64_t cig_cap,
+                             uint64_t needed[2]);
+
+/* ------------------------------------------------------------------ host-buffer pipeline
+ * The worker's `running` clause as a pipeline over host buffers: `depth` slots, each with a resident batch (own HIP
+ * stream), PINNED host buffers for the reads and the hit tables, and a host thread running
+ *     H2D of the reads -> seed search + clustering + extension -> D2H of the hit tables,
+ * so that the upload of batch k+1, the kernels of batch k and the download of batch k-1 overlap.
+ *   bwt_pipe_acquire  a free slot's pinned input buffers, sized for bases_cap bytes / reads_cap reads: the caller writes the
+ *                     concatenated reads and the n+1 offsets (off[0] = 0) straight into them; BWT_ENOSPC when every slot is
+ *                     busy (take a result first).
+ *   bwt_pipe_submit   starts the slot (asynchronous).
+ *   bwt_pipe_wait     blocks for the OLDEST submitted batch; the pointers in *res (pinned memory) stay valid until
+ *                     bwt_pipe_release(slot), which makes the slot free again.
+ * One caller thread per pipe (the handle is not re-entrant); several pipes may share an index. */
+typedef struct bwt_pipe bwt_pipe;
+typedef struct {
+    uint32_t slot, n_reads;
+    int32_t status;                  /* 0 or the BWT_E* code of the batch */
+    uint64_t n_hits, cigar_bytes;
+    const int32_t *read_status;      /* n_reads   (as bwt_align_batch) */
+    const uint64_t *hit_off;         /* n_reads+1 */
+    const bwt_hit_rec *hits;         /* n_hits    */
+    const int64_t *win_off;          /* n_hits    */
+    const int32_t *win_len;          /* n_hits    */
+    const uint64_t *cig_off;         /* n_hits+1  */
+    const char *cigar;               /* cigar_bytes */
+    bwt_batch_counts counts;
+} bwt_pipe_result;
+int bwt_pipe_create(bwt_index *idx, uint32_t depth /* 1..8 */, bwt_pipe **out);
+void bwt_pipe_destroy(bwt_pipe *p);
+int bwt_pipe_acquire(bwt_pipe *p, uint64_t bases_cap, uint32_t reads_cap, uint8_t **bases, uint64_t **off, uint32_t *slot);
+int bwt_pipe_submit(bwt_pipe *p, uint32_t slot, uint32_t n_reads);
+int bwt_pipe_wait(bwt_pipe *p, bwt_pipe_result *res);
+int bwt_pipe_release(bwt_pipe *p, uint32_t slot);
+
 #ifdef __cplusplus
 }
 #endif
