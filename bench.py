@@ -141,6 +141,46 @@ def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
     return out
 
 
+def host_pipeline(ix, read_sets, n_reads, depth=3, rounds=8):
+    """The host-buffer boundary as a pipeline (bwt_pipe): reads in PINNED host memory in, hit tables in pinned host memory
+    out, H2D + kernels + D2H of consecutive batches overlapped on `depth` slots.  Each slot's input buffers are filled once
+    (a FASTQ parser would write there); every submit uploads them again.  Never `value`."""
+    from bwt_amd import lib
+    pipe = lib.Pipe(ix, depth=depth)
+    nb = len(read_sets[0][0])
+    filled = set()
+
+    def submit_next():
+        s, pb, po = pipe.acquire(nb, n_reads)
+        if s not in filled:
+            bases, off = read_sets[s % len(read_sets)]
+            pb[:nb] = bases
+            po[:] = off
+            filled.add(s)
+        pipe.submit(s, n_reads)
+
+    def run(k):
+        submitted = done = hits = 0
+        while done < k:
+            while submitted < k and submitted - done < depth:
+                submit_next(); submitted += 1
+            r = pipe.wait()
+            hits += int(r["counts"]["n_hits"])
+            pipe.release(r["slot"])
+            done += 1
+        return hits
+    try:
+        run(depth)                                         # warm-up: device and pinned buffers sized, inputs in place
+        t0 = time.perf_counter()
+        hits = run(rounds)
+        dt = time.perf_counter() - t0
+        return {"reads_per_s": rounds * n_reads / dt, "ms_per_batch": dt / rounds * 1e3, "depth": depth, "batches": rounds,
+                "hits_per_batch": hits // rounds,
+                "what": "pinned host reads in -> pinned host hit tables + CIGAR text out, H2D / kernels / D2H overlapped (bwt_pipe)"}
+    finally:
+        pipe.close()
+
+
 def load_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -161,6 +201,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the workload's own)")
     ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-batch", action="store_true", help="one resident batch instead of two alternating ones")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the host-buffer pipeline measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,8 +264,20 @@ def main():
                    " and one indel of 1-5 bp with p=0.2 (2x150 bp mates aligned independently, as the reference does)"
                    if wl == "paired150" else ""))
 
+    # two distinct read batches, both resident in HBM before the timed region; the steps alternate between them
     batch = lib.Batch(ix)
-    batch.set_reads(bases, off)                         # resident in HBM before the timed region
+    batch.set_reads(bases, off)
+    batches = [batch]
+    if not args.single_batch:
+        if wl.startswith("config2"):
+            bases2, off2 = synth_reads(ref, n_reads, length, seed=1002 + rank, max_subs=0)
+        else:
+            bases2, off2 = synth_reads(ref, n_reads, length, seed={"grch38": 5, "chr1": 4, "paired150": 6}[wl] * 1000 + 500 + rank,
+                                       max_subs=2, indel_p=0.2 if wl == "paired150" else 0.0)
+        b2 = lib.Batch(ix)
+        b2.set_reads(bases2, off2)
+        batches.append(b2)
+    step_no = [0]
     gather = (world > 1 or force_gather) and stages == lib.STAGE_EXTEND
     lo, _ = shard.slab(n_reads * world, world, rank)
     hit_buf = None
@@ -232,6 +286,8 @@ def main():
 
     def step():
         nonlocal hit_buf
+        batch = batches[step_no[0] % len(batches)]
+        step_no[0] += 1
         c = batch.run(stages)
         if gather:
             # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0, double-buffered so that the
@@ -260,7 +316,9 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    batch.profile(True)                                 # hipEvents around every kernel, on the library's own stream
+    for b_ in batches:
+        b_.profile(True)                                # hipEvents around every kernel, on the library's own streams
+    step_no[0] = 0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -270,7 +328,11 @@ def main():
     dt = time.perf_counter() - t0
     if gather and rank == 0:
         counts["gathered_hits"] = gathered[0]
-    kt = batch.kernel_times()
+    kt = {}
+    for b_ in batches:
+        for k, v in b_.kernel_times().items():
+            a = kt.setdefault(k, {"ms": 0.0, "launches": 0})
+            a["ms"] += v["ms"]; a["launches"] += v["launches"]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -292,9 +354,20 @@ def main():
         io_terms = counts["n_reads"] * length + 16 * counts["n_tasks"]
         kdepth, kwide = ix.ktable
         unfused = counts["n_small"] / max(counts["n_reads"], 1) if kwide else 1.0
+        fast = "fm_lookup_rest" in per                     # k_seed_fast took the ordinary groups, k_seed_tasks the handed-back ones
+        rw_ = 64 // max(1, length // 8)
+        back = min(1.0, counts.get("n_handed_back", 0) * rw_ / max(counts["n_reads"], 1)) if fast else 1.0
+        narrow = counts["n_reads"] * sum(1 for k in range(length // 8) if 8 <= length - 8 * k < kdepth) if kdepth else 0
+        wide_l = max(0, counts["n_lookups"] - narrow) if kwide else 0
+        narrow_l = counts["n_lookups"] - wide_l
+        # seed stage, both kernels: Lq per read in, one table entry per task (64 B / 8 B), 16 B per read (r_pend, r_P, r_qty) + 4 B (r_K)
+        # + 8 B per cluster out; the general kernel also writes the sub-read table (4 B per task) and the rows of the reads it
+        # does not cluster itself (16 B per task)
+        seed_common = counts["n_reads"] * (length + 20) + 64 * wide_l + 8 * narrow_l + 8 * counts["n_clusters"]
+        general_extra = 4 * counts["n_tasks"] + int(16 * counts["n_tasks"] * unfused)
         models = {
-            "fm_lookup": ("k_seed_tasks", counts["n_reads"] * (length + 16) + (64 if kwide else 8) * counts["n_lookups"]
-                          + 4 * counts["n_tasks"] + int(16 * counts["n_tasks"] * unfused) + 8 * counts["n_clusters"]),
+            "fm_lookup": (("k_seed_fast", int(seed_common * (1.0 - back))) if fast else ("k_seed_tasks", seed_common + general_extra)),
+            "fm_lookup_rest": ("k_seed_tasks", int((seed_common + general_extra) * back)),
             "fm_search": ("k_search_pending" if "fm_lookup" in per else "k_search",
                           128 * counts["lf_steps"] + (0 if "fm_lookup" in per else io_terms)),
             "cluster_small": ("k_cluster_small", 4 * counts["sa_reads"] + 16 * counts["n_tasks"] + 8 * counts["n_clusters"]),
@@ -309,7 +382,7 @@ def main():
         if "fm_lookup" in roofs:
             # random 64-byte reads are rated per line (profiles/r1/rand_access_microbench.txt: 47-55 G lines/s on this part,
             # 4..16 bytes used per line or all 64 alike): one table line per task
-            glines = counts["n_lookups"] / (per["fm_lookup"] / 1e3) / 1e9
+            glines = counts["n_lookups"] * ((1.0 - back) if fast else 1.0) / (per["fm_lookup"] / 1e3) / 1e9
             roofs["fm_lookup"]["random_lines"] = {"achieved_Glines_per_s": glines, "measured_ceiling_Glines_per_s": 47.0,
                                                   "frac": glines / 47.0}
         dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
@@ -350,6 +423,8 @@ def main():
         if stages == lib.STAGE_EXTEND:
             batch.fetch_hits()
         line["pcie_inclusive_reads_per_s"] = n_reads / (time.perf_counter() - t0)
+        if stages == lib.STAGE_EXTEND and not args.no_pipeline:
+            line["host_pipeline"] = host_pipeline(ix, [(bases, off)] + ([(bases2, off2)] if len(batches) > 1 else []), n_reads)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1,
                                                 batch=batch)

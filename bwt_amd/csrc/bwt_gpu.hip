@@ -564,18 +564,19 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u, nolist, nocount);
         else if (fast) {
             if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
-            uint32_t *dbgp = nullptr, dbg_g = 0;
-            if (const char *eg = getenv("BWT_SEED_DBG_GROUP")) { dbg_g = (uint32_t)atoi(eg); HIPCHK(hipMalloc(&dbgp, 4096 * 2)); HIPCHK(hipMemset(dbgp, 0xee, 4096 * 2)); }
-            KLAUNCH(b, "fm_lookup", k_seed_fast, resident(3, (const void *)k_seed_fast), 256, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
-                    b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
-                    b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>(), dbgp, dbg_g);
-            if (dbgp) {
-                std::vector<uint32_t> h(1024);
-                HIPCHK(hipMemcpyAsync(h.data(), dbgp, 4096, hipMemcpyDeviceToHost, b->stream));
-                HIPCHK(hipStreamSynchronize(b->stream));
-                const char *nm[] = {"c", "dst", "P", "qty", "seed0", "own.y", "key", "incl", "sorted0", "sorted1", "sorted2", "sorted3", "sorted4"};
-                for (int k = 0; k < 13; k++) { fprintf(stderr, "%s:", nm[k]); for (int i = 0; i < 64; i++) fprintf(stderr, " %x", h[64 * k + i]); fprintf(stderr, "\n"); }
-                (void)hipFree(dbgp);
+            {
+                const char *env_pad = getenv("BWT_SEED_LDS_PAD");      // experiments: extra dynamic LDS per block (lowers the occupancy)
+                const size_t pad = env_pad ? (size_t)atoi(env_pad) : 0;
+                uint32_t grid = resident(3, (const void *)k_seed_fast);
+                if (pad) {
+                    int per_cu = 8;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_seed_fast, 256, pad);
+                    grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * std::max(1, std::min(per_cu, 8))));
+                }
+                ProfScope ps(b, "fm_lookup");
+                hipLaunchKernelGGL(k_seed_fast, dim3(grid), dim3(256), pad, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
+                                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
+                                   b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
             }
             KLAUNCH(b, "fm_lookup_rest", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), 1, b->ulen,
                     (const uint32_t *)b->gq.as<uint32_t>(), (const unsigned int *)&b->ctr.as<Counters>()->n_gq);

@@ -927,6 +927,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
 // on lane masks in SGPRs (run starts by one ballot; run lengths, the emit test and the cluster count are scalar ops; only
 // the one or two emitted clusters touch the VALU again), no task-table rows, one store of the group's results at the end.
 #define SF_ROW 64
+#define SF_SLOT 5
 __device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
@@ -985,12 +986,12 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                     uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_cl,
-                                                    uint32_t *__restrict__ gq, Counters *ctr, uint32_t *dbg, uint32_t dbg_g) {
-    __shared__ uint4 stag_[4 * 64 * 4];                          // per wave: 64 task slots x four 16-byte quarters
+                                                    uint32_t *__restrict__ gq, Counters *ctr) {
+    __shared__ uint4 stag_[4 * 64 * SF_SLOT];                    // per wave: 64 task slots x four 16-byte quarters (+ 16 bytes: slots 80 bytes apart, no bank conflicts)
     __shared__ uint32_t rows_[4 * 8 * SF_ROW];                   // per wave: a row of seeds per read of the pass
     __shared__ uint32_t gq_[4 * 128];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint4 *stag = stag_ + wv * 256;
+    uint4 *stag = stag_ + wv * 64 * SF_SLOT;
     uint32_t *rows = rows_ + wv * 8 * SF_ROW;
     WaveQ q;
     q.buf = gq_ + wv * 128; q.have = 0;
@@ -1011,6 +1012,44 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     const uint32_t groups = (n + rw - 1) / rw;
     uint32_t live = 0, why = 0, why2 = 0;                          // why: hand-backs by reason (packed counts, flushed when a byte fills)
     unsigned long long Psum = 0;
+    // Software pipeline: when a pass starts on group g, g's table entries are already in flight (their loads were issued a
+    // pass earlier, before the sorts of the group before it) and so are the plane windows of the group after g.  The pass
+    // moves g's entries into the LDS staging area, issues the next group's table loads into the same registers and the
+    // plane loads of the group after that, and only then works on g -- from LDS, with no global load to wait for.
+    // (Entries of lanes that ask for none are left undefined on purpose -- a zero default would make the compiler merge it
+    // with the loaded value right behind the load, i.e. wait for it; nothing reads them: such lanes have no seeds.  The plane
+    // words travel raw, two 16-byte loads per lane, and are aligned to the window when the next pass picks them up.)
+    uint4 Q0, Q1, Q2, Q3;
+    unsigned long long nent;
+    bool abn0_c = false;
+    auto planes_raw = [&](uint32_t g2, uint4 &pa, uint4 &pb) {     // plane words around the window [e - 16, e) of my sub-read in group g2
+        const uint32_t r2 = g2 * rw + lread;
+        const uint64_t endp2 = (uint64_t)r2 * ulen + (uint64_t)e;
+        const bool has = g2 < groups && lread < rw && r2 < n && e > 0 && endp2 >= 16;
+        const uint64_t wi = has ? (endp2 - 16) >> 5 : 0ull;        // no such task: word 0 (cached, never looked at)
+        pa = ((const uint4 *)planes)[wi]; pb = ((const uint4 *)planes)[wi + 1];
+    };
+    auto issue_table = [&](uint32_t g2, const uint4 &pa, const uint4 &pb) {   // keys of group g2 from its plane words, table loads issued
+        const uint32_t r2 = g2 * rw + lread;
+        const bool act2 = g2 < groups && lread < rw && r2 < n && e > 0;
+        const uint64_t endp2 = (uint64_t)r2 * ulen + (uint64_t)e;
+        const uint32_t sh = (uint32_t)(endp2 - 16) & 31u;
+        const uint32_t wx = __builtin_amdgcn_alignbit(pb.x, pa.x, sh), wy = __builtin_amdgcn_alignbit(pb.y, pa.y, sh);
+        const uint32_t wz = __builtin_amdgcn_alignbit(pb.z, pa.z, sh), ww = __builtin_amdgcn_alignbit(pb.w, pa.w, sh);
+        const uint32_t key = ((wx >> ksh) & kmask) | (((wy >> ksh) & kmask) << m);
+        abn0_c = act2 && (endp2 < 16 || ((wz | ww) & inread) != 0);
+        // lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
+        const uint32_t aw = act2 && wide ? 1u : 0u;
+        { const uint32_t kt = quad_bcast<0>(key); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<1>(key); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<2>(key); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        if (act2 && !wide) nent = ix.ktab[loff + key];
+    };
+    uint4 wa, wb;
+    planes_raw(wave, wa, wb);
+    issue_table(wave, wa, wb);
+    planes_raw(wave + nwaves, wa, wb);
     for (uint32_t g = wave; g < groups; g += nwaves) {
         if (((why | why2) & 0x80808080u) && lane == 0) {
             atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);
@@ -1020,28 +1059,19 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t r = g * rw + lread;
         const bool valid = lread < rw && r < n;
         const bool act = valid && e > 0;
-        const uint64_t endp = (uint64_t)r * ulen + (uint64_t)e;
-        uint4 w = make_uint4(0, 0, 0, 0);
-        if (act && endp >= 16) w = planes4(planes, endp - 16);
-        const uint32_t key = ((w.x >> ksh) & kmask) | (((w.y >> ksh) & kmask) << m);
-        const bool abn0 = act && (endp < 16 || ((w.z | w.w) & inread) != 0);
+        const bool abn0 = abn0_c;
         bool abn = abn0;
-        // the table reads: lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
-        const uint32_t aw = act && wide ? 1u : 0u;
-        uint4 Q0 = make_uint4(0, 0, 0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0;
-        { const uint32_t kt = quad_bcast<0>(key); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        { const uint32_t kt = quad_bcast<1>(key); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        { const uint32_t kt = quad_bcast<2>(key); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        unsigned long long nent = 0;
-        if (act && !wide) nent = ix.ktab[loff + key];
         live += (uint32_t)__popcll(__ballot(act));
         // transpose through LDS: afterwards slot t of the staging area holds the whole entry of lane t
-        const uint32_t qb = (lane & ~3u) * 4 + ql;
-        stag[qb] = Q0; stag[qb + 4] = Q1; stag[qb + 8] = Q2; stag[qb + 12] = Q3;
+        const uint32_t qb = (lane & ~3u) * SF_SLOT + ql;
+        stag[qb] = Q0; stag[qb + SF_SLOT] = Q1; stag[qb + 2 * SF_SLOT] = Q2; stag[qb + 3 * SF_SLOT] = Q3;
         __builtin_amdgcn_wave_barrier();
-        uint4 own = stag[lane * 4];
-        if (!wide) { own.x = (uint32_t)nent; own.y = (uint32_t)(nent >> 32); }
+        uint4 own = stag[lane * SF_SLOT];
+        if (!wide) { own.x = act ? (uint32_t)nent : 0u; own.y = act ? (uint32_t)(nent >> 32) : 0u; }
+        if (!act) own.y = 0;
+        // the next group's table loads, the plane loads of the group after it
+        issue_table(g + nwaves, wa, wb);
+        planes_raw(g + 2 * nwaves, wa, wb);
         const uint32_t wd = own.y & KT_OVF, nn = own.y >> 28;
         // bwa.erl:31-45 at the end of the search: the range check applies unless a step came back not_found (n < m)
         const bool seeds = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
@@ -1065,10 +1095,6 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t Pq = hi - lo, P = Pq & 0xffffu, qty = Pq >> 16;
         const uint32_t dst = (incl - v - lo) & 0xffffu;
         const bool fuse_read = valid && qty >= 2 && P > 0;             // sga.erl:42-43
-        if (dbg && g == dbg_g) {
-            dbg[lane] = c; dbg[64 + lane] = dst; dbg[128 + lane] = P; dbg[192 + lane] = qty; dbg[256 + lane] = own.z + nadd;
-            dbg[320 + lane] = own.y; dbg[384 + lane] = key; dbg[448 + lane] = incl;
-        }
         if (__ballot(fuse_read && P > SF_ROW)) {
             why2 += 1u;
             __builtin_amdgcn_wave_barrier();
@@ -1083,19 +1109,19 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             if (cw > 0) row[0] = own.z + nadd;
             if (cw > 1) row[1] = own.w + nadd;
             if (__ballot(cw > 2)) {
-                const uint4 t = stag[lane * 4 + 1];
+                const uint4 t = stag[lane * SF_SLOT + 1];
                 if (cw > 2) row[2] = t.x + nadd;
                 if (cw > 3) row[3] = t.y + nadd;
                 if (cw > 4) row[4] = t.z + nadd;
                 if (cw > 5) row[5] = t.w + nadd;
                 if (__ballot(cw > 6)) {
-                    const uint4 t2 = stag[lane * 4 + 2];
+                    const uint4 t2 = stag[lane * SF_SLOT + 2];
                     if (cw > 6) row[6] = t2.x + nadd;
                     if (cw > 7) row[7] = t2.y + nadd;
                     if (cw > 8) row[8] = t2.z + nadd;
                     if (cw > 9) row[9] = t2.w + nadd;
                     if (__ballot(cw > 10)) {
-                        const uint4 t3 = stag[lane * 4 + 3];
+                        const uint4 t3 = stag[lane * SF_SLOT + 3];
                         if (cw > 10) row[10] = t3.x + nadd;
                         if (cw > 11) row[11] = t3.y + nadd;
                         if (cw > 12) row[12] = t3.z + nadd;
@@ -1130,7 +1156,6 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             if (take == 1) pp[0] = wave_sort_u32(pp[0]);
             else if (take == 2) wave_sort2_u32(pp[0], pp[1]);
             else bitonic_sort_upto3<64>(pp[0], pp[1], pp[2]);
-            if (dbg && g == dbg_g) { dbg[512 + 64 * jj[0] + lane] = pp[0]; if (take > 1) dbg[512 + 64 * jj[1] + lane] = pp[1]; if (take > 2) dbg[512 + 64 * jj[2] + lane] = pp[2]; }
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if ((uint32_t)t < take) {
