@@ -917,8 +917,8 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     }
     if ((rc = fetch_counters(b))) return rc;
     if (getenv("BWT_DEBUG_HANDBACK") && b->hctr.n_gq)
-        fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u groups: non-ACGT %u, table overflow %u, seeds below top level %u, >14 seeds in a task %u, >64 seeds in a read %u, >%d clusters %u\n",
-                b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[2], b->hctr.why[3], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
+        fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u groups: non-ACGT %u, table overflow %u, >64 seeds in a read %u, >%d clusters %u\n",
+                b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
     if (counts) {
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;

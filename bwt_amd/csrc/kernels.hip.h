@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
 // same length (ulen), the table is K = 15 with SA values in its top level, and in the group of 64 / maxT reads a wave
 // takes per pass
 //   * no read holds a base outside ACGT (the windows [e-16, e) of a read's sub-reads cover the whole read),
-//   * every table entry fits (no KT_OVF), every seed list came with its entry (<= 14 seeds, top level),
+//   * every table entry fits (no KT_OVF),
 //   * every read has at most 64 seeds and at most CL_STAGE clusters.
 // A group that fails any of these is handed back untouched -- its index goes to gq and k_seed_tasks runs on that list
 // afterwards -- so the results are k_seed_tasks' by construction; this kernel only has to be right on what it keeps.
@@ -941,47 +941,57 @@ __device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
 __device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t idx, uint32_t v) {
     return (threadIdx.x & 63u) == idx ? v : old;
 }
-template <int K, int J>
-__device__ __forceinline__ void bitonic_merge3(uint32_t &a, uint32_t &b, uint32_t &c) {
-    a = bitonic_stage<K, J>(a); b = bitonic_stage<K, J>(b); c = bitonic_stage<K, J>(c);
-    if constexpr (J > 1) bitonic_merge3<K, J / 2>(a, b, c);
+// Sort of N registers (one u32 per lane each, N independent sorts side by side), ascending, for k_seed_fast.  A bitonic
+// network in its "mirror" form: the merge of two sorted runs of K/2 first pairs lane l with lane l ^ (K - 1), then halves the
+// distance (l ^ K/4, l ^ K/8, ...), and in EVERY stage the lower lane of a pair keeps the smaller value.  The select then
+// needs no compare and no lane mask in SGPRs: r = bfi(lower ? ~0 : 0, min(p, o), max(p, o)) with six per-lane constants
+// (is bit b of my lane number clear?), and the partner comes folded into v_min_u32_dpp / v_max_u32_dpp for 15 of the 21
+// stages (quad_perm, row_half_mirror, row_mirror, row_ror:8); the other six go through the LDS crossbar (ds_swizzle,
+// one ds_bpermute).  3 VALU per DPP stage, 1 DS + 3 VALU otherwise, no SALU -- the compare / ballot / xor / select form of
+// bitonic_stage costs 6 issue slots per stage, and this kernel is bound by instruction issue.
+struct SortMasks { uint32_t m1, m2, m4, m8, m16, m32; int mirror63; };
+__device__ __forceinline__ SortMasks sort_masks() {
+    const uint32_t l = threadIdx.x & 63u;
+    SortMasks M;
+    M.m1 = (l & 1u) ? 0u : ~0u; M.m2 = (l & 2u) ? 0u : ~0u; M.m4 = (l & 4u) ? 0u : ~0u; M.m8 = (l & 8u) ? 0u : ~0u;
+    M.m16 = (l & 16u) ? 0u : ~0u; M.m32 = (l & 32u) ? 0u : ~0u;
+    M.mirror63 = (int)((l ^ 63u) << 2);
+    return M;
 }
-template <int K>
-__device__ __forceinline__ void bitonic_sort_upto3(uint32_t &a, uint32_t &b, uint32_t &c) {
-    if constexpr (K > 2) bitonic_sort_upto3<K / 2>(a, b, c);
-    bitonic_merge3<K, K / 2>(a, b, c);
+__device__ __forceinline__ uint32_t ms_keep(uint32_t p, uint32_t o, uint32_t lower) {
+    const uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
+    return (mn & lower) | (mx & ~lower);
 }
-// get_similar (sga.erl:42-64) on one sorted lane-per-seed register, on lane masks: p ascending in lanes [0, Pj), 0xffffffff
-// above.  The read's clusters (descending position) go to lanes 8 j .. 8 j + Kc - 1 of (cv0, cv1) = (S, D); returns Kc.
-__device__ __forceinline__ uint32_t sf_emit(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t j, uint32_t &cv0, uint32_t &cv1) {
-    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xF, 0xF, false);            // wave_shr:1
-    // Keep the shift a plain v_mov_b32_dpp: folded into the subtraction (v_subrev_u32_dpp d, p, p wave_shr:1) this part
-    // returns prev - p instead of p - prev (measured, scripts/dpp_probe.hip) -- every lane after an equal or larger
-    // neighbour would then count as a run start.
-    asm volatile("" : "+v"(prev));
-    const unsigned long long vmask = Pj >= 64 ? ~0ull : ((1ull << Pj) - 1ull);
-    const unsigned long long sm = (__ballot(p - prev > BWT_TOLERANCE) | 1ull) & vmask;       // run starts (lane 0 always)
-    unsigned long long em = ((sm >> 1) | (1ull << (Pj - 1))) & vmask;                        // run ends: the lane before a start, the last
-    const uint32_t nthr = 2 + qj / 7;                                                        // sga.erl:46
-    const unsigned long long A = ~sm;
-    unsigned long long ok = A;                                                               // lane e ends a run of >= nthr <=> no start in (e - nthr + 1, e]
-    for (uint32_t k = 1; k + 1 < nthr; k++) ok &= A << k;
-    em &= ok;
-    const uint32_t Kc = (uint32_t)__popcll(em);
-    if (Kc > CL_STAGE) return Kc;
-    uint32_t kk = 0;
-    while (em) {
-        const int e = 63 - __clzll((long long)em);
-        em &= ~(1ull << e);
-        const int s0 = 63 - __clzll((long long)(sm & ((2ull << e) - 1ull)));
-        const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)p, e), pf = (uint32_t)__builtin_amdgcn_readlane((int)p, s0);
-        cv0 = set_lane(cv0, 8 * j + kk, pe);
-        cv1 = set_lane(cv1, 8 * j + kk, pe - pf);
-        kk++;
+template <int CTRL, int N>
+__device__ __forceinline__ void ms_dpp(uint32_t (&p)[N], uint32_t lower) {
+#pragma unroll
+    for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p[t], CTRL, 0xF, 0xF, true), lower);
+}
+template <int XOR, int N>
+__device__ __forceinline__ void ms_swz(uint32_t (&p)[N], uint32_t lower) {          // partner lane ^ XOR inside 32 lanes
+    uint32_t o[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)p[t], (XOR << 10) | 0x1f);
+#pragma unroll
+    for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], lower);
+}
+template <int N>
+__device__ __forceinline__ void mirror_sort64(uint32_t (&p)[N], const SortMasks &M) {
+    enum { X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HALF_MIRROR = 0x141, ROW_MIRROR = 0x140, ROR8 = 0x128 };
+    ms_dpp<X1>(p, M.m1);                                                                                  // runs of 2
+    ms_dpp<X3>(p, M.m2); ms_dpp<X1>(p, M.m1);                                                             // 4
+    ms_dpp<HALF_MIRROR>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);                               // 8
+    ms_dpp<ROW_MIRROR>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);            // 16
+    ms_swz<31>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);   // 32
+    {
+        uint32_t o[N];
+#pragma unroll
+        for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(M.mirror63, (int)p[t]);
+#pragma unroll
+        for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], M.m32);
     }
-    return Kc;
+    ms_swz<16>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);   // 64
 }
-
 __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
@@ -1007,11 +1017,12 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     const uint64_t loff = kt_level_off(m > KT_MIN ? m : KT_MIN);
     const uint32_t shsk = BWT_MIN_LEN * slot;
     const int hi_l = (int)(((seg0 + maxT - 1) & 63u) << 2), lo_l = (int)(((seg0 - 1) & 63u) << 2);
+    const SortMasks SM = sort_masks();
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t groups = (n + rw - 1) / rw;
     uint32_t live = 0, why = 0, why2 = 0;                          // why: hand-backs by reason (packed counts, flushed when a byte fills)
-    unsigned long long Psum = 0;
+    unsigned long long Pacc = 0;                                   // seeds clustered here, per leader lane
     // Software pipeline: when a pass starts on group g, g's table entries are already in flight (their loads were issued a
     // pass earlier, before the sorts of the group before it) and so are the plane windows of the group after g.  The pass
     // moves g's entries into the LDS staging area, issues the next group's table loads into the same registers and the
@@ -1076,9 +1087,9 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         // bwa.erl:31-45 at the end of the search: the range check applies unless a step came back not_found (n < m)
         const bool seeds = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
         const uint32_t c = seeds ? wd + 1u : 0u;
-        abn = abn || (act && wd == KT_OVF) || (seeds && (!wide || c > KT_INLINE));
+        abn = abn || (act && wd == KT_OVF);
         if (__ballot(abn)) {                                           // hand the group back
-            why += __ballot(abn0) ? 1u : __ballot(act && wd == KT_OVF) ? 1u << 8 : __ballot(seeds && !wide) ? 1u << 16 : 1u << 24;
+            why += __ballot(abn0) ? 1u : 1u << 8;
             __builtin_amdgcn_wave_barrier();
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
             live -= (uint32_t)__popcll(__ballot(act));
@@ -1105,7 +1116,19 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         // every lane copies its own seeds (+ N + Shift) into its read's row
         {
             uint32_t *row = rows + lread * SF_ROW + dst;
-            const uint32_t cw = fuse_read ? c : 0u;
+            // seeds that did not come with the entry -- everything of a task that ended below the top level, the seeds past the
+            // first 14 of a top-level task -- are read from the SA, the whole wave on one task's range at a time (rare)
+            const uint32_t inl = wide ? KT_INLINE : 0u;
+            unsigned long long more = __ballot(fuse_read && c > inl);
+            while (more) {
+                const int src = __ffsll((long long)more) - 1;
+                more &= more - 1ull;
+                const uint32_t sp_s = (uint32_t)__builtin_amdgcn_readlane((int)own.x, src), c_s = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
+                const uint32_t add_s = (uint32_t)__builtin_amdgcn_readlane((int)nadd, src), from_s = (uint32_t)__builtin_amdgcn_readlane((int)inl, src);
+                const uint32_t dst_s = (uint32_t)__builtin_amdgcn_readlane((int)(lread * SF_ROW + dst), src);
+                if (lane >= from_s && lane < c_s) rows[dst_s + lane] = ix.sa[sp_s - 1 + lane] + add_s;
+            }
+            const uint32_t cw = fuse_read ? (c < inl ? c : inl) : 0u;
             if (cw > 0) row[0] = own.z + nadd;
             if (cw > 1) row[1] = own.w + nadd;
             if (__ballot(cw > 2)) {
@@ -1131,58 +1154,82 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // sort + get_similar, up to three reads side by side (independent chains of 21 stages)
+        // Sort, up to three reads side by side.  Each sorted read goes back into its row, and its run starts (one ballot:
+        // lane i starts a run iff p[i] - p[i-1] > TOLERANCE) into the read's leader lane; get_similar itself then runs ONCE
+        // for all reads of the pass, on 64-bit lane arithmetic in the leader lanes (sga.erl:42-64).
         unsigned long long bf = __ballot(fuse_read && slot == 0);        // bit seg0 of every read to cluster
-        uint32_t cv0 = 0xffffffffu, cv1 = 0, kcv = 0;
-        unsigned long long Pgrp = 0;
-        bool over = false;
+        uint32_t smlo = 0, smhi = 0;
         uint32_t left = (uint32_t)__popcll(bf);
         while (left) {
             const uint32_t take = left == 1 ? 1u : (left == 2 || left == 4) ? 2u : 3u;
-            uint32_t jj[3], Pj[3], qj[3], pp[3];
+            uint32_t jj[3], pp[3];
+            int bb[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                jj[t] = 0; Pj[t] = 1; qj[t] = 0; pp[t] = 0xffffffffu;
+                jj[t] = 0; bb[t] = 0; pp[t] = 0xffffffffu;
                 if ((uint32_t)t < take) {
-                    const int b = __ffsll((long long)bf) - 1;
+                    bb[t] = __ffsll((long long)bf) - 1;
                     bf &= bf - 1ull;
-                    jj[t] = (uint32_t)b / maxT;
-                    Pj[t] = (uint32_t)__builtin_amdgcn_readlane((int)P, b);
-                    qj[t] = (uint32_t)__builtin_amdgcn_readlane((int)qty, b);
-                    pp[t] = lane < Pj[t] ? rows[jj[t] * SF_ROW + lane] : 0xffffffffu;
-                    Pgrp += Pj[t];
+                    jj[t] = (uint32_t)bb[t] / maxT;
+                    const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, bb[t]);
+                    pp[t] = lane < Pj ? rows[jj[t] * SF_ROW + lane] : 0xffffffffu;
                 }
             }
-            if (take == 1) pp[0] = wave_sort_u32(pp[0]);
-            else if (take == 2) wave_sort2_u32(pp[0], pp[1]);
-            else bitonic_sort_upto3<64>(pp[0], pp[1], pp[2]);
+            if (take == 1) { uint32_t a[1] = {pp[0]}; mirror_sort64(a, SM); pp[0] = a[0]; }
+            else if (take == 2) { uint32_t a[2] = {pp[0], pp[1]}; mirror_sort64(a, SM); pp[0] = a[0]; pp[1] = a[1]; }
+            else mirror_sort64(pp, SM);
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if ((uint32_t)t < take) {
-                    const uint32_t Kc = sf_emit(pp[t], Pj[t], qj[t], jj[t], cv0, cv1);
-                    over = over || Kc > CL_STAGE;
-                    kcv = set_lane(kcv, jj[t] * maxT, Kc);
+                    rows[jj[t] * SF_ROW + lane] = pp[t];
+                    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pp[t], 0x138, 0xF, 0xF, false);   // wave_shr:1
+                    // Keep the shift a plain v_mov_b32_dpp: folded into the subtraction (v_subrev_u32_dpp d, p, p wave_shr:1) this
+                    // part returns prev - p instead of p - prev (measured, scripts/dpp_probe.hip).
+                    asm volatile("" : "+v"(prev));
+                    const unsigned long long sm = __ballot(pp[t] - prev > BWT_TOLERANCE) | 1ull;     // (lanes >= P: masked below)
+                    smlo = set_lane(smlo, (uint32_t)bb[t], (uint32_t)sm);
+                    smhi = set_lane(smhi, (uint32_t)bb[t], (uint32_t)(sm >> 32));
                 }
             left -= take;
         }
         __builtin_amdgcn_wave_barrier();
-        if (over) {                                                    // a read with more clusters than its staging row holds
+        // get_similar in the leader lanes: run ends = the lane before a start + the last seed; a run of >= 2 + Qty div 7 (:46)
+        // seeds ending in lane e <=> no start in (e - nthr + 1, e]; clusters in descending position order
+        const bool lead = fuse_read && slot == 0;
+        const unsigned long long vmask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+        const unsigned long long sm = (((unsigned long long)smhi << 32) | smlo) & vmask;
+        const unsigned long long A = ~sm;
+        const uint32_t tq = qty / 7;
+        unsigned long long ok = A;
+        for (uint32_t k = 1; __ballot(lead && k <= tq); k++) if (k <= tq) ok &= A << k;
+        unsigned long long em = lead ? ((sm >> 1) | (1ull << ((P - 1) & 63u))) & vmask & ok : 0ull;
+        const uint32_t Kc = (uint32_t)__popcll(em);
+        if (__ballot(Kc > CL_STAGE)) {                                 // a read with more clusters than its staging row holds
             why2 += 1u << 16;
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
             live -= (uint32_t)__popcll(__ballot(act));
             continue;
         }
-        Psum += Pgrp;
         // the group's results
-        if (cv0 != 0xffffffffu) {
-            uint32_t *dstp = r_cl + ((uint64_t)g * rw + (lane >> 3)) * (2 * CL_STAGE) + 2 * (lane & 7u);
-            dstp[0] = cv0; dstp[1] = cv1;
+        {
+            uint32_t *cl = r_cl + (uint64_t)r * (2 * CL_STAGE);
+            const uint32_t *row = rows + lread * SF_ROW;
+            while (__ballot(em != 0)) {
+                if (em) {
+                    const int e1 = 63 - __clzll((long long)em);
+                    em &= ~(1ull << e1);
+                    const int s1 = 63 - __clzll((long long)(sm & ((2ull << e1) - 1ull)));
+                    const uint32_t pe = row[e1], pf = row[s1];
+                    cl[0] = pe; cl[1] = pe - pf;
+                    cl += 2;
+                }
+            }
         }
         if (valid && slot == 0) {
             r_pend[r] = 0ull;
             r_P[r] = 0;
             r_qty[r] = qty | (fuse_read ? RQ_DONE : 0u);
-            if (fuse_read) r_K[r] = kcv;
+            if (fuse_read) { r_K[r] = Kc; Pacc += P; }
         }
     }
     waveq_drain(q, gq, &ctr->n_gq);
@@ -1190,6 +1237,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);
         atomicAdd(&ctr->why[3], why >> 24); atomicAdd(&ctr->why[4], why2 & 0xffffu); atomicAdd(&ctr->why[5], why2 >> 16);
     }
+    const unsigned long long Psum = wave_sum_u64(Pacc);
     if (lane == 0 && (live | Psum)) {
         atomicAdd(&ctr->n_tasks, (unsigned long long)live);
         atomicAdd(&ctr->kt_lookups, (unsigned long long)live);

@@ -138,6 +138,6 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags, kt_lookups;
     unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, n_small;
     unsigned int n_gq, pad_;   // groups k_seed_fast handed back to k_seed_tasks
-    unsigned int why[6];       // ... by reason: base outside ACGT / table overflow / seeds below the top level / > 14 seeds in a task / > 64 seeds in a read / > CL_STAGE clusters
+    unsigned int why[6];       // ... by reason: [0] base outside ACGT, [1] table overflow, [4] > 64 seeds in a read, [5] > CL_STAGE clusters
 };
 

@@ -6,7 +6,8 @@
 __global__ void probe(const uint32_t *in, uint32_t *out, uint32_t Pj, uint32_t qj) {
     const uint32_t lane = threadIdx.x;
     uint32_t a = lane < Pj ? in[lane] : 0xffffffffu, b = in[64 + lane], c = in[128 + lane];
-    bitonic_sort_upto3<64>(a, b, c);
+    { uint32_t v[3] = {a, b, c}; mirror_sort64(v, sort_masks()); a = v[0]; b = v[1]; c = v[2]; }
+    out[640 + lane] = b; out[704 + lane] = c;
     out[lane] = a;
     uint32_t cv0 = 0xffffffffu, cv1 = 0;
     const uint32_t Kc = sf_emit(a, Pj, qj, 1, cv0, cv1);
@@ -33,7 +34,7 @@ __global__ void probe(const uint32_t *in, uint32_t *out, uint32_t Pj, uint32_t q
 int main() {
     const uint32_t s1[21] = {0x1aba34, 0x2d6f12, 0x1ee45f, 0x229c63, 0x256c18, 0xca0f0, 0x2591fa, 0x1bd1d5, 0x3dc20, 0x9505, 0x10c99, 0x3dc20, 0x3dc21, 0x3dc20,
                              0x14af7a, 0x181a46, 0x1c8685, 0x246109, 0x299ce6, 0x2b4234, 0x2ccb26};
-    uint32_t h[192], o[640], *din, *dout;
+    uint32_t h[192], o[768], *din, *dout;
     for (int i = 0; i < 192; i++) h[i] = 0x12345u * (uint32_t)(i + 7) % 3000017u;
     for (int i = 0; i < 21; i++) h[i] = s1[i];
     (void)hipMalloc(&din, sizeof h); (void)hipMalloc(&dout, sizeof o);
@@ -43,6 +44,17 @@ int main() {
     const char *nm[] = {"sorted", "cv0", "cv1", "Kc", "prev", "start", "scan", "subrev_dpp", "mov_dpp_bc"};
     printf("sm %x ok %x em %x nthr %u\n", o[576], o[577], o[578], o[579]);
     for (int k = 0; k < 9; k++) { printf("%s:", nm[k]); for (int i = 0; i < 24; i++) printf(" %x", o[64 * k + i]); printf("\n"); }
+    {   // the three sorted registers against std::sort
+        int bads = 0;
+        for (int k = 0; k < 3; k++) {
+            uint32_t ref[64];
+            for (int i = 0; i < 64; i++) ref[i] = (k == 0 && i >= 21) ? 0xffffffffu : h[64 * k + i];
+            for (int i = 0; i < 64; i++) for (int j = i + 1; j < 64; j++) if (ref[j] < ref[i]) { uint32_t t = ref[i]; ref[i] = ref[j]; ref[j] = t; }
+            const uint32_t *got = k == 0 ? o : o + 640 + 64 * (k - 1);
+            for (int i = 0; i < 64; i++) bads += got[i] != ref[i];
+        }
+        printf("mirror_sort64 mismatches %d\n", bads);
+    }
     uint32_t run = 0; int bad = 0;
     for (int i = 0; i < 64; i++) { run += h[i] & 15u; bad += o[384 + i] != run; }
     printf("scan mismatches %d; expected cluster (3dc21, 1) in lane 8\n", bad);
