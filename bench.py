@@ -141,7 +141,7 @@ def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
     return out
 
 
-def host_pipeline(ix, read_sets, n_reads, depth=3, rounds=8):
+def host_pipeline(ix, read_sets, n_reads, depth=3, rounds=12):
     """The host-buffer boundary as a pipeline (bwt_pipe): reads in PINNED host memory in, hit tables in pinned host memory
     out, H2D + kernels + D2H of consecutive batches overlapped on `depth` slots.  Each slot's input buffers are filled once
     (a FASTQ parser would write there); every submit uploads them again.  Never `value`."""

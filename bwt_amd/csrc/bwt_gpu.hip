@@ -310,6 +310,7 @@ struct bwt_batch {
     uint32_t ulen = 0;                 // common read length of the batch, 0 if the lengths differ
     bool rows_kept = true;             // every read's task-table rows were written (not so after a lean fused run)
     bool fused = false;                // ... and clustered what it could (r_K zeroed, RQ_DONE reads staged in r_cl)
+    bool cand_pending = false;         // the candidate arrays are still to be made (by the prefilter, from the per-read clusters)
     // reads
     DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
@@ -464,30 +465,58 @@ extern "C" int bwt_batch_kernel_times(bwt_batch *b, char *names, uint32_t names_
     return (int)k;
 }
 
+// lengths of the reads of a batch, checked where the offsets already are: {min, max, flags (1: offsets decrease, 2: a read > 65535)}
+__global__ __launch_bounds__(256) static void k_off_check(const uint64_t *__restrict__ off, uint32_t n, unsigned int *__restrict__ out) {
+    uint32_t mn = 0xffffffffu, mx = 0, bad = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t a = off[i], b = off[i + 1];
+        if (b < a) bad |= 1u;
+        else {
+            const uint64_t l = b - a;
+            if (l > 65535) bad |= 2u;
+            const uint32_t l32 = l > 0xffffffffull ? 0xffffffffu : (uint32_t)l;
+            mn = l32 < mn ? l32 : mn; mx = l32 > mx ? l32 : mx;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)mn, o, 64), b = (uint32_t)__shfl_xor((int)mx, o, 64), c = (uint32_t)__shfl_xor((int)bad, o, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx; bad |= c;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); if (bad) atomicOr(&out[2], bad); }
+}
+
 extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n) {
     if (!b || (!bases && n) || !off) return fail(BWT_EINVAL, "bwt_batch_set_reads: null argument");
     HIPCHK(hipSetDevice(b->device));
-    uint32_t maxlq = 0, minlq = 0xffffffffu;
-    for (uint32_t i = 0; i < n; i++) {
-        if (off[i + 1] < off[i]) return fail(BWT_EINVAL, "bwt_batch_set_reads: offsets must be non-decreasing");
-        uint64_t l = off[i + 1] - off[i];
-        if (l > 65535) return fail(BWT_EINVAL, "bwt_batch_set_reads: read longer than 65535 bases");
-        maxlq = std::max<uint32_t>(maxlq, (uint32_t)l);
-        minlq = std::min<uint32_t>(minlq, (uint32_t)l);
-    }
+    if (n && off[n] < off[0]) return fail(BWT_EINVAL, "bwt_batch_set_reads: offsets must be non-decreasing");
     const uint64_t total = n ? off[n] - off[0] : 0;
     int rc;
-    if ((rc = b->bases.ensure(total + 16)) || (rc = b->off.ensure(((size_t)n + 1) * 8))) return rc;
-    // offsets are rebased to 0 on the device
-    std::vector<uint64_t> o((size_t)n + 1);
-    for (uint32_t i = 0; i <= n; i++) o[i] = off[i] - off[0];
+    if ((rc = b->bases.ensure(total + 16)) || (rc = b->off.ensure(((size_t)n + 1) * 8)) || (rc = b->scan_tmp.ensure(64))) return rc;
+    // The offsets go up as they are when they start at 0 (with pinned caller buffers both copies are plain DMA); otherwise
+    // they are rebased on the host first.  The per-read length checks run on the device, over the uploaded offsets.
+    std::vector<uint64_t> o;
+    const uint64_t *src = off;
+    if (off[0] != 0) {
+        o.resize((size_t)n + 1);
+        for (uint32_t i = 0; i <= n; i++) o[i] = off[i] - off[0];
+        src = o.data();
+    }
     if (total) HIPCHK(hipMemcpyAsync(b->bases.p, bases + off[0], total, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->off.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->off.p, src, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    unsigned int chk[3] = {0xffffffffu, 0u, 0u};
+    unsigned int *dchk = b->scan_tmp.as<unsigned int>();
+    HIPCHK(hipMemcpyAsync(dchk, chk, sizeof chk, hipMemcpyHostToDevice, b->stream));
+    if (n) hipLaunchKernelGGL(k_off_check, dim3(std::min<uint32_t>(cdiv(n, 256), 1024)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, dchk);
+    HIPCHK(hipMemcpyAsync(chk, dchk, sizeof chk, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    b->n = 0; b->done = 0; b->n_cand = 0; b->n_hits = 0; b->cig_bytes = 0;
+    if (chk[2] & 1u) return fail(BWT_EINVAL, "bwt_batch_set_reads: offsets must be non-decreasing");
+    if (chk[2] & 2u) return fail(BWT_EINVAL, "bwt_batch_set_reads: read longer than 65535 bases");
+    const uint32_t maxlq = n ? chk[1] : 0, minlq = n ? chk[0] : 0;
     b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
     b->ulen = (n && minlq == maxlq) ? maxlq : 0;       // every read the same length: offsets are r * ulen (no offset load in the seed kernel)
     b->total_bases = total;
-    b->done = 0; b->n_cand = 0; b->n_hits = 0; b->cig_bytes = 0;
     return 0;
 }
 
@@ -617,7 +646,7 @@ static int stage_search(bwt_batch *b, bool lean) {
     return 0;
 }
 
-static int stage_cluster(bwt_batch *b) {
+static int stage_cluster(bwt_batch *b, bool to_extend) {
     const uint32_t n = b->n, maxT = b->maxT;
     int rc;
     if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
@@ -697,6 +726,11 @@ static int stage_cluster(bwt_batch *b) {
         (rc = b->c_qoff.ensure(nc * 8)) || (rc = b->c_qlen.ensure(nc * 4)) || (rc = b->c_woff.ensure(nc * 8)) ||
         (rc = b->c_wlen.ensure(nc * 4)))
         return rc;
+    if (to_extend) {                                                          // the prefilter makes the candidates itself (run_sw)
+        b->cand_pending = true;
+        b->hctr.max_w = 0; b->hctr.max_lq = 0;
+        return 0;
+    }
     KLAUNCH(b, "candidates", k_candidates, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
             b->seed_off.as<uint64_t>(), b->clus_off.as<uint64_t>(), b->pos.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_cl.as<uint32_t>(),
             b->c_read.as<uint32_t>(),
@@ -718,8 +752,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         (rc = b->c_ciglen.ensure(nc * 4 + 4)) || (rc = b->fpq.ensure(nc * 4 + 4)) || (rc = b->tq.ensure(nc * 4 + 4)) ||
         (rc = b->dq.ensure(nc * 4 + 4)) || (rc = b->tq2.ensure(nc * 4 + 4)))
         return rc;
-    if (nc == 0) return 0;
-    const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
+    if (nc == 0) { b->cand_pending = false; return 0; }
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, b->device);
     if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
@@ -735,8 +768,21 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
     if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
         io.dq = b->dq.as<uint32_t>();
-        KLAUNCH(b, "sw_prefilter", k_sw_prefilter, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc);   // quad per candidate
+        CandSrc src{};
+        if (b->cand_pending) {
+            // quad per READ: the window arithmetic of k_candidates happens on the way, the candidate arrays are written once
+            src.off = b->off.as<uint64_t>(); src.r_K = b->r_K.as<uint32_t>(); src.seed_off = b->seed_off.as<uint64_t>();
+            src.clus_off = b->clus_off.as<uint64_t>(); src.pos = b->pos.as<uint32_t>(); src.r_qty = b->r_qty.as<uint32_t>();
+            src.r_cl = b->r_cl.as<uint32_t>(); src.c_S = b->c_S.as<uint32_t>(); src.c_D = b->c_D.as<uint32_t>(); src.c_qoff = b->c_qoff.as<uint64_t>();
+            src.c_qlen = b->c_qlen.as<uint32_t>(); src.c_woff = b->c_woff.as<int64_t>(); src.c_wlen = b->c_wlen.as<uint32_t>();
+            KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, std::min<uint32_t>(cdiv((uint64_t)b->n * 4, 256), 2048), 256, io, b->n, src);
+            b->cand_pending = false;
+            if ((rc = fetch_counters(b))) return rc;                       // max_w / max_lq size the DP kernels' LDS and slabs
+            max_w = b->hctr.max_w; max_lq = b->hctr.max_lq;
+        } else
+            KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc, src);   // quad per candidate
     }
+    const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
 
     // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
     // lane-per-alignment work would run a handful of waves for the full serial length of a DP
@@ -882,6 +928,7 @@ static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, 
                         uint32_t max_lq, int32_t shift, const uint32_t *qplanes = nullptr,
                         const uint32_t *wplanes = nullptr) {
     for (int attempt = 0; attempt < 8; attempt++) {
+        if (attempt && b->ix) { max_w = b->hctr.max_w; max_lq = b->hctr.max_lq; }    // (known since the first attempt's prefilter)
         int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq, qplanes, wplanes);
         if (rc) return rc;
         // clear the sticky CIGAR-overflow flag before counting
@@ -906,7 +953,11 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         b->done = BWT_STAGE_SEARCH;
     }
     if (stages & (BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
-        if ((rc = stage_cluster(b))) return rc;
+        {
+            const char *env_pf = getenv("BWT_SW_PREFILTER"), *env_fc = getenv("BWT_SW_FUSE_CAND");   // experiments: 0 = separate k_candidates
+            const bool to_extend = (stages & BWT_STAGE_EXTEND) && !(env_pf && env_pf[0] == '0') && !(env_fc && env_fc[0] == '0');
+            if ((rc = stage_cluster(b, to_extend))) return rc;
+        }
         b->done |= BWT_STAGE_CLUSTER;
     }
     if (stages & BWT_STAGE_EXTEND) {
@@ -1193,7 +1244,7 @@ extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, 
         const bool ok = cst[i] == CS_OK;
         if (status) status[i] = ok ? 0 : 1;
         if (score) score[i] = ok ? csc[i] : 0;
-        if (ok) o += cl[i];
+        if (ok) o += cl[i] & ~CIG_DIAG;
     }
     if (cig_off) cig_off[n] = o;
     if (o > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");

@@ -140,8 +140,13 @@ __device__ __forceinline__ uint64_t block_scan_u64(uint64_t s, uint64_t &excl) {
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict__ in, uint64_t *__restrict__ bsum, uint64_t n) {
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint64_t s = 0;
+    if ((uint64_t)(blockIdx.x + 1) * SCAN_TILE <= n) {             // a full tile: two 16-byte loads per thread
+        const uint4 a = *(const uint4 *)(in + base), b = *(const uint4 *)(in + base + 4);
+        s = (uint64_t)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) s += base + k < n ? in[base + k] : 0u;
+        for (int k = 0; k < SCAN_ITEMS; k++) s += base + k < n ? in[base + k] : 0u;
+    }
     uint64_t excl;
     const uint64_t total = block_scan_u64(s, excl);
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
@@ -173,15 +178,32 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t n
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
                                                        const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) {
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    const bool full = (uint64_t)(blockIdx.x + 1) * SCAN_TILE <= n;  // a full tile: 16-byte loads and stores
     uint32_t v[SCAN_ITEMS];
     uint64_t s = 0;
+    if (full) {
+        const uint4 a = *(const uint4 *)(in + base), b = *(const uint4 *)(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+        for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    }
     uint64_t excl;
     (void)block_scan_u64(s, excl);
     uint64_t run = bsum[blockIdx.x] + excl;
+    if (full) {
+        uint64_t o[SCAN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+        for (int k = 0; k < SCAN_ITEMS; k++) { o[k] = run; run += v[k]; }
+        ulonglong2 *dst = (ulonglong2 *)(out + base);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS / 2; k++) dst[k] = make_ulonglong2(o[2 * k], o[2 * k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
 }
 
@@ -1775,6 +1797,7 @@ __global__ __launch_bounds__(256) void k_candidates(uint32_t n, const uint64_t *
 //   SW_TRACE  integer, 2-bit directions to a per-wave HBM slab [strip][j][lane], fused traceback.
 //   SW_FP     the same with IEEE doubles (any N / IUPAC: sigma may return 1.6), fused traceback.
 #define SW_R 16
+#define CIG_DIAG 0x80000000u      // c_ciglen flag: the text is "<window length>M" and was not written to the slot
 enum { DIR_LEFT = 0, DIR_UP = 1, DIR_UL = 2, DIR_UNDEF = 3 };
 enum { SW_SCORE = 0, SW_TRACE = 1, SW_FP = 2 };
 
@@ -2033,22 +2056,64 @@ __device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ plane
     uint32_t lo1, hi1;
     return quad_planes4(planes, pos, ql, lo1, hi1);
 }
-__global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items) {
+// FROM_READS: the candidates are made on the way (k_candidates folded in): a quad takes a READ, walks its clusters
+// (src: the cluster stage's per-read results), does the window arithmetic of worker_loop (src/worker_bwt.erl:86-90), writes
+// the candidate arrays the later kernels read and goes on with the candidate -- one launch and one round trip of the
+// candidate arrays less.  n_items = reads then; the candidate index is clus_off[r] + k.
+struct CandSrc {
+    const uint64_t *off; const uint32_t *r_K; const uint64_t *seed_off, *clus_off; const uint32_t *pos, *r_qty, *r_cl;
+    uint32_t *c_S, *c_D; uint64_t *c_qoff; uint32_t *c_qlen; int64_t *c_woff; uint32_t *c_wlen;
+};
+template <bool FROM_READS>
+__global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
     __shared__ uint32_t wq_[4][2][128];
     WaveQ qfp, qdp;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
     const uint32_t *qp = io.qplanes, *wp = io.wplanes;
     const int ql = (int)(threadIdx.x & 3);
-    const uint32_t stride = (gridDim.x * blockDim.x) >> 2;                  // candidates per sweep
+    const uint32_t stride = (gridDim.x * blockDim.x) >> 2;                  // candidates (reads) per sweep
     const uint32_t first = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 2;
+    unsigned long long cells = 0, wbytes = 0;                               // FROM_READS: what k_candidates totals
+    uint32_t maxw = 0, maxlq = 0;
     for (uint32_t c0 = first; c0 < n_items; c0 += stride) {                 // whole waves iterate together
-        const uint32_t c = c0 + ((threadIdx.x & 63) >> 2);
+      const uint32_t item = c0 + ((threadIdx.x & 63) >> 2);
+      uint32_t K_r = 1, kmax = 1;
+      uint64_t co_r = 0, qo_r = 0;
+      uint32_t lq_r = 0;
+      const uint32_t *cl_r = nullptr;
+      if (FROM_READS) {
+          K_r = item < n_items ? src.r_K[item] : 0u;
+          kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(K_r));
+          if (K_r) {
+              qo_r = src.off[item]; lq_r = (uint32_t)(src.off[item + 1] - qo_r);
+              co_r = src.clus_off[item];
+              // clusters staged by the seed kernels (RQ_DONE) sit in the read's r_cl row, the cluster kernels' in its slice of pos
+              cl_r = (src.r_qty[item] & RQ_DONE) ? src.r_cl + (uint64_t)item * (2 * CL_STAGE) : src.pos + src.seed_off[item];
+              maxlq = lq_r > maxlq ? lq_r : maxlq;
+          }
+      }
+      for (uint32_t kc = 0; kc < kmax; kc++) {                              // (one pass unless FROM_READS)
+        const uint32_t c = FROM_READS ? (uint32_t)(co_r + kc) : item;
         int route = 0;                 // 0 nothing (idle / out of range / settled), 1 fp64 queue, 2 DP queue
         // quad-uniform from here on: the four lanes of a quad hold the same candidate
-        const bool have = c < n_items;
-        const uint32_t lq = have ? io.c_qlen[c] : 0u, w = have ? io.c_wlen[c] : 0u;
-        const int64_t wo = have ? io.c_woff[c] : 0;
-        const uint64_t qo = have ? io.c_qoff[c] : 0;
+        const bool have = FROM_READS ? kc < K_r : c < n_items;
+        uint32_t lq, w;
+        int64_t wo;
+        uint64_t qo;
+        if (FROM_READS) {
+            const uint32_t S = have ? cl_r[2 * kc] : 0u, D = have ? cl_r[2 * kc + 1] : 0u;
+            lq = have ? lq_r : 0u; w = have ? lq_r + D : 0u; qo = qo_r;
+            wo = (int64_t)S - (int64_t)w + BWT_REF_EXT;
+            if (have && ql == 0) {
+                src.c_S[c] = S; src.c_D[c] = D; src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_wlen[c] = w; src.c_woff[c] = wo;
+                cells += (unsigned long long)lq * w; wbytes += w;
+                maxw = w > maxw ? w : maxw;
+            }
+        } else {
+            lq = have ? io.c_qlen[c] : 0u; w = have ? io.c_wlen[c] : 0u;
+            wo = have ? io.c_woff[c] : 0;
+            qo = have ? io.c_qoff[c] : 0;
+        }
         const bool oor = wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0;
         const bool live = have && !oor;
         if (have && oor && ql == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
@@ -2137,20 +2202,35 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items)
         if (clean) {
             if (!done) { if (ql == 0) io.c_status[c] = CS_PENDING; route = 2; }
             else if (ql == 0) {
-                uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
-                int p = (int)io.cig_stride, len = 0;
-                cig_emit(slot, p, len, lq, 'M');
+                // "<Lq>M": only its length is recorded (CIG_DIAG: k_hits_write prints it from the window length, which equals
+                // Lq here) -- no scattered write into the candidate's text slot
+                uint32_t len = 2;
+                for (uint32_t v = lq; v >= 10; v /= 10) len++;
                 io.c_score[c] = score;
-                io.c_ciglen[c] = (uint32_t)len;
-                io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                io.c_ciglen[c] = len | (square ? CIG_DIAG : 0u);
+                if (!square) {                                   // (exact match on a shifted diagonal: the window is wider than Lq)
+                    uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+                    int p = (int)io.cig_stride, l2 = 0;
+                    cig_emit(slot, p, l2, lq, 'M');
+                }
+                io.c_status[c] = len > io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
             }
         }
         // the two queues, staged in LDS (one atomic per 64 entries)
         waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
         waveq_push(qdp, route == 2 && ql == 0, c, io.dq, &io.ctr->dq_count);
+      }
     }
     waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
     waveq_drain(qdp, io.dq, &io.ctr->dq_count);
+    if (FROM_READS) {
+        cells = wave_sum_u64(cells); wbytes = wave_sum_u64(wbytes);
+        maxw = wave_max_u32(maxw); maxlq = wave_max_u32(maxlq);
+        if ((threadIdx.x & 63) == 0 && maxlq) {
+            atomicAdd(&io.ctr->sw_cells, cells); atomicAdd(&io.ctr->window_bytes, wbytes);
+            atomicMax(&io.ctr->max_w, maxw); atomicMax(&io.ctr->max_lq, maxlq);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2682,7 +2762,7 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
     if (b > a) st = 0;
     for (uint64_t k = a; k < b; k++) {
         const int32_t cs = c_status[k];
-        if (cs == CS_OK) { nh++; cb += c_ciglen[k]; }
+        if (cs == CS_OK) { nh++; cb += c_ciglen[k] & ~CIG_DIAG; }
         else if (cs == CS_WINDOW_OOR) st = -2;
         else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
     }
@@ -2711,12 +2791,18 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
     uint64_t ho = hit_off[r], co = cigb_off[r];
     for (uint64_t k = b; k-- > a;) {                  // reverse of the cluster order
         if (c_status[k] != CS_OK) continue;
-        const uint32_t wl = c_wlen[k], cl = c_ciglen[k];
+        const uint32_t wl = c_wlen[k], clf = c_ciglen[k], cl = clf & ~CIG_DIAG;
         HitRec hr; hr.read = r; hr.score = c_score[k];
         hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
         h_rec[ho] = hr; h_woff[ho] = c_woff[k]; h_wlen[ho] = (int32_t)wl; h_cigoff[ho] = co;
-        const uint8_t *src = cig + k * (uint64_t)cig_stride + (cig_stride - cl);
-        for (uint32_t x = 0; x < cl; x++) h_cig[co + x] = src[x];
+        if (clf & CIG_DIAG) {                                      // "<W>M" with W = Lq (settled by the prefilter on a square window)
+            h_cig[co + cl - 1] = (uint8_t)'M';
+            uint32_t v = wl;
+            for (uint32_t x = cl - 1; x-- > 0;) { h_cig[co + x] = (uint8_t)('0' + v % 10); v /= 10; }
+        } else {
+            const uint8_t *src = cig + k * (uint64_t)cig_stride + (cig_stride - cl);
+            for (uint32_t x = 0; x < cl; x++) h_cig[co + x] = src[x];
+        }
         ho++; co += cl;
     }
 }

@@ -57,6 +57,9 @@ struct bwt_pipe {
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false;
+    // one upload and one download at a time: slots that copy side by side share the link and stay in lock step (all upload,
+    // all compute, all download -- no overlap between the phases); taking turns staggers them into a real pipeline
+    std::mutex h2d_turn, d2h_turn;
 };
 
 static void slot_worker(bwt_pipe *p, uint32_t si) {
@@ -68,7 +71,11 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
             p->cv.wait(lk, [&] { return p->stop || s.state == QUEUED; });
             if (p->stop) return;
         }
-        int rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
+        int rc;
+        {
+            std::lock_guard<std::mutex> turn(p->h2d_turn);
+            rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
+        }
         if (!rc) rc = bwt_batch_run(s.batch, BWT_STAGE_EXTEND, &s.counts);
         uint64_t need[2] = {0, 0};
         if (!rc) {
@@ -80,10 +87,12 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
                 if ((rc = s.rstat.ensure(((size_t)s.n + 1) * 4)) || (rc = s.hoff.ensure(((size_t)s.n + 1) * 8)) ||
                     (rc = s.rec.ensure((nh + 1) * 16)) || (rc = s.woff.ensure((nh + 1) * 8)) || (rc = s.wlen.ensure((nh + 1) * 4)) ||
                     (rc = s.cigoff.ensure((nh + 2) * 8)) || (rc = s.cig.ensure((size_t)need[1] + 16))) {
-                } else
+                } else {
+                    std::lock_guard<std::mutex> turn(p->d2h_turn);
                     rc = bwt_batch_fetch_hits_raw(s.batch, (int32_t *)s.rstat.p, (uint64_t *)s.hoff.p, (bwt_hit_rec *)s.rec.p,
                                                   (int64_t *)s.woff.p, (int32_t *)s.wlen.p, (uint64_t *)s.cigoff.p, (char *)s.cig.p,
                                                   need[0], need[1], need);
+                }
             }
         }
         {
