@@ -663,11 +663,17 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         KLAUNCH(b, "read_counts", k_read_counts, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, maxT, b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),
                 b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>(), b->ctr.as<Counters>());
-    uint64_t total_seeds = 0;
+    uint64_t total_seeds = 0, ncand = 0;
+    bool all_clustered = false;
     if (b->fused) {
-        // the seed kernel clustered what it could: the per-read seed slices (seed_off, pos) are only needed if reads are left
+        // the seed kernel clustered what it could: the per-read seed slices (seed_off, pos) are only needed if reads are left.
+        // Most batches leave none: the candidate offsets are scanned before the counters come back, so that such a batch needs
+        // one synchronisation here, not two.
+        if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
+        HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
         if ((rc = fetch_counters(b))) return rc;                               // sync #1
-        if (b->hctr.n_small || b->hctr.n_mid2 || b->hctr.n_mid4 || b->hctr.n_big) {
+        all_clustered = !(b->hctr.n_small || b->hctr.n_mid2 || b->hctr.n_mid4 || b->hctr.n_big);
+        if (!all_clustered) {
             if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
             HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
             HIPCHK(hipStreamSynchronize(b->stream));
@@ -681,7 +687,8 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
     if (total_seeds > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 seeds: split it");
     if ((rc = b->pos.ensure(total_seeds * 4 + 16))) return rc;
     b->n_small = b->hctr.n_small;
-    if (b->fused && b->hctr.n_small < n / 8) {
+    if (all_clustered) {
+    } else if (b->fused && b->hctr.n_small < n / 8) {
         // few reads left for the wave-per-read kernel: list them first (a wave per read of the batch costs ~1 ms in launches alone)
         if (b->hctr.n_small) {
             if ((rc = b->smallq.ensure((size_t)b->hctr.n_small * 4 + 64))) return rc;
@@ -699,7 +706,7 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                 b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
                 b->r_K.as<uint32_t>(), (const uint32_t *)nullptr, (const unsigned int *)nullptr);
-    if (b->hctr.n_mid2)
+    if (b->hctr.n_mid2 && !all_clustered)
         KLAUNCH(b, "cluster_wave2", k_cluster_wave<2>, cdiv((uint64_t)b->hctr.n_mid2 * 64, 256), 256, b->ix->d, b->hctr.n_mid2,
                 b->mid2q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
@@ -714,10 +721,11 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                 b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
                 b->r_K.as<uint32_t>());
-    if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
-    uint64_t ncand = 0;
-    HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    if ((rc = fetch_counters(b))) return rc;                                   // sync #2
+    if (!all_clustered) {
+        if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
+        HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = fetch_counters(b))) return rc;                               // sync #2
+    }
     if (b->hctr.err_flags & 8) return fail(BWT_EHIP, "internal: cluster queue count mismatch");
     if (ncand > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "batch produced more than 2^32 candidates: split it");
     b->n_cand = ncand;
@@ -903,24 +911,23 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
             b->r_status.as<int32_t>(), b->ctr.as<Counters>());
     if ((rc = dev_scan(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), n))) return rc;
     if ((rc = dev_scan(b, b->r_cigb.as<uint32_t>(), b->cigb_off.as<uint64_t>(), n))) return rc;
-    uint64_t tot[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(&tot[0], b->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(&tot[1], b->cigb_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    if ((rc = fetch_counters(b))) return rc;                                   // sync
-    b->n_hits = tot[0]; b->cig_bytes = tot[1];
-    const size_t nh = (size_t)tot[0] + 1;
+    // the hit tables are sized by their bounds (a hit per candidate, a full text slot per hit), so that nothing has to come
+    // back to the host before k_hits_write: the totals are read once, together with the counters, when everything is queued
+    const size_t nh = (size_t)b->n_cand + 1;
     if ((rc = b->h_rec.ensure(nh * 16)) || (rc = b->h_woff.ensure(nh * 8)) || (rc = b->h_wlen.ensure(nh * 4)) ||
-        (rc = b->h_cigoff.ensure(nh * 8)) || (rc = b->h_cig.ensure(tot[1] + 16)))
+        (rc = b->h_cigoff.ensure(nh * 8)) || (rc = b->h_cig.ensure((size_t)b->n_cand * b->cig_stride + 16)))
         return rc;
     KLAUNCH(b, "hits_write", k_hits_write, cdiv(n, 256), 256, n, shift, b->clus_off.as<uint64_t>(),
             b->hit_off.as<uint64_t>(), b->cigb_off.as<uint64_t>(), b->r_status.as<int32_t>(), b->c_status.as<int32_t>(),
             b->c_score.as<int32_t>(), b->c_ciglen.as<uint32_t>(), b->c_S.as<uint32_t>(), b->c_wlen.as<uint32_t>(),
             b->c_woff.as<int64_t>(), b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->h_woff.as<int64_t>(),
             b->h_wlen.as<int32_t>(), b->h_cigoff.as<uint64_t>(), b->h_cig.as<uint8_t>());
-    // terminating offset for the cigar text
-    HIPCHK(hipMemcpyAsync(b->h_cigoff.as<uint64_t>() + tot[0], &b->cig_bytes, 8, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    uint64_t tot[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&tot[0], b->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(&tot[1], b->cigb_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = fetch_counters(b))) return rc;                                   // sync
     HIPCHK(hipGetLastError());
+    b->n_hits = tot[0]; b->cig_bytes = tot[1];
     return 0;
 }
 
@@ -966,7 +973,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
             return rc;
         b->done |= BWT_STAGE_EXTEND;
     }
-    if ((rc = fetch_counters(b))) return rc;
+    if (!(stages & BWT_STAGE_EXTEND) && (rc = fetch_counters(b))) return rc;     // (the extend stage ends with the counters on the host)
     if (getenv("BWT_DEBUG_HANDBACK") && b->hctr.n_gq)
         fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u groups: non-ACGT %u, table overflow %u, >64 seeds in a read %u, >%d clusters %u\n",
                 b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);

@@ -2786,6 +2786,7 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
                                                      uint64_t *__restrict__ h_cigoff, uint8_t *__restrict__ h_cig) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    if (r == 0) h_cigoff[hit_off[n]] = cigb_off[n];     // the terminating offset of the CIGAR text
     if (r_status[r] != 0) return;
     const uint64_t a = clus_off[r], b = clus_off[r + 1];
     uint64_t ho = hit_off[r], co = cigb_off[r];

@@ -5,9 +5,9 @@ OUT=$ROOT/gpurun_out/pmc_sq
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/a -o pmc -- \
-   python3 $ROOT/bench.py --steps 1 --warmup 1 --workload grch38 --no-cpu-baseline > $OUT/a.json 2> $OUT/a.err
+   python3 $ROOT/bench.py --steps 1 --warmup 1 --workload grch38 --no-cpu-baseline --no-pipeline > $OUT/a.json 2> $OUT/a.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/b -o pmc -- \
-   python3 $ROOT/bench.py --steps 1 --warmup 1 --workload grch38 --no-cpu-baseline > $OUT/b.json 2> $OUT/b.err
+   python3 $ROOT/bench.py --steps 1 --warmup 1 --workload grch38 --no-cpu-baseline --no-pipeline > $OUT/b.json 2> $OUT/b.err
 python3 - <<'PY'
 import csv, collections, glob, os
 root=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/pmc_sq"
