@@ -100,7 +100,6 @@ __device__ __forceinline__ uint32_t bitonic_sort_upto(uint32_t p) {
     if constexpr (K > 2) p = bitonic_sort_upto<K / 2>(p);
     return bitonic_merge<K, K / 2>(p);
 }
-__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) { return bitonic_sort_upto<64>(p); }
 // two independent sorts side by side: each is a chain of 21 dependent stages (10 of them LDS round trips), interleaved
 // the swizzle latency of one hides behind the VALU work of the other
 template <int K, int J>
@@ -113,6 +112,60 @@ __device__ __forceinline__ void bitonic_sort_upto2(uint32_t &a, uint32_t &b) {
     if constexpr (K > 2) bitonic_sort_upto2<K / 2>(a, b);
     bitonic_merge2<K, K / 2>(a, b);
 }
+// Sort of N registers (one u32 per lane each, N independent sorts side by side), ascending.  A bitonic
+// network in its "mirror" form: the merge of two sorted runs of K/2 first pairs lane l with lane l ^ (K - 1), then halves the
+// distance (l ^ K/4, l ^ K/8, ...), and in EVERY stage the lower lane of a pair keeps the smaller value.  The select then
+// needs no compare and no lane mask in SGPRs: r = bfi(lower ? ~0 : 0, min(p, o), max(p, o)) with six per-lane constants
+// (is bit b of my lane number clear?), and the partner comes folded into v_min_u32_dpp / v_max_u32_dpp for 15 of the 21
+// stages (quad_perm, row_half_mirror, row_mirror, row_ror:8); the other six go through the LDS crossbar (ds_swizzle,
+// one ds_bpermute).  3 VALU per DPP stage, 1 DS + 3 VALU otherwise, no SALU -- the compare / ballot / xor / select form of
+// bitonic_stage costs 6 issue slots per stage, and this kernel is bound by instruction issue.
+struct SortMasks { uint32_t m1, m2, m4, m8, m16, m32; int mirror63; };
+__device__ __forceinline__ SortMasks sort_masks() {
+    const uint32_t l = threadIdx.x & 63u;
+    SortMasks M;
+    M.m1 = (l & 1u) ? 0u : ~0u; M.m2 = (l & 2u) ? 0u : ~0u; M.m4 = (l & 4u) ? 0u : ~0u; M.m8 = (l & 8u) ? 0u : ~0u;
+    M.m16 = (l & 16u) ? 0u : ~0u; M.m32 = (l & 32u) ? 0u : ~0u;
+    M.mirror63 = (int)((l ^ 63u) << 2);
+    return M;
+}
+__device__ __forceinline__ uint32_t ms_keep(uint32_t p, uint32_t o, uint32_t lower) {
+    const uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
+    return (mn & lower) | (mx & ~lower);
+}
+template <int CTRL, int N>
+__device__ __forceinline__ void ms_dpp(uint32_t (&p)[N], uint32_t lower) {
+#pragma unroll
+    for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p[t], CTRL, 0xF, 0xF, true), lower);
+}
+template <int XOR, int N>
+__device__ __forceinline__ void ms_swz(uint32_t (&p)[N], uint32_t lower) {          // partner lane ^ XOR inside 32 lanes
+    uint32_t o[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)p[t], (XOR << 10) | 0x1f);
+#pragma unroll
+    for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], lower);
+}
+template <int N>
+__device__ __forceinline__ void mirror_sort64(uint32_t (&p)[N], const SortMasks &M) {
+    enum { X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HALF_MIRROR = 0x141, ROW_MIRROR = 0x140, ROR8 = 0x128 };
+    ms_dpp<X1>(p, M.m1);                                                                                  // runs of 2
+    ms_dpp<X3>(p, M.m2); ms_dpp<X1>(p, M.m1);                                                             // 4
+    ms_dpp<HALF_MIRROR>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);                               // 8
+    ms_dpp<ROW_MIRROR>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);            // 16
+    ms_swz<31>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);   // 32
+    {
+        uint32_t o[N];
+#pragma unroll
+        for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(M.mirror63, (int)p[t]);
+#pragma unroll
+        for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], M.m32);
+    }
+    ms_swz<16>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);   // 64
+}
+// The general kernels keep the compare / ballot / select form: with the mirror form k_seed_tasks needs 127 VGPRs and spills
+// SGPRs, and is slower (6.9 against 6.7 ms at GRCh38 scale, 12.6 against 12.0 ms on 150-bp reads).
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) { return bitonic_sort_upto<64>(p); }
 __device__ __forceinline__ void wave_sort2_u32(uint32_t &a, uint32_t &b) { bitonic_sort_upto2<64>(a, b); }
 
 // ------------------------------------------------------------------------------------------------
@@ -962,57 +1015,6 @@ __device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
 // the (wave-uniform) value v into lane `idx` of a register
 __device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t idx, uint32_t v) {
     return (threadIdx.x & 63u) == idx ? v : old;
-}
-// Sort of N registers (one u32 per lane each, N independent sorts side by side), ascending, for k_seed_fast.  A bitonic
-// network in its "mirror" form: the merge of two sorted runs of K/2 first pairs lane l with lane l ^ (K - 1), then halves the
-// distance (l ^ K/4, l ^ K/8, ...), and in EVERY stage the lower lane of a pair keeps the smaller value.  The select then
-// needs no compare and no lane mask in SGPRs: r = bfi(lower ? ~0 : 0, min(p, o), max(p, o)) with six per-lane constants
-// (is bit b of my lane number clear?), and the partner comes folded into v_min_u32_dpp / v_max_u32_dpp for 15 of the 21
-// stages (quad_perm, row_half_mirror, row_mirror, row_ror:8); the other six go through the LDS crossbar (ds_swizzle,
-// one ds_bpermute).  3 VALU per DPP stage, 1 DS + 3 VALU otherwise, no SALU -- the compare / ballot / xor / select form of
-// bitonic_stage costs 6 issue slots per stage, and this kernel is bound by instruction issue.
-struct SortMasks { uint32_t m1, m2, m4, m8, m16, m32; int mirror63; };
-__device__ __forceinline__ SortMasks sort_masks() {
-    const uint32_t l = threadIdx.x & 63u;
-    SortMasks M;
-    M.m1 = (l & 1u) ? 0u : ~0u; M.m2 = (l & 2u) ? 0u : ~0u; M.m4 = (l & 4u) ? 0u : ~0u; M.m8 = (l & 8u) ? 0u : ~0u;
-    M.m16 = (l & 16u) ? 0u : ~0u; M.m32 = (l & 32u) ? 0u : ~0u;
-    M.mirror63 = (int)((l ^ 63u) << 2);
-    return M;
-}
-__device__ __forceinline__ uint32_t ms_keep(uint32_t p, uint32_t o, uint32_t lower) {
-    const uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
-    return (mn & lower) | (mx & ~lower);
-}
-template <int CTRL, int N>
-__device__ __forceinline__ void ms_dpp(uint32_t (&p)[N], uint32_t lower) {
-#pragma unroll
-    for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p[t], CTRL, 0xF, 0xF, true), lower);
-}
-template <int XOR, int N>
-__device__ __forceinline__ void ms_swz(uint32_t (&p)[N], uint32_t lower) {          // partner lane ^ XOR inside 32 lanes
-    uint32_t o[N];
-#pragma unroll
-    for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)p[t], (XOR << 10) | 0x1f);
-#pragma unroll
-    for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], lower);
-}
-template <int N>
-__device__ __forceinline__ void mirror_sort64(uint32_t (&p)[N], const SortMasks &M) {
-    enum { X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HALF_MIRROR = 0x141, ROW_MIRROR = 0x140, ROR8 = 0x128 };
-    ms_dpp<X1>(p, M.m1);                                                                                  // runs of 2
-    ms_dpp<X3>(p, M.m2); ms_dpp<X1>(p, M.m1);                                                             // 4
-    ms_dpp<HALF_MIRROR>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);                               // 8
-    ms_dpp<ROW_MIRROR>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);            // 16
-    ms_swz<31>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);   // 32
-    {
-        uint32_t o[N];
-#pragma unroll
-        for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(M.mirror63, (int)p[t]);
-#pragma unroll
-        for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], M.m32);
-    }
-    ms_swz<16>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);   // 64
 }
 __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,

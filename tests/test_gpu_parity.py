@@ -587,3 +587,79 @@ def test_edge_batches(gpu_index, orc_fm, ref_bytes):
             got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(),
                     int(out["pos"][h]), int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
             assert got == exp, (i, len(q))
+
+
+def test_size_independent_properties_at_scale():
+    """Properties that hold whatever the size (checked where the oracle cannot follow: 60 M-row index, 1.5 M reads of 100 bp
+    through the fast seed kernel):
+      * sharding: the hit tables of a batch are the concatenation of the hit tables of its slabs (what --gpus N relies on);
+      * idempotence: a second run of the same resident batch gives the same tables;
+      * every CIGAR consumes exactly Lq read bases (sum of M and I), every score >= 2 * ceil(Lq / 2) (sw.erl:62,69,79) and
+        <= 2 Lq, pos = win_off - 200 + shift, win_len >= Lq;
+      * a read copied from the genome without edits whose hit list is not empty holds {2 Lq, "<Lq>M"} at its own position."""
+    import re
+    from bwt_amd import lib
+    rng = np.random.default_rng(77)
+    n_ref, n_reads, lq, shift = 60_000_000, 1_500_000, 100, 5
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_ref, dtype=np.uint8)]
+    ix = lib.Index.build(ref, shift=shift)
+    try:
+        ix.set_ktable(15, 1)
+        starts = rng.integers(0, n_ref - lq, n_reads)
+        bases = ref[starts[:, None] + np.arange(lq)[None, :]].copy()
+        edited = rng.random(n_reads) < 0.6
+        rows = np.nonzero(edited)[0]
+        cols = rng.integers(0, lq, len(rows))
+        bases[rows, cols] = np.frombuffer(b"ACGT", np.uint8)[(np.searchsorted(np.frombuffer(b"ACGT", np.uint8), bases[rows, cols]) + rng.integers(1, 4, len(rows))) & 3]
+        bases = bases.reshape(-1)
+        off = np.arange(0, (n_reads + 1) * lq, lq, dtype=np.uint64)
+        b = lib.Batch(ix)
+        b.set_reads(bases, off)
+        c = b.run(lib.STAGE_EXTEND)
+        whole = b.fetch_hits()
+        assert c["n_handed_back"] < n_reads // 5 // 20          # the fast kernel kept (nearly) every group
+        b.run(lib.STAGE_EXTEND)
+        again = b.fetch_hits()
+        for k in whole:
+            assert np.array_equal(np.asarray(whole[k]), np.asarray(again[k])) if k != "cigar" else whole[k] == again[k], k
+        # sharding: three uneven slabs
+        cuts = [0, 400_003, 1_100_001, n_reads]
+        ho, co = 0, 0
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            b.set_reads(bases[a * lq:e * lq], off[: e - a + 1])
+            b.run(lib.STAGE_EXTEND)
+            part = b.fetch_hits()
+            nh = len(part["score"])
+            assert np.array_equal(part["read_status"], whole["read_status"][a:e])
+            assert np.array_equal(part["hit_off"].astype(np.int64) + ho, whole["hit_off"][a:e + 1].astype(np.int64))
+            for k in ("score", "pos", "win_off", "win_len"):
+                assert np.array_equal(part[k], whole[k][ho:ho + nh]), k
+            assert part["cigar"] == whole["cigar"][co:co + len(part["cigar"])]
+            ho += nh; co += len(part["cigar"])
+        assert ho == len(whole["score"]) and co == len(whole["cigar"])
+        b.destroy()
+        # per-hit laws
+        score, pos, woff, wlen = whole["score"], whole["pos"], whole["win_off"], whole["win_len"]
+        assert score.min() >= 2 * ((lq + 1) // 2) and score.max() <= 2 * lq
+        assert np.array_equal(pos, woff - 200 + shift) and wlen.min() >= lq
+        cigs = whole["cigar"]
+        co_ = whole["cig_off"].astype(np.int64)
+        plain = (b"%dM" % lq)
+        is_plain = np.array([cigs[co_[h]:co_[h + 1]] == plain for h in range(0, len(score), 97)])      # a sample of the texts
+        assert is_plain.mean() > 0.9
+        for h in np.nonzero(np.diff(co_) != len(plain))[0][:2000]:                                         # every other text form
+            ops = re.findall(rb"(\d+)([MID])", cigs[co_[h]:co_[h + 1]])
+            assert b"".join(n + o for n, o in ops) == cigs[co_[h]:co_[h + 1]]
+            assert sum(int(n) for n, o in ops if o in b"MI") == lq
+        # unedited reads with hits hold the full-score diagonal at their own position
+        hoff = whole["hit_off"].astype(np.int64)
+        clean = np.nonzero(~edited & (np.diff(hoff) > 0))[0]
+        assert len(clean) > n_reads // 10
+        first = hoff[clean]
+        own = np.zeros(len(clean), bool)
+        for d in range(int(np.diff(hoff).max())):
+            h = np.minimum(first + d, hoff[clean + 1] - 1)
+            own |= (pos[h] == starts[clean] + shift) & (score[h] == 2 * lq)
+        assert own.all()
+    finally:
+        ix.close()
