@@ -280,23 +280,21 @@ def main():
     step_no = [0]
     gather = (world > 1 or force_gather) and stages == lib.STAGE_EXTEND
     lo, _ = shard.slab(n_reads * world, world, rank)
-    hit_buf = None
     gatherer = shard.HitGatherer(dist, rank, world, torch.device("cuda", local_rank)) if gather else None
     gathered = [0]
 
     def step():
-        nonlocal hit_buf
         batch = batches[step_no[0] % len(batches)]
         step_no[0] += 1
         c = batch.run(stages)
         if gather:
-            # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0, double-buffered so that the
-            # gather of this step overlaps the next step's kernels
+            # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0, double-buffered so that the gather of
+            # this step overlaps the next step's kernels; the library writes the records (global read ids) straight into the
+            # gatherer's send buffer
             nh = c["n_hits"]
-            if hit_buf is None or hit_buf.shape[0] < nh:
-                hit_buf = torch.zeros((max(nh, 1) * 5 // 4, 2), dtype=torch.int64, device="cuda")
-            batch.hits_to_device(hit_buf.data_ptr(), hit_buf.shape[0])
-            parts = gatherer.submit(shard.globalize(hit_buf[:nh], lo))
+            parts, buf = gatherer.begin(nh)
+            batch.hits_to_device_global(buf.data_ptr(), buf.shape[0], lo)
+            gatherer.commit()
             if rank == 0 and parts is not None:
                 gathered[0] = int(sum(p.shape[0] for p in parts))
         return c

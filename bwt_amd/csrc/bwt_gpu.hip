@@ -1094,6 +1094,71 @@ extern "C" int bwt_batch_hits_to_device(bwt_batch *b, void *dev_dst, uint64_t ca
     return 0;
 }
 
+__global__ __launch_bounds__(256) static void k_hits_global(const HitRec *__restrict__ in, uint64_t n, uint32_t base, HitRec *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        HitRec h = in[i];
+        h.read += base;
+        out[i] = h;
+    }
+}
+extern "C" int bwt_batch_hits_to_device_global(bwt_batch *b, void *dev_dst, uint64_t cap_hits, uint32_t read_base) {
+    if (!b || !(b->done & BWT_STAGE_EXTEND) || !dev_dst) return fail(BWT_EINVAL, "bwt_batch_hits_to_device_global: not ready");
+    HIPCHK(hipSetDevice(b->device));
+    if (b->n_hits > cap_hits) return fail(BWT_ENOSPC, "hit capacity too small");
+    if (b->n_hits)
+        hipLaunchKernelGGL(k_hits_global, dim3((uint32_t)std::min<uint64_t>(cdiv(b->n_hits, 256), 4096)), dim3(256), 0, b->stream,
+                           b->h_rec.as<HitRec>(), b->n_hits, read_base, (HitRec *)dev_dst);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fastq:reverse_complement/1 (src/fastq.erl:43-50): wave per read, coalesced reads from the right end
+__global__ __launch_bounds__(256) static void k_revcomp(const uint8_t *__restrict__ in, const uint64_t *__restrict__ off, uint32_t n,
+                                                         uint8_t *__restrict__ out, int32_t *__restrict__ status) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n; r += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+        const uint64_t a = off[r], len = off[r + 1] - a;
+        bool bad = false;
+        for (uint64_t i = lane; i < len; i += 64) {
+            const uint8_t c = in[a + len - 1 - i];
+            const uint8_t d = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'N' ? 'N' : 0;
+            bad = bad || d == 0;
+            out[a + i] = d;
+        }
+        const bool any = __ballot(bad) != 0;
+        if (lane == 0) status[r] = any ? -1 : 0;
+    }
+}
+
+extern "C" int bwt_reverse_complement_batch(int device, const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *out, int32_t *status) {
+    if (!off || (!bases && n) || (!out && n) || (!status && n)) return fail(BWT_EINVAL, "bwt_reverse_complement_batch: null argument");
+    for (uint32_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return fail(BWT_EINVAL, "bwt_reverse_complement_batch: offsets must be non-decreasing");
+    if (!n) return 0;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BWT_EINVAL, "bwt_reverse_complement_batch: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    const uint64_t lo = off[0], total = off[n] - lo;
+    DevBuf din, dout, doff, dst;
+    struct G { DevBuf *b[4]; ~G() { for (auto x : b) x->release(); } } g{{&din, &dout, &doff, &dst}};
+    int rc;
+    if ((rc = din.ensure(total + 16)) || (rc = dout.ensure(total + 16)) || (rc = doff.ensure(((size_t)n + 1) * 8)) || (rc = dst.ensure((size_t)n * 4)))
+        return rc;
+    std::vector<uint64_t> o((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; i++) o[i] = off[i] - lo;
+    HIPCHK(hipMemcpy(din.p, bases + lo, total, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(doff.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_revcomp, dim3((uint32_t)std::min<uint64_t>(cdiv((uint64_t)n * 64, 256), 4096)), dim3(256), 0, 0, din.as<uint8_t>(),
+                       doff.as<uint64_t>(), n, dout.as<uint8_t>(), dst.as<int32_t>());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out + lo, dout.p, total, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status, dst.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-buffer entry points (what a NIF binds)
 extern "C" int bwt_find_seeds_batch(bwt_index *ix, const uint8_t *bases, const uint64_t *off, uint32_t n, int32_t *status,

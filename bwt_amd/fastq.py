@@ -55,3 +55,14 @@ def read_seqs(dev, n):
     if state == "eof":
         return "eof"
     return "eof", acc
+
+
+def reverse_complement(ls):
+    """fastq:reverse_complement(Ls) (src/fastq.erl:43-50) on the GPU; a base outside ACGTN raises (the reference has no clause)."""
+    ls = bytes(ls)
+    if not ls:
+        return b""
+    out, st = lib.reverse_complement_batch(*lib.pack_reads([ls]))
+    if st[0] != 0:
+        raise ValueError("fastq:rc/2: no function clause matching (a base outside ACGTN)")
+    return out.tobytes()

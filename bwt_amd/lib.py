@@ -19,7 +19,7 @@ EXPORTS = [
     "bwt_build_index", "bwt_index_save", "bwt_index_export", "bwt_fastq_open", "bwt_fastq_close", "bwt_fastq_read_seqs", "bwt_ref1_gather",
     "bwt_seeds_generate_fs", "bwt_fs_find_seeds", "bwt_fs_find_seeds_index",
     "bwt_batch_fetch_hits_raw", "bwt_pipe_create", "bwt_pipe_destroy", "bwt_pipe_acquire", "bwt_pipe_submit", "bwt_pipe_wait",
-    "bwt_pipe_release",
+    "bwt_pipe_release", "bwt_reverse_complement_batch", "bwt_batch_hits_to_device_global",
 ]
 
 
@@ -268,6 +268,15 @@ class Index:
         return out
 
 
+def reverse_complement_batch(bases, off, device=0):
+    """fastq:reverse_complement/1 on a packed batch -> (u8 array at the same offsets, status i32[n]: -1 = no clause)."""
+    bases = np.ascontiguousarray(bases, np.uint8); off = np.ascontiguousarray(off, np.uint64)
+    n = len(off) - 1
+    out = np.zeros(len(bases), np.uint8); st = np.zeros(n, np.int32)
+    _chk(load().bwt_reverse_complement_batch(int(device), _p(bases), _p(off), C.c_uint32(n), _p(out), _p(st)))
+    return out, st
+
+
 def seeds_generate_fs(qsec, length, defects):
     """bwt_seeds_generate_fs: the text of fs.erl as seeds:generate_fs/3 writes it (bytes)."""
     q = np.frombuffer(bytes(qsec), np.uint8)
@@ -368,6 +377,9 @@ class Batch:
 
     def hits_to_device(self, dev_ptr, cap_hits):
         _chk(load().bwt_batch_hits_to_device(self.h, C.c_void_p(dev_ptr), C.c_uint64(cap_hits)))
+
+    def hits_to_device_global(self, dev_ptr, cap_hits, read_base):
+        _chk(load().bwt_batch_hits_to_device_global(self.h, C.c_void_p(dev_ptr), C.c_uint64(cap_hits), C.c_uint32(read_base)))
 
     def fetch_tasks(self):
         need = C.c_uint64(0)

@@ -55,65 +55,69 @@ def gather_hits(dist, rec, rank, world, dst=0):
 
 
 class HitGatherer:
-    """Asynchronous, double-buffered form of gather_hits for a steady stream of batches: the gather of
-    batch b runs on the collective's own stream while batch b+1 is being computed.  All ranks agree once on a
-    padded capacity (all_reduce MAX of the first batch's hit count, +1/16: the padding travels too, and at ~10 ms
-    per 12.5 M-read batch rank 0 takes in more than 100 GB/s); a batch that outgrows it falls back to the synchronous path."""
+    """Asynchronous, double-buffered form of gather_hits for a steady stream of batches: the gather of batch b runs on the
+    collective's own stream while batch b+1 is being computed.
+
+    Per batch: one small all_gather of the hit counts (every rank learns every count, so every rank takes the same decisions:
+    the padded capacity grows when a count outgrows it, +1/16 head-room because the padding travels too -- at ~7 ms per
+    12.5 M-read batch rank 0 takes in more than 150 GB/s), then one asynchronous gather of the padded send buffers.
+    `begin(n)` hands out the send buffer of the batch so that the producer writes its records straight into it
+    (bwt_batch_hits_to_device_global: device-to-device, read ids made global on the way); `commit()` starts the gather;
+    `submit(rec)` is both for records that already sit in a tensor.  Results come one batch late (`begin` / `submit` return
+    the previous batch's, `wait()` the last one's): on dst the list of per-rank tensors in rank order, None elsewhere."""
 
     def __init__(self, dist, rank, world, device, dst=0):
         self.dist, self.rank, self.world, self.device, self.dst = dist, rank, world, device, dst
         self.cap = 0
         self.send = [None, None]
         self.recv = [None, None]
-        self.cnt_in = [None, None]
-        self.cnt_out = [None, None]
-        self.pending = None          # (slot, [work handles])
+        self.cnt_in = torch.zeros(1, dtype=torch.int64, device=device)
+        self.cnt_out = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        self.pending = None          # (slot, work handle, counts)
+        self.cur = None              # (slot, counts) between begin and commit
         self.k = 0
 
-    def _agree_capacity(self, n):
-        t = torch.tensor([n], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        self.cap = max(int(t.item()) * 17 // 16 + 1024, 1)
+    def _grow(self, need):
+        self.cap = max(need * 17 // 16 + 1024, 1)
         for s in (0, 1):
             self.send[s] = torch.zeros((self.cap, 2), dtype=torch.int64, device=self.device)
-            self.cnt_in[s] = torch.zeros(1, dtype=torch.int64, device=self.device)
-            self.cnt_out[s] = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
             if self.rank == self.dst:
                 self.recv[s] = [torch.empty((self.cap, 2), dtype=torch.int64, device=self.device) for _ in range(self.world)]
 
-    def submit(self, rec):
-        """Start gathering `rec` ([k,2] int64, global read ids).  Returns the result of the PREVIOUS submit
-        (list of per-rank tensors on dst, None elsewhere, None for the very first call)."""
-        n = rec.shape[0]
-        if self.cap == 0:
-            self._agree_capacity(n)
-        prev = self.wait()
-        over = torch.tensor([1 if n > self.cap else 0], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(over, op=self.dist.ReduceOp.MAX)          # every rank takes the same path
-        if int(over.item()):
-            self.sync_result = gather_hits(self.dist, rec, self.rank, self.world, self.dst)
-            self.pending = ("sync", None)
-            return prev
+    def begin(self, n):
+        """-> (result of the previous batch, send buffer [cap, 2] int64 to fill with this batch's n records)."""
+        prev = self.wait()                                   # (also: both slots are idle, so they may be reallocated)
+        self.cnt_in[0] = n
+        self.dist.all_gather(self.cnt_out, self.cnt_in)
+        counts = torch.cat(self.cnt_out).tolist()            # one synchronisation
+        if max(counts) > self.cap:
+            self._grow(max(counts))                          # the same decision on every rank
         s = self.k & 1
         self.k += 1
-        self.send[s][:n] = rec
-        self.cnt_in[s][0] = n
-        w1 = self.dist.all_gather(self.cnt_out[s], self.cnt_in[s], async_op=True)
-        w2 = self.dist.gather(self.send[s], self.recv[s] if self.rank == self.dst else None, dst=self.dst, async_op=True)
-        self.pending = (s, [w1, w2])
+        self.cur = (s, counts)
+        return prev, self.send[s]
+
+    def commit(self):
+        s, counts = self.cur
+        self.cur = None
+        w = self.dist.gather(self.send[s], self.recv[s] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        self.pending = (s, w, counts)
+
+    def submit(self, rec):
+        """Start gathering `rec` ([k,2] int64, global read ids).  Returns the result of the PREVIOUS submit."""
+        n = rec.shape[0]
+        prev, buf = self.begin(n)
+        buf[:n] = rec
+        self.commit()
         return prev
 
     def wait(self):
         """Finish the outstanding gather, if any, and return its result."""
         if self.pending is None:
             return None
-        s, works = self.pending
+        s, work, counts = self.pending
         self.pending = None
-        if s == "sync":
-            return self.sync_result
-        for w in works:
-            w.wait()
+        work.wait()
         if self.rank != self.dst:
             return None
-        counts = [int(c.item()) for c in self.cnt_out[s]]
         return [self.recv[s][r][: counts[r]] for r in range(self.world)]

@@ -181,6 +181,12 @@ int bwt_fastq_read_seqs(bwt_fastq *f, uint32_t n, uint8_t *bases, uint64_t bases
                         char *names, uint64_t names_cap, uint64_t *name_off /* n+1 */, uint32_t *n_out,
                         int *state, uint64_t needed[2]);
 
+/* fastq:reverse_complement/1 (src/fastq.erl:43-50; exported by the reference, unused by its worker path) on n reads:
+ * out receives the reverse complements at the same offsets (out may not alias bases).  status[i]: 0, or -1 where the
+ * reference has no clause (a base outside ACGTN: function_clause) -- reported per read, that read's output is undefined. */
+int bwt_reverse_complement_batch(int device, const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *out,
+                                 int32_t *status);
+
 /* ------------------------------------------------------------------ resident-batch interface
  * The same pipeline split so that a caller can keep reads and hits in HBM (bench, multi-GPU
  * gather): upload once, run stages on the index's HIP stream, fetch what is wanted. */
@@ -214,6 +220,8 @@ int bwt_batch_kernel_times(bwt_batch *b, char *names, uint32_t names_cap, double
 /* device-to-device copy of the compact hit table {read:u32, score:i32, pos:i64} (16 B/hit)
  * into caller-owned device memory (e.g. a torch tensor used for the RCCL gather) */
 int bwt_batch_hits_to_device(bwt_batch *b, void *dev_dst, uint64_t cap_hits);
+/* the same with `read_base` added to every record's read index (slab-local -> global read ids for the gather) */
+int bwt_batch_hits_to_device_global(bwt_batch *b, void *dev_dst, uint64_t cap_hits, uint32_t read_base);
 int bwt_batch_fetch_tasks(bwt_batch *b, int32_t *status, uint32_t *sp, uint32_t *ep, uint32_t *nmatch,
                           uint32_t *task_read, uint32_t *task_end, uint64_t cap, uint64_t *needed);
 int bwt_batch_fetch_clusters(bwt_batch *b, uint64_t *clus_off, int64_t *S, int32_t *D, uint64_t cap,

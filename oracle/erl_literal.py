@@ -756,3 +756,15 @@ def fs_find_seeds(pats, ref_seq):
             continue
         break                                                # find_seeds(Acc,_,_) -> Acc
     return acc
+
+
+def fastq_reverse_complement(ls):
+    """fastq:reverse_complement/1 (src/fastq.erl:43-50): rc/2 walks the list prepending the complement; a base outside
+    ACGTN has no clause (function_clause -> ErlCrash)."""
+    acc = []
+    comp = {ord("A"): ord("T"), ord("T"): ord("A"), ord("C"): ord("G"), ord("G"): ord("C"), ord("N"): ord("N")}
+    for c in ls:
+        if c not in comp:
+            raise ErlCrash("fastq:rc/2: no function clause matching %r" % (c,))
+        acc.insert(0, comp[c])
+    return bytes(acc)

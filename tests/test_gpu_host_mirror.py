@@ -99,3 +99,27 @@ def test_master_run_end_to_end(tmp_path, lit_fm, ref_bytes):
     got = out.getvalue().split("\n\nReads:")[0]
     assert got == "".join(exp)
     assert lines == len(exp) > 20
+
+
+def test_reverse_complement(ref_bytes):
+    """fastq:reverse_complement/1 (src/fastq.erl:43-50): the GPU batch kernel against the literal oracle, ragged lengths,
+    empty reads, N, and the inputs the reference has no clause for."""
+    import numpy as np
+    import pytest
+    from bwt_amd import lib, fastq
+    from oracle import erl_literal as E
+    rng = np.random.default_rng(5)
+    reads = [b"", b"A", b"ACGTN", ref_bytes[:1], ref_bytes[100:1100]] + \
+            [bytes(rng.choice(list(b"ACGTN"), int(rng.integers(0, 300))).tolist()) for _ in range(200)] + [b"ACGR", b"acgt"]
+    out, st = lib.reverse_complement_batch(*lib.pack_reads(reads))
+    o = 0
+    for i, r in enumerate(reads):
+        try:
+            exp = E.fastq_reverse_complement(r)
+            assert st[i] == 0 and out[o:o + len(r)].tobytes() == exp, r
+        except E.ErlCrash:
+            assert st[i] == -1
+        o += len(r)
+    assert fastq.reverse_complement(b"AACGTN") == b"NACGTT"
+    with pytest.raises(ValueError):
+        fastq.reverse_complement(b"ACGX")
