@@ -214,6 +214,12 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
 
+    # stdout carries ONE JSON line: whatever libraries print there on the way (RCCL's version banner at communicator set-up)
+    # goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
@@ -430,7 +436,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1,
                                                 batch=batch)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     batch.destroy()
     ix.close()
     if dist is not None:

@@ -298,6 +298,7 @@ struct bwt_batch {
     bool own_stream = false;
     int occ_seed[4] = {0, 0, 0, 0};    // resident blocks per CU of the three k_seed_tasks instances and k_seed_fast (queried once per batch)
     DevBuf gq;                         // groups k_seed_fast handed back
+    uint32_t occ_seed_maxT = 0;        // ... k_seed_fast's occupancy was queried for this many sub-reads per read (its LDS depends on it)
     // inputs
     uint32_t n = 0, maxT = 0, max_lq = 0;
     uint64_t total_bases = 0;
@@ -584,26 +585,27 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
             return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
         };
         // Batches of one read length with the full-depth wide table: k_seed_fast takes the ordinary groups of reads and hands
-        // the others back as a list for k_seed_tasks (results are k_seed_tasks' either way).  Up to 14 sub-reads per read:
-        // longer reads mostly hold more than the 64 seeds the fast kernel sorts.
+        // the others back as a list for k_seed_tasks (results are k_seed_tasks' either way).  Up to 21 sub-reads per read (three
+        // reads per wave pass), up to 128 seeds per read.
         const char *env_fast = getenv("BWT_SEED_FAST");             // experiments / tests: 0 = general kernel only
-        const bool fast = fuse && lean && b->ulen && b->ix->d.kt_k == BWT_MAX_LEN && maxT <= 14 && !(env_fast && env_fast[0] == '0');
+        const bool fast = fuse && lean && b->ulen && b->ix->d.kt_k == BWT_MAX_LEN && maxT <= 21 && !(env_fast && env_fast[0] == '0');
         const uint32_t *nolist = nullptr;
         const unsigned int *nocount = nullptr;
         if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u, nolist, nocount);
         else if (fast) {
             if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
             {
-                const char *env_pad = getenv("BWT_SEED_LDS_PAD");      // experiments: extra dynamic LDS per block (lowers the occupancy)
-                const size_t pad = env_pad ? (size_t)atoi(env_pad) : 0;
-                uint32_t grid = resident(3, (const void *)k_seed_fast);
-                if (pad) {
-                    int per_cu = 8;
-                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_seed_fast, 256, pad);
-                    grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * std::max(1, std::min(per_cu, 8))));
+                const size_t lds = sf_lds_bytes(maxT);
+                int &per_cu = b->occ_seed[3];
+                if (!per_cu || b->occ_seed_maxT != maxT) {
+                    per_cu = 8;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_seed_fast, 256, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 4; }
+                    per_cu = std::max(1, std::min(per_cu, 8));
+                    b->occ_seed_maxT = maxT;
                 }
+                const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
                 ProfScope ps(b, "fm_lookup");
-                hipLaunchKernelGGL(k_seed_fast, dim3(grid), dim3(256), pad, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
+                hipLaunchKernelGGL(k_seed_fast, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
                                    b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
                                    b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
             }

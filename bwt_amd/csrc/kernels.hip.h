@@ -120,13 +120,13 @@ __device__ __forceinline__ void bitonic_sort_upto2(uint32_t &a, uint32_t &b) {
 // stages (quad_perm, row_half_mirror, row_mirror, row_ror:8); the other six go through the LDS crossbar (ds_swizzle,
 // one ds_bpermute).  3 VALU per DPP stage, 1 DS + 3 VALU otherwise, no SALU -- the compare / ballot / xor / select form of
 // bitonic_stage costs 6 issue slots per stage, and this kernel is bound by instruction issue.
-struct SortMasks { uint32_t m1, m2, m4, m8, m16, m32; int mirror63; };
+struct SortMasks { uint32_t m1, m2, m4, m8, m16, m32; int mirror63, x32; };
 __device__ __forceinline__ SortMasks sort_masks() {
     const uint32_t l = threadIdx.x & 63u;
     SortMasks M;
     M.m1 = (l & 1u) ? 0u : ~0u; M.m2 = (l & 2u) ? 0u : ~0u; M.m4 = (l & 4u) ? 0u : ~0u; M.m8 = (l & 8u) ? 0u : ~0u;
     M.m16 = (l & 16u) ? 0u : ~0u; M.m32 = (l & 32u) ? 0u : ~0u;
-    M.mirror63 = (int)((l ^ 63u) << 2);
+    M.mirror63 = (int)((l ^ 63u) << 2); M.x32 = (int)((l ^ 32u) << 2);
     return M;
 }
 __device__ __forceinline__ uint32_t ms_keep(uint32_t p, uint32_t o, uint32_t lower) {
@@ -145,6 +145,19 @@ __device__ __forceinline__ void ms_swz(uint32_t (&p)[N], uint32_t lower) {      
     for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)p[t], (XOR << 10) | 0x1f);
 #pragma unroll
     for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], lower);
+}
+// a bitonic sequence of 64 (per register) into ascending order: the half-cleaners l ^ 32, 16, 8, 4, 2, 1
+template <int N>
+__device__ __forceinline__ void bitonic_merge64(uint32_t (&p)[N], const SortMasks &M) {
+    enum { X1 = 0xB1, X2 = 0x4E, ROR8 = 0x128 };
+    {
+        uint32_t o[N];
+#pragma unroll
+        for (int t = 0; t < N; t++) o[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(M.x32, (int)p[t]);
+#pragma unroll
+        for (int t = 0; t < N; t++) p[t] = ms_keep(p[t], o[t], M.m32);
+    }
+    ms_swz<16>(p, M.m16); ms_dpp<ROR8>(p, M.m8); ms_swz<4>(p, M.m4); ms_dpp<X2>(p, M.m2); ms_dpp<X1>(p, M.m1);
 }
 template <int N>
 __device__ __forceinline__ void mirror_sort64(uint32_t (&p)[N], const SortMasks &M) {
@@ -992,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
 // takes per pass
 //   * no read holds a base outside ACGT (the windows [e-16, e) of a read's sub-reads cover the whole read),
 //   * every table entry fits (no KT_OVF),
-//   * every read has at most 64 seeds and at most CL_STAGE clusters.
+//   * every read has at most 128 seeds and at most CL_STAGE clusters.
 // A group that fails any of these is handed back untouched -- its index goes to gq and k_seed_tasks runs on that list
 // afterwards -- so the results are k_seed_tasks' by construction; this kernel only has to be right on what it keeps.
 // What it saves over the general kernel (which sits at the VALU issue limit): the sub-read chain and the N-plane loads
@@ -1001,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
 // every lane reads its own slot), the predicated word-by-word seed stores (each lane copies its own seeds), get_similar
 // on lane masks in SGPRs (run starts by one ballot; run lengths, the emit test and the cluster count are scalar ops; only
 // the one or two emitted clusters touch the VALU again), no task-table rows, one store of the group's results at the end.
-#define SF_ROW 64
+#define SF_ROW 128            // seeds of a read the fast kernel sorts: one register (<= 64) or two
 #define SF_SLOT 5
 __device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
@@ -1016,20 +1029,27 @@ __device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
 __device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t idx, uint32_t v) {
     return (threadIdx.x & 63u) == idx ? v : old;
 }
+// dynamic LDS of a k_seed_fast block (4 waves)
+__host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT) {
+    const uint32_t rw = 64u / maxT, nslot = (rw * maxT + 3u) & ~3u;
+    return 4u * 4u * (nslot * SF_SLOT * 4 + rw * SF_ROW + 128);
+}
 __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                     uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_cl,
                                                     uint32_t *__restrict__ gq, Counters *ctr) {
-    __shared__ uint4 stag_[4 * 64 * SF_SLOT];                    // per wave: 64 task slots x four 16-byte quarters (+ 16 bytes: slots 80 bytes apart, no bank conflicts)
-    __shared__ uint32_t rows_[4 * 8 * SF_ROW];                   // per wave: a row of seeds per read of the pass
-    __shared__ uint32_t gq_[4 * 128];
+    // LDS per wave (dynamic, sized by the host: sf_lds_bytes): task slots x four 16-byte quarters (+ 16 bytes: slots 80 bytes
+    // apart, no bank conflicts) | a row of SF_ROW seeds per read of the pass | 128 words of queue staging
+    extern __shared__ uint4 sf_lds_[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint4 *stag = stag_ + wv * 64 * SF_SLOT;
-    uint32_t *rows = rows_ + wv * 8 * SF_ROW;
-    WaveQ q;
-    q.buf = gq_ + wv * 128; q.have = 0;
     const uint32_t rw = 64u / maxT;
+    const uint32_t nslot = (rw * maxT + 3u) & ~3u, wave_words = nslot * SF_SLOT * 4 + rw * SF_ROW + 128;
+    uint32_t *wbase = (uint32_t *)sf_lds_ + wv * wave_words;
+    uint4 *stag = (uint4 *)wbase;
+    uint32_t *rows = wbase + nslot * SF_SLOT * 4;
+    WaveQ q;
+    q.buf = rows + rw * SF_ROW; q.have = 0;
     const uint32_t lread = lane / maxT, slot = lane - lread * maxT, seg0 = lread * maxT;
     const uint32_t ql = lane & 3u;
     // lane constants of the slot: sub-read end, step limit = table level, bits of the 16-base window that belong to the read
@@ -1111,9 +1131,11 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         // bwa.erl:31-45 at the end of the search: the range check applies unless a step came back not_found (n < m)
         const bool seeds = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
         const uint32_t c = seeds ? wd + 1u : 0u;
-        abn = abn || (act && wd == KT_OVF);
+        // (a task with more seeds than a row holds: its read is over the limit anyway, and the packed scan below must not overflow)
+        abn = abn || (act && wd == KT_OVF) || c > SF_ROW;
         if (__ballot(abn)) {                                           // hand the group back
-            why += __ballot(abn0) ? 1u : 1u << 8;
+            why += __ballot(abn0) ? 1u : __ballot(act && wd == KT_OVF) ? 1u << 8 : 0u;
+            if (!__ballot(abn0) && !__ballot(act && wd == KT_OVF)) why2 += 1u;          // (a task over the row limit counts as a read over it)
             __builtin_amdgcn_wave_barrier();
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
             live -= (uint32_t)__popcll(__ballot(act));
@@ -1151,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                 const uint32_t add_s = (uint32_t)__builtin_amdgcn_readlane((int)nadd, src), from_s = (uint32_t)__builtin_amdgcn_readlane((int)inl, src);
                 const uint32_t dst_s = (uint32_t)__builtin_amdgcn_readlane((int)(lread * SF_ROW + dst), src);
                 if (lane >= from_s && lane < c_s) rows[dst_s + lane] = ix.sa[sp_s - 1 + lane] + add_s;
+                if (lane + 64 < c_s) rows[dst_s + 64 + lane] = ix.sa[sp_s - 1 + 64 + lane] + add_s;
             }
             const uint32_t cw = fuse_read ? (c < inl ? c : inl) : 0u;
             if (cw > 0) row[0] = own.z + nadd;
@@ -1178,11 +1201,15 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // Sort, up to three reads side by side.  Each sorted read goes back into its row, and its run starts (one ballot:
-        // lane i starts a run iff p[i] - p[i-1] > TOLERANCE) into the read's leader lane; get_similar itself then runs ONCE
-        // for all reads of the pass, on 64-bit lane arithmetic in the leader lanes (sga.erl:42-64).
-        unsigned long long bf = __ballot(fuse_read && slot == 0);        // bit seg0 of every read to cluster
-        uint32_t smlo = 0, smhi = 0;
+        // Sort: reads of up to 64 seeds up to three side by side in one register each; a read of 65..128 seeds in two registers
+        // (element e = 64 q + lane: both halves sorted, element i meets element 127 - i, each half -- bitonic now -- merged).
+        // Each sorted read goes back into its row, and its run starts (a ballot per register: lane i starts a run iff
+        // p[i] - p[i-1] > TOLERANCE) into the read's leader lane; get_similar itself then runs ONCE for all reads of the pass,
+        // on lane masks held as integers in the leader lanes (sga.erl:42-64).
+        const unsigned long long bfall = __ballot(fuse_read && slot == 0);   // bit seg0 of every read to cluster
+        const unsigned long long bfbig = __ballot(fuse_read && slot == 0 && P > 64);
+        unsigned long long bf = bfall & ~bfbig;
+        uint32_t smlo = 0, smhi = 0, sm2lo = 0, sm2hi = 0;                   // run starts of elements 0..63 / 64..127
         uint32_t left = (uint32_t)__popcll(bf);
         while (left) {
             const uint32_t take = left == 1 ? 1u : (left == 2 || left == 4) ? 2u : 3u;
@@ -1216,18 +1243,51 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                 }
             left -= take;
         }
+        for (unsigned long long bg = bfbig; bg; bg &= bg - 1ull) {
+            const int b1 = __ffsll((long long)bg) - 1;
+            const uint32_t j1 = (uint32_t)b1 / maxT;
+            const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, b1);
+            uint32_t *row = rows + j1 * SF_ROW;
+            uint32_t a[2] = {row[lane], lane + 64 < Pj ? row[64 + lane] : 0xffffffffu};
+            mirror_sort64(a, SM);
+            const uint32_t rv = (uint32_t)__builtin_amdgcn_ds_bpermute(SM.mirror63, (int)a[1]);
+            a[1] = a[0] < rv ? rv : a[0]; a[0] = a[0] < rv ? a[0] : rv;
+            bitonic_merge64(a, SM);
+            row[lane] = a[0]; row[64 + lane] = a[1];
+            uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[0], 0x138, 0xF, 0xF, false);
+            uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[1], 0x138, 0xF, 0xF, false);
+            asm volatile("" : "+v"(p0), "+v"(p1));
+            const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane((int)a[0], 63);
+            if (lane == 0) p1 = last0;                                         // element 64 follows element 63
+            const unsigned long long s0 = __ballot(a[0] - p0 > BWT_TOLERANCE) | 1ull, s1 = __ballot(a[1] - p1 > BWT_TOLERANCE);
+            smlo = set_lane(smlo, (uint32_t)b1, (uint32_t)s0); smhi = set_lane(smhi, (uint32_t)b1, (uint32_t)(s0 >> 32));
+            sm2lo = set_lane(sm2lo, (uint32_t)b1, (uint32_t)s1); sm2hi = set_lane(sm2hi, (uint32_t)b1, (uint32_t)(s1 >> 32));
+        }
         __builtin_amdgcn_wave_barrier();
         // get_similar in the leader lanes: run ends = the lane before a start + the last seed; a run of >= 2 + Qty div 7 (:46)
-        // seeds ending in lane e <=> no start in (e - nthr + 1, e]; clusters in descending position order
+        // seeds ending in element e <=> no start in (e - nthr + 1, e]; clusters in descending position order.  Elements
+        // 64..127 (mask words *1) only exist in passes that hold a read of more than 64 seeds.
         const bool lead = fuse_read && slot == 0;
-        const unsigned long long vmask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
-        const unsigned long long sm = (((unsigned long long)smhi << 32) | smlo) & vmask;
-        const unsigned long long A = ~sm;
         const uint32_t tq = qty / 7;
-        unsigned long long ok = A;
-        for (uint32_t k = 1; __ballot(lead && k <= tq); k++) if (k <= tq) ok &= A << k;
-        unsigned long long em = lead ? ((sm >> 1) | (1ull << ((P - 1) & 63u))) & vmask & ok : 0ull;
-        const uint32_t Kc = (uint32_t)__popcll(em);
+        const unsigned long long vm0 = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+        const unsigned long long sm0 = (((unsigned long long)smhi << 32) | smlo) & vm0;
+        const unsigned long long A0 = ~sm0;
+        unsigned long long ok0 = A0, em0, sm1 = 0, em1 = 0;
+        if (!bfbig) {
+            for (uint32_t k = 1; __ballot(lead && k <= tq); k++) if (k <= tq) ok0 &= A0 << k;
+            em0 = lead ? ((sm0 >> 1) | (1ull << ((P - 1) & 63u))) & vm0 & ok0 : 0ull;
+        } else {
+            const unsigned long long vm1 = P <= 64 ? 0ull : P >= 128 ? ~0ull : ((1ull << (P - 64)) - 1ull);
+            sm1 = (((unsigned long long)sm2hi << 32) | sm2lo) & vm1;
+            const unsigned long long A1 = ~sm1;
+            unsigned long long ok1 = A1;
+            for (uint32_t k = 1; __ballot(lead && k <= tq); k++)
+                if (k <= tq) { ok0 &= A0 << k; ok1 &= (A1 << k) | (A0 >> (64 - k)); }       // (k <= 18 < 64)
+            const unsigned long long last0 = P <= 64 ? 1ull << ((P - 1) & 63u) : 0ull, last1 = P > 64 ? 1ull << ((P - 65) & 63u) : 0ull;
+            em0 = lead ? ((sm0 >> 1) | (sm1 << 63) | last0) & vm0 & ok0 : 0ull;
+            em1 = lead ? ((sm1 >> 1) | last1) & vm1 & ok1 : 0ull;
+        }
+        const uint32_t Kc = (uint32_t)(__popcll(em0) + __popcll(em1));
         if (__ballot(Kc > CL_STAGE)) {                                 // a read with more clusters than its staging row holds
             why2 += 1u << 16;
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
@@ -1238,11 +1298,20 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         {
             uint32_t *cl = r_cl + (uint64_t)r * (2 * CL_STAGE);
             const uint32_t *row = rows + lread * SF_ROW;
-            while (__ballot(em != 0)) {
-                if (em) {
-                    const int e1 = 63 - __clzll((long long)em);
-                    em &= ~(1ull << e1);
-                    const int s1 = 63 - __clzll((long long)(sm & ((2ull << e1) - 1ull)));
+            while (__ballot((em0 | em1) != 0)) {
+                if (em0 | em1) {
+                    int e1, s1;
+                    if (em1) {
+                        const int h = 63 - __clzll((long long)em1);
+                        em1 &= ~(1ull << h);
+                        e1 = 64 + h;
+                        const unsigned long long below = sm1 & ((2ull << h) - 1ull);
+                        s1 = below ? 64 + 63 - __clzll((long long)below) : 63 - __clzll((long long)sm0);
+                    } else {
+                        e1 = 63 - __clzll((long long)em0);
+                        em0 &= ~(1ull << e1);
+                        s1 = 63 - __clzll((long long)(sm0 & ((2ull << e1) - 1ull)));
+                    }
                     const uint32_t pe = row[e1], pf = row[s1];
                     cl[0] = pe; cl[1] = pe - pf;
                     cl += 2;

@@ -596,7 +596,8 @@ def test_size_independent_properties_at_scale():
       * idempotence: a second run of the same resident batch gives the same tables;
       * every CIGAR consumes exactly Lq read bases (sum of M and I), every score >= 2 * ceil(Lq / 2) (sw.erl:62,69,79) and
         <= 2 Lq, pos = win_off - 200 + shift, win_len >= Lq;
-      * a read copied from the genome without edits whose hit list is not empty holds {2 Lq, "<Lq>M"} at its own position."""
+      * a read copied from the genome without edits whose hit list is not empty holds a full-score hit whose window covers the
+        read's own position."""
     import re
     from bwt_amd import lib
     rng = np.random.default_rng(77)
@@ -659,7 +660,8 @@ def test_size_independent_properties_at_scale():
         own = np.zeros(len(clean), bool)
         for d in range(int(np.diff(hoff).max())):
             h = np.minimum(first + d, hoff[clean + 1] - 1)
-            own |= (pos[h] == starts[clean] + shift) & (score[h] == 2 * lq)
+            # (Pos is the WINDOW start, src/worker_bwt.erl:94: a cluster with a stray seed in front of the read widens the window to the left)
+            own |= (pos[h] <= starts[clean] + shift) & (starts[clean] + shift <= pos[h] + wlen[h] - lq) & (score[h] == 2 * lq)
         assert own.all()
     finally:
         ix.close()
