@@ -32,12 +32,19 @@ class FM:
     def close(self):
         self.index.close()
 
+    def save_native(self, chrom, j):
+        """Keeps the index as <fm_indices>/<Chrom>_p<J>.bwtgpu (bwt_index_save_native); get_index finds it when no .fm exists."""
+        self.index.save_native(fm_name(chrom, j) + ".bwtgpu")
+
 
 def get_index(chrom, j, device=0):
     """-> (Meta, FM) with Meta = [("pointers",(Pc,Pg,Pt,Last)), ("shift",Shift)].
     Raises FileNotFoundError / lib.BwtError where the reference's {ok,Bin} = file:read_file badmatches."""
     base = fm_name(chrom, j)
     if not os.path.exists(base + ".fm"):
+        if os.path.exists(base + ".bwtgpu"):             # the compact native file (monolithic indexes: no .fm of that size exists)
+            fm = FM(lib.Index.open_native(base + ".bwtgpu", device))
+            return [("pointers", (fm.Pc, fm.Pg, fm.Pt, fm.Last)), ("shift", fm.shift)], fm
         raise FileNotFoundError(base + ".fm")
     fm = FM(lib.Index.open(base + ".fm", base + ".ref", device))
     meta = [("pointers", (fm.Pc, fm.Pg, fm.Pt, fm.Last)), ("shift", fm.shift)]

@@ -20,6 +20,7 @@ EXPORTS = [
     "bwt_seeds_generate_fs", "bwt_fs_find_seeds", "bwt_fs_find_seeds_index",
     "bwt_batch_fetch_hits_raw", "bwt_pipe_create", "bwt_pipe_destroy", "bwt_pipe_acquire", "bwt_pipe_submit", "bwt_pipe_wait",
     "bwt_pipe_release", "bwt_reverse_complement_batch", "bwt_batch_hits_to_device_global",
+    "bwt_index_save_native", "bwt_index_open_native", "bwt_native_check",
 ]
 
 
@@ -101,6 +102,13 @@ def fm_check(fm_path):
     return tuple(int(x) for x in out[:4]), C.c_int32(int(out[4])).value
 
 
+def native_check(path):
+    """Header and checksums of a native index file, on the host -> ((Pc,Pg,Pt,Last), Shift)."""
+    out = (C.c_uint32 * 5)()
+    _chk(load().bwt_native_check(os.fsencode(path), out))
+    return tuple(int(x) for x in out[:4]), C.c_int32(int(out[4])).value
+
+
 def fm_rewrite(in_path, out_path):
     _chk(load().bwt_fm_rewrite(os.fsencode(in_path), os.fsencode(out_path)))
 
@@ -151,6 +159,15 @@ class Index:
         if rng_state is not None:
             rng_state[:] = [int(x) for x in st]
         return cls(h)
+
+    @classmethod
+    def open_native(cls, path, device=0):
+        h = C.c_void_p()
+        _chk(load().bwt_index_open_native(os.fsencode(path), int(device), C.byref(h)))
+        return cls(h)
+
+    def save_native(self, path):
+        _chk(load().bwt_index_save_native(self.h, os.fsencode(path)))
 
     def export(self):
         """-> (L u8[n_rows], SA u32[n_rows]) copied back from HBM."""

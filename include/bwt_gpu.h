@@ -92,6 +92,15 @@ int bwt_build_index(const uint8_t *ref, uint64_t n, int32_t shift, uint32_t rng_
 /* writes <fm_path> (ETF {Meta,FM}, byte-for-byte what term_to_binary/1 gives) and <ref_path> */
 int bwt_index_save(const bwt_index *idx, const char *fm_path, const char *ref_path);
 
+/* A compact native file next to the reference's format: the index exactly as it sits in HBM -- 64-byte rank
+ * blocks, SA, the .ref bases -- behind a 128-byte header with the pointers, the shift and a checksum per section: 5.4 bytes
+ * per row where the term format takes ~16 (a monolithic GRCh38 index would be a ~50 GB Erlang term).  The .fm / .ref pair
+ * stays the interchange format with the reference; an index of any size can be kept and reopened this way.
+ * bwt_native_check (host only, no GPU) verifies header and checksums and returns {Pc,Pg,Pt,Last,Shift}. */
+int bwt_index_save_native(const bwt_index *idx, const char *path);
+int bwt_index_open_native(const char *path, int device, bwt_index **out);
+int bwt_native_check(const char *path, uint32_t out[5]);
+
 /* copies the L column (n_rows bytes, '$' at its row) and the SA column back to the host */
 int bwt_index_export(const bwt_index *idx, uint8_t *L, uint32_t *SA);
 

@@ -96,3 +96,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         lib.load()
+
+
+def test_native_check_refuses_what_is_not_an_index(tmp_path):
+    """bwt_native_check is host-only: junk, a short file and a wrong magic are BWT_EFORMAT, a missing file BWT_EIO."""
+    import pytest
+    from bwt_amd import lib
+    p = tmp_path / "x.bwtgpu"
+    for blob in (b"", b"BWTGPUIX" + b"\0" * 50, b"NOTANIDX" + b"\0" * 200, b"BWTGPUIX" + b"\x01\0\0\0" + b"\0" * 116 + b"\0" * 64):
+        p.write_bytes(blob)
+        with pytest.raises(lib.BwtError) as e:
+            lib.native_check(str(p))
+        assert e.value.code == -74
+    with pytest.raises(lib.BwtError) as e:
+        lib.native_check(str(tmp_path / "missing.bwtgpu"))
+    assert e.value.code == -5
