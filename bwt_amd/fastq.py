@@ -20,6 +20,10 @@ class Dev:
             lib.load().bwt_fastq_close(self.h)
             self.h = None
 
+    def set_threads(self, threads=0, min_records=65536):
+        """0 = automatic, 1 = the sequential reader only; batches of at least min_records records use the threaded reader."""
+        lib._chk(lib.load().bwt_fastq_set_threads(self.h, C.c_uint32(threads), C.c_uint64(min_records)))
+
     def __del__(self):
         try:
             self.close()

@@ -20,7 +20,7 @@ EXPORTS = [
     "bwt_seeds_generate_fs", "bwt_fs_find_seeds", "bwt_fs_find_seeds_index",
     "bwt_batch_fetch_hits_raw", "bwt_pipe_create", "bwt_pipe_destroy", "bwt_pipe_acquire", "bwt_pipe_submit", "bwt_pipe_wait",
     "bwt_pipe_release", "bwt_reverse_complement_batch", "bwt_batch_hits_to_device_global",
-    "bwt_index_save_native", "bwt_index_open_native", "bwt_native_check",
+    "bwt_index_save_native", "bwt_index_open_native", "bwt_native_check", "bwt_fastq_set_threads",
 ]
 
 

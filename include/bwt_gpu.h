@@ -186,6 +186,10 @@ int bwt_fs_find_seeds_index(const bwt_index *idx, const uint8_t *qsec, uint32_t 
 typedef struct bwt_fastq bwt_fastq;
 int bwt_fastq_open(const char *path, bwt_fastq **out);
 void bwt_fastq_close(bwt_fastq *f);
+/* Big batches are parsed by many threads (files whose records are four lines with an '@' header -- anything else falls back to
+ * the sequential reader, which decides as fastq:read_seq/1 does).  threads: 0 = automatic, 1 = sequential only;
+ * min_records: the batch size from which the threaded reader is used (default 65536). */
+int bwt_fastq_set_threads(bwt_fastq *f, uint32_t threads, uint64_t min_records);
 int bwt_fastq_read_seqs(bwt_fastq *f, uint32_t n, uint8_t *bases, uint64_t bases_cap, uint64_t *off /* n+1 */,
                         char *names, uint64_t names_cap, uint64_t *name_off /* n+1 */, uint32_t *n_out,
                         int *state, uint64_t needed[2]);

@@ -73,3 +73,34 @@ def test_cigar_sink_filter_and_format():
     assert master.cigar_line(("cigar", "r1", (200, "100M"), 5, b"AC"), "21") is None      # master.erl:149: 100 bp reads never pass
     assert master.cigar_line(("cigar", "r1", (200, "100M"), 5, b"AC"), "21", threshold=100) == \
         "\nr1      21      5      100M      200      AC\n"
+
+
+@pytest.mark.parametrize("kind", ["clean", "no_final_newline", "junk_first", "junk_inside", "partial_tail", "tiny"])
+@pytest.mark.parametrize("threads", [2, 5, 16])
+def test_threaded_reader_equals_sequential_and_literal(tmp_path, kind, threads):
+    """The threaded reader (four-line records, '@' headers; quality lines that start with '@' included) against the sequential
+    reader and the literal restatement, batch by batch, on clean files and on every kind of file it must hand back to the
+    sequential rules: a junk line first or in the middle (the reference skips lines until an '@'), a last record cut short,
+    a file without final newline."""
+    from bwt_amd import fastq
+    n = 30 if kind == "tiny" else 4000
+    data = make_fastq(n, with_junk=(kind == "junk_first"), final_newline=(kind != "no_final_newline"), seed=17 + threads)
+    if kind == "junk_inside":
+        cut = data.index(b"@read.1500 ")
+        data = data[:cut] + b"not a header\n" + data[cut:]
+    if kind == "partial_tail":
+        data = data + b"@tail record\nACGTACGT\n"                      # header + sequence, no delimiter / quality: still a record
+    p = tmp_path / "t.fastq"
+    p.write_bytes(data)
+    par, seq = fastq.Dev(str(p)), fastq.Dev(str(p))
+    par.set_threads(threads, min_records=1)
+    seq.set_threads(1)
+    lit = E.LineDev(data)
+    got_any = False
+    for want in (700, 1, 1299, 64, 5000, 10):
+        a = fastq.read_seqs(par, want)
+        b = fastq.read_seqs(seq, want)
+        assert a == b == E.fastq_read_seqs(lit, want), (kind, want)
+        got_any = got_any or (a != "eof" and len(a[1]) > 0)
+    assert got_any
+    par.close(); seq.close()
