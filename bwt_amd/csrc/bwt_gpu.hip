@@ -312,6 +312,7 @@ struct bwt_batch {
     bool rows_kept = true;             // every read's task-table rows were written (not so after a lean fused run)
     bool fused = false;                // ... and clustered what it could (r_K zeroed, RQ_DONE reads staged in r_cl)
     bool cand_pending = false;         // the candidate arrays are still to be made (by the prefilter, from the per-read clusters)
+    bool max_w_known = false;          // ... and the largest window is known without asking the prefilter
     // reads
     DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
@@ -738,7 +739,11 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         return rc;
     if (to_extend) {                                                          // the prefilter makes the candidates itself (run_sw)
         b->cand_pending = true;
-        b->hctr.max_w = 0; b->hctr.max_lq = 0;
+        // every cluster came from the seed kernels: the widest window is known already (Lq + the widest cluster they staged), and
+        // the DP kernels can be sized without waiting for the prefilter
+        b->max_w_known = all_clustered;
+        b->hctr.max_w = all_clustered ? b->max_lq + b->hctr.max_D : 0;
+        b->hctr.max_lq = all_clustered ? b->max_lq : 0;
         return 0;
     }
     KLAUNCH(b, "candidates", k_candidates, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
@@ -787,7 +792,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             src.c_qlen = b->c_qlen.as<uint32_t>(); src.c_woff = b->c_woff.as<int64_t>(); src.c_wlen = b->c_wlen.as<uint32_t>();
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, std::min<uint32_t>(cdiv((uint64_t)b->n * 4, 256), 2048), 256, io, b->n, src);
             b->cand_pending = false;
-            if ((rc = fetch_counters(b))) return rc;                       // max_w / max_lq size the DP kernels' LDS and slabs
+            if (!b->max_w_known && (rc = fetch_counters(b))) return rc;    // max_w / max_lq size the DP kernels' LDS and slabs
             max_w = b->hctr.max_w; max_lq = b->hctr.max_lq;
         } else
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc, src);   // quad per candidate

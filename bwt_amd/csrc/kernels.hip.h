@@ -635,7 +635,7 @@ __device__ __forceinline__ void read_finish(bool active, uint32_t r, unsigned lo
 // position order); more than CL_STAGE clusters: the read goes back to k_cluster_small (returns true).  Whole waves.
 __device__ __forceinline__ bool cl_emit64(uint32_t p, uint32_t Pj, uint32_t qj, uint32_t rj, uint32_t *__restrict__ r_cl,
                                           uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
-                                          uint32_t &nsmall) {
+                                          uint32_t &nsmall, uint32_t &dmax) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t nthr = 2 + qj / 7;                     // sga.erl:46
     const uint32_t prev = __shfl_up(p, 1, 64), next = __shfl_down(p, 1, 64);
@@ -654,6 +654,7 @@ __device__ __forceinline__ bool cl_emit64(uint32_t p, uint32_t Pj, uint32_t qj, 
             const uint32_t kk = __popcll(lane == 63 ? 0ull : (emask >> (lane + 1)));   // emitters above me
             r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = p;
             r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = p - pfirst;
+            dmax = p - pfirst > dmax ? p - pfirst : dmax;
         }
         if (lane == 0) r_K[rj] = Kc;
     } else if (lane == 0) {                               // more clusters than the staging row holds: k_cluster_small redoes it
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     // glist != null: only the groups k_seed_fast handed back (it wrote nothing for them)
     const uint32_t groups = glist ? *gcount : (n + rw - 1) / rw;
-    uint32_t live = 0, looked = 0, nsmall = 0;
+    uint32_t live = 0, looked = 0, nsmall = 0, dmax = 0;
     unsigned long long Psum = 0;
     for (uint32_t gi = wave; gi < groups; gi += nwaves) {
         const uint32_t g = glist ? glist[gi] : gi;
@@ -919,12 +920,12 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                     bool fba, fbb = false;
                     if (last) {
                         pa = wave_sort_u32(pa);
-                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
+                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall, dmax);
                     } else {
                         uint32_t pb = lane < Pj ? lp[j * CL_ROW + lane] : 0xffffffffu;
                         wave_sort2_u32(pa, pb);
-                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall);
-                        fbb = cl_emit64(pb, Pj, qj, g * rw + j, r_cl, r_K, r_P, r_qty, nsmall);
+                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall, dmax);
+                        fbb = cl_emit64(pb, Pj, qj, g * rw + j, r_cl, r_K, r_P, r_qty, nsmall, dmax);
                     }
                     if (lean && valid && ((fba && lread == ja) || (fbb && lread == j))) {
                         t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
@@ -975,6 +976,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                                 const uint32_t kk = above + (uint32_t)__popcll(lane == 63 ? 0ull : (em[q] >> (lane + 1)));
                                 r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk] = pe;
                                 r_cl[(uint64_t)rj * (2 * CL_STAGE) + 2 * kk + 1] = pe - row[s_of[q]];
+                                dmax = pe - row[s_of[q]] > dmax ? pe - row[s_of[q]] : dmax;
                             }
                             above += (uint32_t)__popcll(em[q]);
                         }
@@ -990,6 +992,8 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         }
     }
     readq_drain(rq, bigq, mid2q, mid4q, ctr);
+    dmax = wave_max_u32(dmax);
+    if (lane == 0 && dmax) atomicMax(&ctr->max_D, dmax);
     unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
     if (lane == 0 && (l | k | s | ns)) {
         atomicAdd(&ctr->n_tasks, l);
@@ -1067,6 +1071,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     const uint32_t groups = (n + rw - 1) / rw;
     uint32_t live = 0, why = 0, why2 = 0;                          // why: hand-backs by reason (packed counts, flushed when a byte fills)
     unsigned long long Pacc = 0;                                   // seeds clustered here, per leader lane
+    uint32_t dmaxl = 0;                                            // widest cluster staged here
     // Software pipeline: when a pass starts on group g, g's table entries are already in flight (their loads were issued a
     // pass earlier, before the sorts of the group before it) and so are the plane windows of the group after g.  The pass
     // moves g's entries into the LDS staging area, issues the next group's table loads into the same registers and the
@@ -1315,6 +1320,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                     const uint32_t pe = row[e1], pf = row[s1];
                     cl[0] = pe; cl[1] = pe - pf;
                     cl += 2;
+                    dmaxl = pe - pf > dmaxl ? pe - pf : dmaxl;
                 }
             }
         }
@@ -1330,6 +1336,8 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);
         atomicAdd(&ctr->why[3], why >> 24); atomicAdd(&ctr->why[4], why2 & 0xffffu); atomicAdd(&ctr->why[5], why2 >> 16);
     }
+    dmaxl = wave_max_u32(dmaxl);
+    if (lane == 0 && dmaxl) atomicMax(&ctr->max_D, dmaxl);
     const unsigned long long Psum = wave_sum_u64(Pacc);
     if (lane == 0 && (live | Psum)) {
         atomicAdd(&ctr->n_tasks, (unsigned long long)live);
