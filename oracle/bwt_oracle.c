@@ -395,6 +395,54 @@ int orc_batch(const orc_fm *fm, const uint8_t *ref1, int64_t ref1_len, const uin
     return 0;
 }
 
+/* Per-read digests of the complete answer (every hit's score, pos, window and CIGAR text, in list order), for at-scale
+ * comparisons where aggregates are too coarse:
+ *   digest(read) = sum over its hits h (k = 1-based rank in the read's list) of
+ *                  k * (pos * 1000003 + score * 10007 + wlen * 101 + woff * 7 + sum_i text[i] * (i + 1)^2)      (mod 2^64)
+ * reads without a hit list digest to 0, reads the reference would crash on to 1 (the C ABI reports them). */
+typedef struct { const orc_fm *fm; const uint8_t *ref1; int64_t ref1_len; const uint8_t *bases; const uint32_t *off;
+                 uint32_t lo, hi; uint64_t *dig; } djob_t;
+static void *djob_run(void *p) {
+    djob_t *j = (djob_t *)p;
+    enum { CAP = 256 };
+    int32_t score[CAP]; int64_t pos[CAP], woff[CAP]; int32_t wlen[CAP];
+    char *cig = (char *)malloc(1 << 16);
+    for (uint32_t r = j->lo; r < j->hi; r++) {
+        const uint8_t *q = j->bases + j->off[r];
+        int lq = (int)(j->off[r + 1] - j->off[r]);
+        int n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen, cig, 1 << 16, CAP, 0);
+        uint64_t d = 0;
+        if (n < -1) d = 1;
+        const char *t = cig;
+        for (int k = 0; k < n; k++) {
+            uint64_t th = 0;
+            size_t len = strlen(t);
+            for (size_t i = 0; i < len; i++) th += (uint64_t)(uint8_t)t[i] * (uint64_t)((i + 1) * (i + 1));
+            d += (uint64_t)(k + 1) * ((uint64_t)pos[k] * 1000003ull + (uint64_t)(int64_t)score[k] * 10007ull + (uint64_t)wlen[k] * 101ull +
+                                      (uint64_t)woff[k] * 7ull + th);
+            t += len + 1;
+        }
+        j->dig[r] = d;
+    }
+    free(cig);
+    return 0;
+}
+int orc_batch_digest(const orc_fm *fm, const uint8_t *ref1, int64_t ref1_len, const uint8_t *bases, const uint32_t *off,
+                     uint32_t n_reads, int nthreads, uint64_t *dig) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    djob_t *jobs = (djob_t *)calloc(nthreads, sizeof(djob_t));
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].fm = fm; jobs[t].ref1 = ref1; jobs[t].ref1_len = ref1_len; jobs[t].bases = bases; jobs[t].off = off; jobs[t].dig = dig;
+        jobs[t].lo = (uint32_t)((uint64_t)n_reads * t / nthreads);
+        jobs[t].hi = (uint32_t)((uint64_t)n_reads * (t + 1) / nthreads);
+        pthread_create(&th[t], 0, djob_run, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], 0);
+    free(th); free(jobs);
+    return 0;
+}
+
 /* The I column from L: I[r] = C0[L[r]] + occ(L[r], r) - 1 with C0 = {$:0, A:1, C:Pc-1, G:Pg-1, T:Pt-1}
  * (bwt.erl:105-112 + fmi.erl:43-60: the K-th row whose L is c pops the K-th 0-based row whose F is c). */
 int orc_make_I(const uint8_t *L, uint32_t n, uint32_t Pc, uint32_t Pg, uint32_t Pt, uint32_t *I) {

@@ -151,3 +151,43 @@ def fs_find_seeds(pats, ref):
     n = lib().orc_fs_find_seeds(pats.ctypes.data_as(C.c_void_p), C.c_long(pats.shape[0]), int(pats.shape[1]), ref,
                                 C.c_long(len(ref)), out.ctypes.data_as(C.c_void_p), C.c_long(cap))
     return out[:n].tolist()
+
+
+def batch_digest(fm, ref1, bases, off, nthreads):
+    """Per-read digests of the complete answer (see bwt_oracle.c: orc_batch_digest) -> u64 array."""
+    bases = np.ascontiguousarray(bases, np.uint8); off = np.ascontiguousarray(off, np.uint32)
+    dig = np.zeros(len(off) - 1, np.uint64)
+    lib().orc_batch_digest(C.byref(fm.c), ref1, C.c_int64(len(ref1)), bases.ctypes.data_as(C.c_void_p),
+                           off.ctypes.data_as(C.c_void_p), C.c_uint32(len(off) - 1), int(nthreads), dig.ctypes.data_as(C.c_void_p))
+    return dig
+
+
+def hits_digest(out):
+    """The same digests from a hit table as the C ABI returns it (dict of arrays: read_status, hit_off, score, pos, win_off,
+    win_len, cig_off, cigar), vectorised."""
+    hoff = np.asarray(out["hit_off"]).astype(np.int64)
+    n = len(hoff) - 1
+    nh = int(hoff[-1])
+    dig = np.zeros(n, np.uint64)
+    st = np.asarray(out["read_status"])
+    dig[st < 0] = 1
+    if nh == 0:
+        return dig
+    coff = np.asarray(out["cig_off"]).astype(np.int64)
+    text = np.frombuffer(out["cigar"], np.uint8).astype(np.uint64)
+    lens = np.diff(coff)
+    idx = np.arange(len(text), dtype=np.int64) - np.repeat(coff[:-1], lens) + 1
+    th = np.zeros(nh, np.uint64)
+    nonempty = lens > 0
+    th[nonempty] = np.add.reduceat(text * (idx * idx).astype(np.uint64), coff[:-1][nonempty])
+    with np.errstate(over="ignore"):
+        v = (np.asarray(out["pos"]).astype(np.int64).astype(np.uint64) * np.uint64(1000003) +
+             np.asarray(out["score"]).astype(np.int64).astype(np.uint64) * np.uint64(10007) +
+             np.asarray(out["win_len"]).astype(np.int64).astype(np.uint64) * np.uint64(101) +
+             np.asarray(out["win_off"]).astype(np.int64).astype(np.uint64) * np.uint64(7) + th)
+        counts = np.diff(hoff)
+        rank = (np.arange(nh, dtype=np.int64) - np.repeat(hoff[:-1], counts) + 1).astype(np.uint64)
+        v = v * rank
+        has = counts > 0
+        dig[has] = np.add.reduceat(v, hoff[:-1][has])
+    return dig

@@ -222,3 +222,31 @@ def test_bwt_erl_test_queries_run(lit_fm, orc_fm):
           b"CAGCGGTGCGATCTCGGCTCACTGCAAGCTCTGTCTCCTGGGTTCACGCCATTCTCCTGC"]
     for q in qs:
         assert E.sga(lit_fm, q) == orc.sga(orc_fm, q)
+
+
+def test_digest_of_hit_tables_matches_the_c_oracle(orc_fm, ref_bytes):
+    """orc.hits_digest (numpy, over a hit table in the C ABI's layout) and orc_batch_digest (C, straight from align_read) are
+    the same function of the answer: built here from the oracle's own per-read results."""
+    import numpy as np
+    from conftest import synth_reads
+    from oracle import orc, erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = synth_reads(ref_bytes, 300, 100, 5, indel_frac=0.3, n_frac=0.1) + [b"ACGTACGX" * 13]
+    status, hoff, score, pos, woff, wlen, coff, text = [], [0], [], [], [], [], [0], b""
+    for q in reads:
+        try:
+            r = orc.align_read(orc_fm, ref1, q)
+        except RuntimeError:
+            status.append(-1); hoff.append(hoff[-1]); continue
+        status.append(1 if r is None else 0)
+        for (s, c, p, wo, wl) in (r or []):
+            score.append(s); pos.append(p); woff.append(wo); wlen.append(wl); text += c.encode(); coff.append(len(text))
+        hoff.append(len(score))
+    out = dict(read_status=np.array(status, np.int32), hit_off=np.array(hoff, np.uint64), score=np.array(score, np.int32),
+               pos=np.array(pos, np.int64), win_off=np.array(woff, np.int64), win_len=np.array(wlen, np.int32),
+               cig_off=np.array(coff, np.uint64), cigar=text)
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    off = np.zeros(len(reads) + 1, np.uint32); off[1:] = np.cumsum([len(r) for r in reads])
+    a = orc.hits_digest(out)
+    b = orc.batch_digest(orc_fm, ref1, bases, off, 4)
+    assert np.array_equal(a, b) and (a > 1).sum() > 100 and (a == 1).sum() == 1
