@@ -596,19 +596,28 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         else if (fast) {
             if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
             {
-                const size_t lds = sf_lds_bytes(maxT);
+                // reads of up to 14 sub-reads rarely pass 64 seeds: the one-register variant runs a wave more per SIMD
+                const char *env_big = getenv("BWT_SEED_BIG");           // experiments: 0 / 1 force the variant
+                const bool big = env_big ? env_big[0] == '1' : maxT > 14;
+                const size_t lds = sf_lds_bytes(maxT, big);
+                const void *kern = big ? (const void *)k_seed_fast<true> : (const void *)k_seed_fast<false>;
                 int &per_cu = b->occ_seed[3];
-                if (!per_cu || b->occ_seed_maxT != maxT) {
+                if (!per_cu || b->occ_seed_maxT != (maxT | (big ? 0x100u : 0u))) {
                     per_cu = 8;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_seed_fast, 256, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 4; }
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 4; }
                     per_cu = std::max(1, std::min(per_cu, 8));
-                    b->occ_seed_maxT = maxT;
+                    b->occ_seed_maxT = maxT | (big ? 0x100u : 0u);
                 }
                 const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
                 ProfScope ps(b, "fm_lookup");
-                hipLaunchKernelGGL(k_seed_fast, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
-                                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
-                                   b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
+                if (big)
+                    hipLaunchKernelGGL(k_seed_fast<true>, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
+                                       b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
+                                       b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
+                else
+                    hipLaunchKernelGGL(k_seed_fast<false>, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
+                                       b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
+                                       b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
             }
             KLAUNCH(b, "fm_lookup_rest", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), 1, b->ulen,
                     (const uint32_t *)b->gq.as<uint32_t>(), (const unsigned int *)&b->ctr.as<Counters>()->n_gq);

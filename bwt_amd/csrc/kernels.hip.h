@@ -1034,10 +1034,13 @@ __device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t idx, uint32_
     return (threadIdx.x & 63u) == idx ? v : old;
 }
 // dynamic LDS of a k_seed_fast block (4 waves)
-__host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT) {
+__host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT, bool big) {
     const uint32_t rw = 64u / maxT, nslot = (rw * maxT + 3u) & ~3u;
-    return 4u * 4u * (nslot * SF_SLOT * 4 + rw * SF_ROW + 128);
+    return 4u * 4u * (nslot * SF_SLOT * 4 + rw * (big ? SF_ROW : 64u) + 128);
 }
+// BIG: reads of up to 128 seeds (two registers per read; 106 VGPRs, 4 waves per SIMD); else up to 64 (95 VGPRs, 5 waves -- worth
+// 5 % on batches whose reads rarely pass 64 seeds, e.g. 100-bp reads)
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
@@ -1048,12 +1051,13 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     extern __shared__ uint4 sf_lds_[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t rw = 64u / maxT;
-    const uint32_t nslot = (rw * maxT + 3u) & ~3u, wave_words = nslot * SF_SLOT * 4 + rw * SF_ROW + 128;
+    constexpr uint32_t ROW = BIG ? SF_ROW : 64u;                     // seeds a read's row holds
+    const uint32_t nslot = (rw * maxT + 3u) & ~3u, wave_words = nslot * SF_SLOT * 4 + rw * ROW + 128;
     uint32_t *wbase = (uint32_t *)sf_lds_ + wv * wave_words;
     uint4 *stag = (uint4 *)wbase;
     uint32_t *rows = wbase + nslot * SF_SLOT * 4;
     WaveQ q;
-    q.buf = rows + rw * SF_ROW; q.have = 0;
+    q.buf = rows + rw * ROW; q.have = 0;
     const uint32_t lread = lane / maxT, slot = lane - lread * maxT, seg0 = lread * maxT;
     const uint32_t ql = lane & 3u;
     // lane constants of the slot: sub-read end, step limit = table level, bits of the 16-base window that belong to the read
@@ -1137,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const bool seeds = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
         const uint32_t c = seeds ? wd + 1u : 0u;
         // (a task with more seeds than a row holds: its read is over the limit anyway, and the packed scan below must not overflow)
-        abn = abn || (act && wd == KT_OVF) || c > SF_ROW;
+        abn = abn || (act && wd == KT_OVF) || c > ROW;
         if (__ballot(abn)) {                                           // hand the group back
             why += __ballot(abn0) ? 1u : __ballot(act && wd == KT_OVF) ? 1u << 8 : 0u;
             if (!__ballot(abn0) && !__ballot(act && wd == KT_OVF)) why2 += 1u;          // (a task over the row limit counts as a read over it)
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t Pq = hi - lo, P = Pq & 0xffffu, qty = Pq >> 16;
         const uint32_t dst = (incl - v - lo) & 0xffffu;
         const bool fuse_read = valid && qty >= 2 && P > 0;             // sga.erl:42-43
-        if (__ballot(fuse_read && P > SF_ROW)) {
+        if (__ballot(fuse_read && P > ROW)) {
             why2 += 1u;
             __builtin_amdgcn_wave_barrier();
             waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         }
         // every lane copies its own seeds (+ N + Shift) into its read's row
         {
-            uint32_t *row = rows + lread * SF_ROW + dst;
+            uint32_t *row = rows + lread * ROW + dst;
             // seeds that did not come with the entry -- everything of a task that ended below the top level, the seeds past the
             // first 14 of a top-level task -- are read from the SA, the whole wave on one task's range at a time (rare)
             const uint32_t inl = wide ? KT_INLINE : 0u;
@@ -1176,9 +1180,9 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                 more &= more - 1ull;
                 const uint32_t sp_s = (uint32_t)__builtin_amdgcn_readlane((int)own.x, src), c_s = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
                 const uint32_t add_s = (uint32_t)__builtin_amdgcn_readlane((int)nadd, src), from_s = (uint32_t)__builtin_amdgcn_readlane((int)inl, src);
-                const uint32_t dst_s = (uint32_t)__builtin_amdgcn_readlane((int)(lread * SF_ROW + dst), src);
+                const uint32_t dst_s = (uint32_t)__builtin_amdgcn_readlane((int)(lread * ROW + dst), src);
                 if (lane >= from_s && lane < c_s) rows[dst_s + lane] = ix.sa[sp_s - 1 + lane] + add_s;
-                if (lane + 64 < c_s) rows[dst_s + 64 + lane] = ix.sa[sp_s - 1 + 64 + lane] + add_s;
+                if (BIG && lane + 64 < c_s) rows[dst_s + 64 + lane] = ix.sa[sp_s - 1 + 64 + lane] + add_s;
             }
             const uint32_t cw = fuse_read ? (c < inl ? c : inl) : 0u;
             if (cw > 0) row[0] = own.z + nadd;
@@ -1212,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         // p[i] - p[i-1] > TOLERANCE) into the read's leader lane; get_similar itself then runs ONCE for all reads of the pass,
         // on lane masks held as integers in the leader lanes (sga.erl:42-64).
         const unsigned long long bfall = __ballot(fuse_read && slot == 0);   // bit seg0 of every read to cluster
-        const unsigned long long bfbig = __ballot(fuse_read && slot == 0 && P > 64);
+        const unsigned long long bfbig = BIG ? __ballot(fuse_read && slot == 0 && P > 64) : 0ull;
         unsigned long long bf = bfall & ~bfbig;
         uint32_t smlo = 0, smhi = 0, sm2lo = 0, sm2hi = 0;                   // run starts of elements 0..63 / 64..127
         uint32_t left = (uint32_t)__popcll(bf);
@@ -1228,7 +1232,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                     bf &= bf - 1ull;
                     jj[t] = (uint32_t)bb[t] / maxT;
                     const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, bb[t]);
-                    pp[t] = lane < Pj ? rows[jj[t] * SF_ROW + lane] : 0xffffffffu;
+                    pp[t] = lane < Pj ? rows[jj[t] * ROW + lane] : 0xffffffffu;
                 }
             }
             if (take == 1) { uint32_t a[1] = {pp[0]}; mirror_sort64(a, SM); pp[0] = a[0]; }
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if ((uint32_t)t < take) {
-                    rows[jj[t] * SF_ROW + lane] = pp[t];
+                    rows[jj[t] * ROW + lane] = pp[t];
                     uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pp[t], 0x138, 0xF, 0xF, false);   // wave_shr:1
                     // Keep the shift a plain v_mov_b32_dpp: folded into the subtraction (v_subrev_u32_dpp d, p, p wave_shr:1) this
                     // part returns prev - p instead of p - prev (measured, scripts/dpp_probe.hip).
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             const int b1 = __ffsll((long long)bg) - 1;
             const uint32_t j1 = (uint32_t)b1 / maxT;
             const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, b1);
-            uint32_t *row = rows + j1 * SF_ROW;
+            uint32_t *row = rows + j1 * ROW;
             uint32_t a[2] = {row[lane], lane + 64 < Pj ? row[64 + lane] : 0xffffffffu};
             mirror_sort64(a, SM);
             const uint32_t rv = (uint32_t)__builtin_amdgcn_ds_bpermute(SM.mirror63, (int)a[1]);
@@ -1302,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         // the group's results
         {
             uint32_t *cl = r_cl + (uint64_t)r * (2 * CL_STAGE);
-            const uint32_t *row = rows + lread * SF_ROW;
+            const uint32_t *row = rows + lread * ROW;
             while (__ballot((em0 | em1) != 0)) {
                 if (em0 | em1) {
                     int e1, s1;
