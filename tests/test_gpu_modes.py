@@ -207,3 +207,48 @@ def test_pipe_overlapped_batches_equal_align_batch(gpu_index, ref_bytes):
             assert np.array_equal(g[k], w[k]), k
         assert g["cigar"] == w["cigar"]
         assert g["counts"]["n_hits"] == len(w["score"])
+
+
+@pytest.fixture(scope="module")
+def repeat_index():
+    """A 2 M-row genome with a 400-bp segment in 7 copies (reads from it carry 60..130 seeds and several clusters), K = 15 wide."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(123)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 2_000_000, dtype=np.uint8)].tobytes())
+    seg = bytes(g[5000:5400])
+    for k in range(1, 7):
+        g[250_000 * k:250_000 * k + 400] = seg
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=2)
+    ix.set_ktable(15, 1)
+    L, SA = ix.export()
+    ptr, shift = ix.meta()
+    yield ix, ref, orc.OrcFM.from_L_SA(L, SA, ptr, shift), E.make_ref1(ref)
+    ix.close()
+
+
+@pytest.mark.parametrize("length", [64, 71, 72, 89, 96, 111, 112, 120, 128, 150, 168, 175])
+def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
+    """Every number of sub-reads per read the fast seed kernel takes (8..21: 8..3 reads per wave pass), in both variants
+    (one / two registers per read), against the oracle -- with reads from a repeat (many seeds, several clusters), indels, N."""
+    from bwt_amd import lib
+    ix, ref, ofm, ref1 = repeat_index
+    reads = (synth_reads(ref, 300, length, 800 + length, max_subs=2) + synth_reads(ref, 60, length, 801 + length, indel_frac=1.0) +
+             synth_reads(ref, 20, length, 802 + length, n_frac=1.0) +
+             [ref[5000 + 3 * i:5000 + 3 * i + length] for i in range(40)] + [ref[250_000 + 11 * i:250_000 + 11 * i + length] for i in range(20)])
+    packed = lib.pack_reads(reads)
+    kept = []
+    for big in ("0", "1"):
+        monkeypatch.setenv("BWT_SEED_BIG", big)
+        b = lib.Batch(ix)
+        b.set_reads(*packed)
+        c = b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        b.destroy()
+        assert check_against_oracle(out, reads, ofm, ref1) > 100
+        groups = -(-len(reads) // (64 // (length // 8)))
+        kept.append(groups - c["n_handed_back"])
+    # the fast kernel really took groups (on this small genome the 8..10-base last sub-reads of the longest reads alone bring ~30
+    # seeds: past 64 per read for the one-register variant); the two-register variant keeps at least as many
+    assert kept[1] > 0 and kept[1] >= kept[0]
