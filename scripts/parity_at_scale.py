@@ -58,7 +58,7 @@ def main():
         print("cpu %d / %d" % (hi, n), file=sys.stderr, flush=True)
     t_cpu = time.perf_counter() - t0
     bad = np.nonzero(gpu != cpu)[0]
-    out = {"workload": "GRCh38-scale i.i.d. genome of %d bp, %d reads of %d bp: 3/4 with 0-2 substitutions, 1/4 with an indel of 1-5 bp "
+    out = {"workload": "i.i.d. genome of %d bp, %d reads of %d bp: 3/4 with 0-2 substitutions, 1/4 with an indel of 1-5 bp "
                        "as well, 2 %% of the reads with an N or IUPAC base" % (a.genome_len, n, L),
            "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order)",
            "reads": n, "reads_with_hits": int((np.diff(hits["hit_off"].astype(np.int64)) > 0).sum()), "hits": int(c["n_hits"]),
