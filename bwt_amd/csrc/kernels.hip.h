@@ -2159,151 +2159,151 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
     unsigned long long cells = 0, wbytes = 0;                               // FROM_READS: what k_candidates totals
     uint32_t maxw = 0, maxlq = 0;
     for (uint32_t c0 = first; c0 < n_items; c0 += stride) {                 // whole waves iterate together
-      const uint32_t item = c0 + ((threadIdx.x & 63) >> 2);
-      uint32_t K_r = 1, kmax = 1;
-      uint64_t co_r = 0, qo_r = 0;
-      uint32_t lq_r = 0;
-      const uint32_t *cl_r = nullptr;
-      if (FROM_READS) {
-          K_r = item < n_items ? src.r_K[item] : 0u;
-          kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(K_r));
-          if (K_r) {
-              qo_r = src.off[item]; lq_r = (uint32_t)(src.off[item + 1] - qo_r);
-              co_r = src.clus_off[item];
-              // clusters staged by the seed kernels (RQ_DONE) sit in the read's r_cl row, the cluster kernels' in its slice of pos
-              cl_r = (src.r_qty[item] & RQ_DONE) ? src.r_cl + (uint64_t)item * (2 * CL_STAGE) : src.pos + src.seed_off[item];
-              maxlq = lq_r > maxlq ? lq_r : maxlq;
-          }
-      }
-      for (uint32_t kc = 0; kc < kmax; kc++) {                              // (one pass unless FROM_READS)
-        const uint32_t c = FROM_READS ? (uint32_t)(co_r + kc) : item;
-        int route = 0;                 // 0 nothing (idle / out of range / settled), 1 fp64 queue, 2 DP queue
-        // quad-uniform from here on: the four lanes of a quad hold the same candidate
-        const bool have = FROM_READS ? kc < K_r : c < n_items;
-        uint32_t lq, w;
-        int64_t wo;
-        uint64_t qo;
+        const uint32_t item = c0 + ((threadIdx.x & 63) >> 2);
+        uint32_t K_r = 1, kmax = 1;
+        uint64_t co_r = 0, qo_r = 0;
+        uint32_t lq_r = 0;
+        const uint32_t *cl_r = nullptr;
         if (FROM_READS) {
-            const uint32_t S = have ? cl_r[2 * kc] : 0u, D = have ? cl_r[2 * kc + 1] : 0u;
-            lq = have ? lq_r : 0u; w = have ? lq_r + D : 0u; qo = qo_r;
-            wo = (int64_t)S - (int64_t)w + BWT_REF_EXT;
-            if (have && ql == 0) {
-                src.c_S[c] = S; src.c_D[c] = D; src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_wlen[c] = w; src.c_woff[c] = wo;
-                cells += (unsigned long long)lq * w; wbytes += w;
-                maxw = w > maxw ? w : maxw;
+            K_r = item < n_items ? src.r_K[item] : 0u;
+            kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(K_r));
+            if (K_r) {
+                qo_r = src.off[item]; lq_r = (uint32_t)(src.off[item + 1] - qo_r);
+                co_r = src.clus_off[item];
+                // clusters staged by the seed kernels (RQ_DONE) sit in the read's r_cl row, the cluster kernels' in its slice of pos
+                cl_r = (src.r_qty[item] & RQ_DONE) ? src.r_cl + (uint64_t)item * (2 * CL_STAGE) : src.pos + src.seed_off[item];
+                maxlq = lq_r > maxlq ? lq_r : maxlq;
             }
-        } else {
-            lq = have ? io.c_qlen[c] : 0u; w = have ? io.c_wlen[c] : 0u;
-            wo = have ? io.c_woff[c] : 0;
-            qo = have ? io.c_qoff[c] : 0;
         }
-        const bool oor = wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0;
-        const bool live = have && !oor;
-        if (have && oor && ql == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
-        const bool square = w == lq;
-        // one pass over read and window: bases outside ACGT anywhere, and (square window) the mismatches of the diagonal
-        // (square window) also the first mismatch f1 of diagonal +1 (q[k] against r[k+1]) and the last one, h, of diagonal -1
-        // (q[k+1] against r[k]): the two-mismatch case below needs them, and they come out of the words loaded here
-        uint32_t bad = 0, mism = 0, p1 = 0xffffffffu, p2 = 0, f1 = 0xffffffffu, h = 0;
-        const uint32_t lqmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live ? lq : 0u));
-        for (uint32_t i0 = 0; i0 < lqmax; i0 += 128) {                      // wave-uniform trip count, DPP inside
-            const uint32_t i = i0 + 32u * (uint32_t)ql;
-            const bool in = live && i0 < lq;                               // (a shorter read of the wave: stay inside its planes)
-            uint32_t qlo1, qhi1, wlo1, whi1;
-            const uint4 q4 = quad_planes4(qp, in ? qo + i0 : 0, ql, qlo1, qhi1);
-            const uint4 w4 = quad_planes4(wp, in && square ? (uint64_t)wo + i0 : 0, ql, wlo1, whi1);
-            if (live && i < lq) {
-                const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
-                bad |= (q4.z | q4.w) & mk;
-                if (square) {
+        for (uint32_t kc = 0; kc < kmax; kc++) {                              // (one pass unless FROM_READS)
+            const uint32_t c = FROM_READS ? (uint32_t)(co_r + kc) : item;
+            int route = 0;                 // 0 nothing (idle / out of range / settled), 1 fp64 queue, 2 DP queue
+            // quad-uniform from here on: the four lanes of a quad hold the same candidate
+            const bool have = FROM_READS ? kc < K_r : c < n_items;
+            uint32_t lq, w;
+            int64_t wo;
+            uint64_t qo;
+            if (FROM_READS) {
+                const uint32_t S = have ? cl_r[2 * kc] : 0u, D = have ? cl_r[2 * kc + 1] : 0u;
+                lq = have ? lq_r : 0u; w = have ? lq_r + D : 0u; qo = qo_r;
+                wo = (int64_t)S - (int64_t)w + BWT_REF_EXT;
+                if (have && ql == 0) {
+                    src.c_S[c] = S; src.c_D[c] = D; src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_wlen[c] = w; src.c_woff[c] = wo;
+                    cells += (unsigned long long)lq * w; wbytes += w;
+                    maxw = w > maxw ? w : maxw;
+                }
+            } else {
+                lq = have ? io.c_qlen[c] : 0u; w = have ? io.c_wlen[c] : 0u;
+                wo = have ? io.c_woff[c] : 0;
+                qo = have ? io.c_qoff[c] : 0;
+            }
+            const bool oor = wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0;
+            const bool live = have && !oor;
+            if (have && oor && ql == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
+            const bool square = w == lq;
+            // one pass over read and window: bases outside ACGT anywhere, and (square window) the mismatches of the diagonal
+            // (square window) also the first mismatch f1 of diagonal +1 (q[k] against r[k+1]) and the last one, h, of diagonal -1
+            // (q[k+1] against r[k]): the two-mismatch case below needs them, and they come out of the words loaded here
+            uint32_t bad = 0, mism = 0, p1 = 0xffffffffu, p2 = 0, f1 = 0xffffffffu, h = 0;
+            const uint32_t lqmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live ? lq : 0u));
+            for (uint32_t i0 = 0; i0 < lqmax; i0 += 128) {                      // wave-uniform trip count, DPP inside
+                const uint32_t i = i0 + 32u * (uint32_t)ql;
+                const bool in = live && i0 < lq;                               // (a shorter read of the wave: stay inside its planes)
+                uint32_t qlo1, qhi1, wlo1, whi1;
+                const uint4 q4 = quad_planes4(qp, in ? qo + i0 : 0, ql, qlo1, qhi1);
+                const uint4 w4 = quad_planes4(wp, in && square ? (uint64_t)wo + i0 : 0, ql, wlo1, whi1);
+                if (live && i < lq) {
+                    const uint32_t mk = lq - i < 32 ? (1u << (lq - i)) - 1u : 0xffffffffu;
+                    bad |= (q4.z | q4.w) & mk;
+                    if (square) {
+                        bad |= (w4.z | w4.w) & mk;
+                        const uint32_t e = ((q4.x ^ w4.x) | (q4.y ^ w4.y)) & mk;
+                        if (e) {
+                            const uint32_t f = i + (uint32_t)__ffs((int)e) - 1u, l = i + 31u - (uint32_t)__clz((int)e);
+                            p1 = f < p1 ? f : p1; p2 = l > p2 ? l : p2;
+                            mism += __popc(e);
+                        }
+                        if (i + 1 < lq) {                                       // the Lq-1 pairs of the neighbouring diagonals
+                            const uint32_t mk1 = lq - 1 - i < 32 ? (1u << (lq - 1 - i)) - 1u : 0xffffffffu;
+                            const uint32_t eu = ((q4.x ^ wlo1) | (q4.y ^ whi1)) & mk1, ed = ((qlo1 ^ w4.x) | (qhi1 ^ w4.y)) & mk1;
+                            if (eu) { const uint32_t f = i + (uint32_t)__ffs((int)eu) - 1u; f1 = f < f1 ? f : f1; }
+                            if (ed) { const uint32_t l = i + 32u - (uint32_t)__clz((int)ed); h = l > h ? l : h; }   // k = bit + 1
+                        }
+                    }
+                }
+            }
+            const uint32_t wmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live && !square ? w : 0u));
+            for (uint32_t i0 = 0; i0 < wmax; i0 += 128) {
+                const uint32_t i = i0 + 32u * (uint32_t)ql;
+                const uint4 w4 = quad_planes4(wp, live && !square && i0 < w ? (uint64_t)wo + i0 : 0, ql);
+                if (live && !square && i < w) {
+                    const uint32_t mk = w - i < 32 ? (1u << (w - i)) - 1u : 0xffffffffu;
                     bad |= (w4.z | w4.w) & mk;
-                    const uint32_t e = ((q4.x ^ w4.x) | (q4.y ^ w4.y)) & mk;
-                    if (e) {
-                        const uint32_t f = i + (uint32_t)__ffs((int)e) - 1u, l = i + 31u - (uint32_t)__clz((int)e);
-                        p1 = f < p1 ? f : p1; p2 = l > p2 ? l : p2;
-                        mism += __popc(e);
-                    }
-                    if (i + 1 < lq) {                                       // the Lq-1 pairs of the neighbouring diagonals
-                        const uint32_t mk1 = lq - 1 - i < 32 ? (1u << (lq - 1 - i)) - 1u : 0xffffffffu;
-                        const uint32_t eu = ((q4.x ^ wlo1) | (q4.y ^ whi1)) & mk1, ed = ((qlo1 ^ w4.x) | (qhi1 ^ w4.y)) & mk1;
-                        if (eu) { const uint32_t f = i + (uint32_t)__ffs((int)eu) - 1u; f1 = f < f1 ? f : f1; }
-                        if (ed) { const uint32_t l = i + 32u - (uint32_t)__clz((int)ed); h = l > h ? l : h; }   // k = bit + 1
-                    }
                 }
             }
-        }
-        const uint32_t wmax = __builtin_amdgcn_readfirstlane((int)wave_max_u32(live && !square ? w : 0u));
-        for (uint32_t i0 = 0; i0 < wmax; i0 += 128) {
-            const uint32_t i = i0 + 32u * (uint32_t)ql;
-            const uint4 w4 = quad_planes4(wp, live && !square && i0 < w ? (uint64_t)wo + i0 : 0, ql);
-            if (live && !square && i < w) {
-                const uint32_t mk = w - i < 32 ? (1u << (w - i)) - 1u : 0xffffffffu;
-                bad |= (w4.z | w4.w) & mk;
+            bad = quad_or(bad); mism = quad_sum(mism); p1 = quad_min(p1); p2 = quad_max(p2);
+            bool done = false;
+            int score = 2 * (int)lq;
+            const bool clean = live && !bad;
+            if (live && bad) { if (ql == 0) io.c_status[c] = CS_NEED_FP; route = 1; }
+            // square window: one full diagonal with m mismatches at p1 <= p2, score 2*Lq - 3m.  Every other path
+            // into a diagonal cell or into the last row holds u >= 1 insertions, and a run of g gap steps costs
+            // g + 1: u >= 2 loses >= 7, u = 1 loses >= 4.  m <= 1 (loss <= 3): the diagonal is the unique optimum.
+            // m = 2 (loss 6): only two kinds of path can reach it -- one insertion and otherwise all matches:
+            //   (a) into a diagonal cell past p2: start one column in, ride diagonal +1 (q[k] = r[k+1]) for every
+            //       k < t, insert q[t], t >= p2: exists iff the first f1 = #leading matches on diagonal +1 >= p2;
+            //   (b) into the last row at column Lq-1 (a tie there would be the LEFTMOST maximum): main diagonal
+            //       for k < t <= p1, insert q[t], then diagonal -1 (q[k] = r[k-1]) for every k > t: exists iff
+            //       the highest mismatch on diagonal -1 sits at h <= p1.
+            // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
+            // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
+            if (clean && square) { done = mism <= 1 && lq >= 8; score -= 3 * (int)mism; }
+            if (clean && square && mism == 2 && lq >= 8) {
+                f1 = quad_min(f1); h = quad_max(h);
+                if (f1 == 0xffffffffu) f1 = lq - 1;
+                done = !(f1 >= p2) && !(h <= p1);
             }
-        }
-        bad = quad_or(bad); mism = quad_sum(mism); p1 = quad_min(p1); p2 = quad_max(p2);
-        bool done = false;
-        int score = 2 * (int)lq;
-        const bool clean = live && !bad;
-        if (live && bad) { if (ql == 0) io.c_status[c] = CS_NEED_FP; route = 1; }
-        // square window: one full diagonal with m mismatches at p1 <= p2, score 2*Lq - 3m.  Every other path
-        // into a diagonal cell or into the last row holds u >= 1 insertions, and a run of g gap steps costs
-        // g + 1: u >= 2 loses >= 7, u = 1 loses >= 4.  m <= 1 (loss <= 3): the diagonal is the unique optimum.
-        // m = 2 (loss 6): only two kinds of path can reach it -- one insertion and otherwise all matches:
-        //   (a) into a diagonal cell past p2: start one column in, ride diagonal +1 (q[k] = r[k+1]) for every
-        //       k < t, insert q[t], t >= p2: exists iff the first f1 = #leading matches on diagonal +1 >= p2;
-        //   (b) into the last row at column Lq-1 (a tie there would be the LEFTMOST maximum): main diagonal
-        //       for k < t <= p1, insert q[t], then diagonal -1 (q[k] = r[k-1]) for every k > t: exists iff
-        //       the highest mismatch on diagonal -1 sits at h <= p1.
-        // (one insertion + one deletion only ties a diagonal cell, where up_left wins the tie.)  Neither exists:
-        // every diagonal cell keeps its prefix score as up_left and the last row peaks at column Lq alone.
-        if (clean && square) { done = mism <= 1 && lq >= 8; score -= 3 * (int)mism; }
-        if (clean && square && mism == 2 && lq >= 8) {
-            f1 = quad_min(f1); h = quad_max(h);
-            if (f1 == 0xffffffffu) f1 = lq - 1;
-            done = !(f1 >= p2) && !(h <= p1);
-        }
-        const bool slide = clean && !square && w > lq && w - lq <= 64;
-        if (__ballot(slide)) {
-            // exact match on some diagonal d = 0 .. W - Lq: lane q tries d = q, q+4, ... on its own (most diagonals fail in
-            // their first 32 bases); any hit settles the candidate -- {2Lq, "<Lq>M"} does not depend on which
-            uint32_t hit = 0;
-            if (slide)
-                for (uint32_t d = (uint32_t)ql; d + lq <= w && !hit; d += 4) {
-                    bool all = true;
-                    for (uint32_t i = 0; i < lq && all; i += 32) {
-                        const uint4 q4 = planes4(qp, qo + i), w4 = planes4(wp, (uint64_t)wo + d + i);
-                        uint32_t e = (q4.x ^ w4.x) | (q4.y ^ w4.y);
-                        if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
-                        all = e == 0;
+            const bool slide = clean && !square && w > lq && w - lq <= 64;
+            if (__ballot(slide)) {
+                // exact match on some diagonal d = 0 .. W - Lq: lane q tries d = q, q+4, ... on its own (most diagonals fail in
+                // their first 32 bases); any hit settles the candidate -- {2Lq, "<Lq>M"} does not depend on which
+                uint32_t hit = 0;
+                if (slide)
+                    for (uint32_t d = (uint32_t)ql; d + lq <= w && !hit; d += 4) {
+                        bool all = true;
+                        for (uint32_t i = 0; i < lq && all; i += 32) {
+                            const uint4 q4 = planes4(qp, qo + i), w4 = planes4(wp, (uint64_t)wo + d + i);
+                            uint32_t e = (q4.x ^ w4.x) | (q4.y ^ w4.y);
+                            if (lq - i < 32) e &= (1u << (lq - i)) - 1u;
+                            all = e == 0;
+                        }
+                        if (all) hit = 1;
                     }
-                    if (all) hit = 1;
-                }
-            hit = quad_or(hit);
-            if (slide) done = hit != 0;
-        }
-        if (clean) {
-            if (!done) { if (ql == 0) io.c_status[c] = CS_PENDING; route = 2; }
-            else if (ql == 0) {
-                // "<Lq>M": only its length is recorded (CIG_DIAG: k_hits_write prints it from the window length, which equals
-                // Lq here) -- no scattered write into the candidate's text slot
-                uint32_t len = 2;
-                for (uint32_t v = lq; v >= 10; v /= 10) len++;
-                io.c_score[c] = score;
-                io.c_ciglen[c] = len | (square ? CIG_DIAG : 0u);
-                if (!square) {                                   // (exact match on a shifted diagonal: the window is wider than Lq)
-                    uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
-                    int p = (int)io.cig_stride, l2 = 0;
-                    cig_emit(slot, p, l2, lq, 'M');
-                }
-                io.c_status[c] = len > io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                hit = quad_or(hit);
+                if (slide) done = hit != 0;
             }
+            if (clean) {
+                if (!done) { if (ql == 0) io.c_status[c] = CS_PENDING; route = 2; }
+                else if (ql == 0) {
+                    // "<Lq>M": only its length is recorded (CIG_DIAG: k_hits_write prints it from the window length, which equals
+                    // Lq here) -- no scattered write into the candidate's text slot
+                    uint32_t len = 2;
+                    for (uint32_t v = lq; v >= 10; v /= 10) len++;
+                    io.c_score[c] = score;
+                    io.c_ciglen[c] = len | (square ? CIG_DIAG : 0u);
+                    if (!square) {                                   // (exact match on a shifted diagonal: the window is wider than Lq)
+                        uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+                        int p = (int)io.cig_stride, l2 = 0;
+                        cig_emit(slot, p, l2, lq, 'M');
+                    }
+                    io.c_status[c] = len > io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                }
+            }
+            // the two queues, staged in LDS (one atomic per 64 entries)
+            waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
+            waveq_push(qdp, route == 2 && ql == 0, c, io.dq, &io.ctr->dq_count);
         }
-        // the two queues, staged in LDS (one atomic per 64 entries)
-        waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
-        waveq_push(qdp, route == 2 && ql == 0, c, io.dq, &io.ctr->dq_count);
-      }
-    }
+        }
     waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
     waveq_drain(qdp, io.dq, &io.ctr->dq_count);
     if (FROM_READS) {
