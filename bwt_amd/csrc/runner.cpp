@@ -1,0 +1,175 @@
+// libbwtgpu: bwt_run_fastq -- the whole job the reference's master and one worker do for a FASTQ file, natively:
+//   master:produce_workload (src/master.erl:162-178: lists of 200 reads, ten lists per workload), the worker's `running` clause
+//   for every list (src/worker_bwt.erl:73-112: sga + sw per read, then the pick among several alignments by lists:sort/2 with the
+//   comparator R1 > R2, :99-106), and the master's result sink (src/master.erl:149-155: a line per cast whose score reaches the
+//   threshold) -- with the casts in the order the reference sends them: workloads in file order, inside a workload the lists
+//   newest first (produce_workload prepends), inside a list the reads in file order (read_seqs prepends, the worker's fold
+//   prepends again).
+// FASTQ records are parsed by the threaded reader straight into a pipe slot's pinned buffers (bwt_pipe: upload, kernels and download
+// of consecutive batches overlap), picked and printed on the host.  Transport (navel) and the gen_server shell stay out of scope.
+#include "common.h"
+#include "otp_sort.h"
+
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+struct SlotHost { std::vector<char> names; std::vector<uint64_t> name_off; uint32_t n = 0; int state = 0; };
+
+inline char *put_int(char *p, long long v) {
+    char tmp[24];
+    int k = 0;
+    unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+    do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *p++ = '-';
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+}  // namespace
+
+extern "C" int bwt_otp_pick(const int32_t *scores, uint32_t n) {
+    // index of the head of lists:sort(fun(A, B) -> score(A) > score(B) end, L) for L = the candidates in list order
+    if (!scores || !n) return -1;
+    if (n == 1) return 0;
+    otp::L l(n);
+    for (uint32_t i = 0; i < n; i++) l[i] = (int)i;
+    auto fun = [&](int a, int b) { return scores[a] > scores[b]; };
+    return otp::sort(fun, l)[0];
+}
+
+extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *chromosome, int32_t threshold, uint32_t batch_reads,
+                             const char *out_path, bwt_run_stats *stats) {
+    if (!ix || !fastq_path || !chromosome) return fail(BWT_EINVAL, "bwt_run_fastq: null argument");
+    const uint32_t LIST = 200, LISTS = 10, WL = LIST * LISTS;              // master.erl:59, worker_bwt.erl:16
+    if (!batch_reads) batch_reads = 2000000;
+    batch_reads = std::max<uint32_t>(WL, batch_reads / WL * WL);           // whole workloads per batch: the cast order does not straddle batches
+    const auto t0 = std::chrono::steady_clock::now();
+    bwt_run_stats st;
+    memset(&st, 0, sizeof st);
+    bwt_fastq *fq = nullptr;
+    int rc = bwt_fastq_open(fastq_path, &fq);
+    if (rc) return rc;
+    struct FQG { bwt_fastq *f; ~FQG() { bwt_fastq_close(f); } } fqg{fq};
+    FILE *out = nullptr;
+    if (out_path && !(out = fopen(out_path, "wb"))) return fail(BWT_EIO, std::string("cannot create ") + out_path);
+    struct OG { FILE *f; ~OG() { if (f) fclose(f); } } og{out};
+    const uint32_t depth = 3;
+    bwt_pipe *pipe = nullptr;
+    if ((rc = bwt_pipe_create(ix, depth, &pipe))) return rc;
+    struct PG { bwt_pipe *p; ~PG() { bwt_pipe_destroy(p); } } pg{pipe};
+    std::vector<SlotHost> host(depth);
+    const size_t clen = strlen(chromosome);
+    uint64_t bases_cap = (uint64_t)batch_reads * 160 + 4096;
+    bool eof = false;
+    uint32_t inflight = 0;
+    std::vector<char> text;
+    std::vector<uint32_t> sel;            // per read of the batch: the picked hit, or ~0u
+    std::vector<int64_t> gwoff; std::vector<int32_t> gwlen; std::vector<uint64_t> goff; std::vector<uint8_t> gwin;
+    std::vector<int32_t> sc;
+
+    auto consume = [&]() -> int {
+        bwt_pipe_result r;
+        int rc2 = bwt_pipe_wait(pipe, &r);
+        if (rc2) return rc2;
+        SlotHost &h = host[r.slot];
+        const uint32_t n = r.n_reads;
+        // the pick (worker_bwt.erl:99-106) per read; array index i is file-order record n-1-i of the batch
+        sel.assign(n, ~0u);
+        uint64_t nsel = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const int32_t rs = r.read_status[i];
+            if (rs == 1) continue;                                          // sga returned []: nothing is cast (:77)
+            if (rs < 0) { st.crashes++; continue; }
+            st.with_clusters++;
+            const uint64_t a = r.hit_off[i], b = r.hit_off[i + 1];
+            if (a == b) { st.no_cigar++; continue; }
+            uint32_t pick = (uint32_t)a;
+            if (b - a > 1) {
+                sc.resize((size_t)(b - a));
+                for (uint64_t k = a; k < b; k++) sc[(size_t)(k - a)] = r.hits[k].score;
+                pick = (uint32_t)(a + (uint64_t)bwt_otp_pick(sc.data(), (uint32_t)(b - a)));
+            }
+            st.cigars++;
+            if (r.hits[pick].score >= threshold) { sel[i] = pick; nsel++; }
+        }
+        if (nsel && out) {
+            // RefSeq of the printed hits in one device gather, in array order
+            gwoff.resize((size_t)nsel); gwlen.resize((size_t)nsel); goff.resize((size_t)nsel + 1);
+            std::vector<uint32_t> gidx(n, 0);
+            uint64_t k = 0, wbytes = 0;
+            for (uint32_t i = 0; i < n; i++) if (sel[i] != ~0u) { gidx[i] = (uint32_t)k; gwoff[(size_t)k] = r.win_off[sel[i]]; gwlen[(size_t)k] = r.win_len[sel[i]]; wbytes += (uint64_t)r.win_len[sel[i]]; k++; }
+            gwin.resize((size_t)wbytes + 16);
+            uint64_t need = 0;
+            if ((rc2 = bwt_ref1_gather(ix, gwoff.data(), gwlen.data(), nsel, gwin.data(), wbytes, goff.data(), &need))) return rc2;
+            // the lines, in the reference's cast order
+            text.clear();
+            const uint32_t nlists = (n + LIST - 1) / LIST;
+            for (uint32_t w0 = 0; w0 < nlists; w0 += LISTS) {
+                const uint32_t w1 = std::min(nlists, w0 + LISTS);
+                for (uint32_t li = w1; li-- > w0;) {
+                    const uint32_t f1 = std::min(n, (li + 1) * LIST);
+                    for (uint32_t f = li * LIST; f < f1; f++) {
+                        const uint32_t i = n - 1 - f;
+                        if (sel[i] == ~0u) continue;
+                        const uint32_t hsel = sel[i];
+                        const uint64_t nl = h.name_off[i + 1] - h.name_off[i], cl = r.cig_off[hsel + 1] - r.cig_off[hsel];
+                        const uint64_t g = gidx[i], wl = goff[(size_t)g + 1] - goff[(size_t)g];
+                        const size_t at = text.size();
+                        text.resize(at + nl + clen + cl + wl + 96);
+                        char *p = text.data() + at;
+                        *p++ = '\n';
+                        memcpy(p, h.names.data() + h.name_off[i], nl); p += nl;
+                        memcpy(p, "      ", 6); p += 6; memcpy(p, chromosome, clen); p += clen;
+                        memcpy(p, "      ", 6); p += 6; p = put_int(p, r.hits[hsel].pos);
+                        memcpy(p, "      ", 6); p += 6; memcpy(p, r.cigar + r.cig_off[hsel], cl); p += cl;
+                        memcpy(p, "      ", 6); p += 6; p = put_int(p, r.hits[hsel].score);
+                        memcpy(p, "      ", 6); p += 6; memcpy(p, gwin.data() + goff[(size_t)g], wl); p += wl;
+                        *p++ = '\n';
+                        text.resize((size_t)(p - text.data()));
+                        st.lines++;
+                    }
+                }
+            }
+            if (fwrite(text.data(), 1, text.size(), out) != text.size()) return fail(BWT_EIO, "bwt_run_fastq: short write");
+        } else
+            st.lines += nsel;
+        inflight--;
+        return bwt_pipe_release(pipe, r.slot);
+    };
+
+    while (!eof || inflight) {
+        if (!eof && inflight < depth) {
+            uint8_t *pb; uint64_t *po; uint32_t slot;
+            rc = bwt_pipe_acquire(pipe, bases_cap, batch_reads, &pb, &po, &slot);
+            if (rc == BWT_ENOSPC) { if ((rc = consume())) return rc; continue; }
+            if (rc) return rc;
+            SlotHost &h = host[slot];
+            h.names.resize((size_t)batch_reads * 48 + 4096);
+            h.name_off.resize((size_t)batch_reads + 1);
+            uint32_t k = 0; int state = 0; uint64_t need[2] = {0, 0};
+            rc = bwt_fastq_read_seqs(fq, batch_reads, pb, bases_cap, po, h.names.data(), h.names.size(), h.name_off.data(), &k, &state, need);
+            if (rc == BWT_ENOSPC) {                                         // longer reads / names than assumed: grow and take the slot again
+                bases_cap = std::max<uint64_t>(bases_cap, need[0] + 4096);
+                h.names.resize((size_t)need[1] + 4096);
+                (void)bwt_pipe_release(pipe, slot);
+                if ((rc = bwt_pipe_acquire(pipe, bases_cap, batch_reads, &pb, &po, &slot))) return rc;
+                SlotHost &h2 = host[slot];
+                h2.names.resize((size_t)need[1] + 4096); h2.name_off.resize((size_t)batch_reads + 1);
+                rc = bwt_fastq_read_seqs(fq, batch_reads, pb, bases_cap, po, h2.names.data(), h2.names.size(), h2.name_off.data(), &k, &state, need);
+            }
+            if (rc) { (void)bwt_pipe_release(pipe, slot); return rc; }
+            if (state != 0) eof = true;                                     // eof, with or without a last partial batch
+            if (k == 0) { (void)bwt_pipe_release(pipe, slot); continue; }
+            host[slot].n = k;
+            st.reads += k;
+            if ((rc = bwt_pipe_submit(pipe, slot, k))) return rc;
+            inflight++;
+        } else if ((rc = consume()))
+            return rc;
+    }
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+    return 0;
+}

@@ -21,6 +21,7 @@ EXPORTS = [
     "bwt_batch_fetch_hits_raw", "bwt_pipe_create", "bwt_pipe_destroy", "bwt_pipe_acquire", "bwt_pipe_submit", "bwt_pipe_wait",
     "bwt_pipe_release", "bwt_reverse_complement_batch", "bwt_batch_hits_to_device_global",
     "bwt_index_save_native", "bwt_index_open_native", "bwt_native_check", "bwt_fastq_set_threads",
+    "bwt_run_fastq", "bwt_otp_pick",
 ]
 
 
@@ -43,6 +44,10 @@ class BatchCounts(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class RunStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("reads", "with_clusters", "no_cigar", "cigars", "lines", "crashes")] + [("seconds", C.c_double)]
 
 
 HIT_REC = np.dtype([("read", np.uint32), ("score", np.int32), ("pos", np.int64)])
@@ -292,6 +297,20 @@ def reverse_complement_batch(bases, off, device=0):
     out = np.zeros(len(bases), np.uint8); st = np.zeros(n, np.int32)
     _chk(load().bwt_reverse_complement_batch(int(device), _p(bases), _p(off), C.c_uint32(n), _p(out), _p(st)))
     return out, st
+
+
+def otp_pick(scores):
+    """Index of the head of lists:sort(fun R1 > R2, L) for the candidates' scores in list order (bwt_otp_pick)."""
+    a = np.ascontiguousarray(scores, np.int32)
+    return int(load().bwt_otp_pick(_p(a), C.c_uint32(len(a))))
+
+
+def run_fastq(index, fastq_path, chromosome, threshold=265, batch_reads=0, out_path=None):
+    """bwt_run_fastq: master + worker over a whole FASTQ file -> dict of the run's statistics."""
+    st = RunStats()
+    _chk(load().bwt_run_fastq(index.h, os.fsencode(fastq_path), str(chromosome).encode(), C.c_int32(threshold), C.c_uint32(batch_reads),
+                              os.fsencode(out_path) if out_path else None, C.byref(st)))
+    return {k: (float if k == "seconds" else int)(getattr(st, k)) for k, _ in st._fields_}
 
 
 def seeds_generate_fs(qsec, length, defects):

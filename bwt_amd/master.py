@@ -96,6 +96,17 @@ def run(seq_file, chromosome, out=sys.stdout, threshold=CIGAR_RATE_THRESHOLD, de
     return s.stat_workload_amount, lines, sec
 
 
+def run_native(seq_file, chromosome, out_path=None, threshold=CIGAR_RATE_THRESHOLD, device=0, batch_reads=0):
+    """The same job through bwt_run_fastq: threaded FASTQ reader -> pinned-buffer pipeline -> pick -> result lines, all in the
+    library (no per-read Python).  Writes the result lines (not the statistics block) to out_path; returns the statistics."""
+    from . import lib
+    _, fm = fm_index.get_index(chromosome, 1, device)
+    try:
+        return lib.run_fastq(fm.index, seq_file, chromosome, threshold, batch_reads, out_path)
+    finally:
+        fm.close()
+
+
 def main(argv=None):
     import argparse
     import os
@@ -107,9 +118,15 @@ def main(argv=None):
     ap.add_argument("--threshold", type=int, default=CIGAR_RATE_THRESHOLD,
                     help="master.erl:149 drops results whose score is below this (265 silences every 100 bp read)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--native", metavar="OUT", help="run the whole job in the library (bwt_run_fastq) and write the result lines to OUT")
     a = ap.parse_args(argv)
     fm_index.set_env("fm_indices", a.fm_indices)
     path = a.seq_file if os.path.exists(a.seq_file) else os.path.join(a.bwt_files, a.seq_file)
+    if a.native:
+        st = run_native(path, a.chromosome, a.native, a.threshold, a.device)
+        sys.stdout.write("\n\nReads: %r\nChromosomes: %r\nReads aligned: %d\nAlignment completion time: %.1f sec\nWorkers: %d\n\n"
+                         % (path, a.chromosome, st["reads"], st["seconds"], 1))
+        return
     run(path, a.chromosome, threshold=a.threshold, device=a.device)
 
 

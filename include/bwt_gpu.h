@@ -284,6 +284,23 @@ int bwt_pipe_submit(bwt_pipe *p, uint32_t slot, uint32_t n_reads);
 int bwt_pipe_wait(bwt_pipe *p, bwt_pipe_result *res);
 int bwt_pipe_release(bwt_pipe *p, uint32_t slot);
 
+/* ------------------------------------------------------------------ the whole job for one FASTQ file
+ * What the reference's master and one worker do (src/master.erl:162-178 workload production, src/worker_bwt.erl:73-112 the
+ * running clause incl. the final pick by lists:sort/2 with the comparator R1 > R2, src/master.erl:149-155 the result sink):
+ * reads the FASTQ with the threaded reader straight into a bwt_pipe, picks per read, and writes to out_path one line
+ *     "\n<Name>      <Chromosome>      <Pos>      <Cigar>      <Score>      <RefSeq>\n"
+ * per cast whose score reaches `threshold` (master.erl:149 has 265), in the order the reference sends the casts.
+ * out_path NULL: count only.  batch_reads: reads per GPU batch (0 = 2 M; rounded to whole workloads of 2000).
+ * bwt_otp_pick: the index of the head of lists:sort(fun R1 > R2, L) for the scores of a read's candidates in list order
+ * (OTP's merge sort decides among equal scores; restated, see bwt_amd/csrc/otp_sort.h). */
+typedef struct {
+    uint64_t reads, with_clusters, no_cigar, cigars, lines, crashes;
+    double seconds;
+} bwt_run_stats;
+int bwt_run_fastq(bwt_index *idx, const char *fastq_path, const char *chromosome, int32_t threshold, uint32_t batch_reads,
+                  const char *out_path, bwt_run_stats *stats);
+int bwt_otp_pick(const int32_t *scores, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,16 @@ def test_threaded_reader_equals_sequential_and_literal(tmp_path, kind, threads):
         got_any = got_any or (a != "eof" and len(a[1]) > 0)
     assert got_any
     par.close(); seq.close()
+
+
+def test_native_pick_equals_otp_sort_head():
+    """bwt_otp_pick (C++ restatement of lists:sort/2 in the library) against the Python twin: the head of the sorted candidate
+    list for the comparator of worker_bwt.erl:104, ties included."""
+    import random
+    from bwt_amd import lib, otp_lists
+    rng = random.Random(11)
+    for _ in range(5000):
+        n = rng.randrange(1, 16)
+        sc = [rng.randrange(0, rng.choice([1, 2, 3, 6, 100])) for _ in range(n)]
+        exp = otp_lists.sort(lambda a, b: sc[a] > sc[b], list(range(n)))[0]
+        assert lib.otp_pick(sc) == exp, sc

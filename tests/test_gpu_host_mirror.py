@@ -123,3 +123,31 @@ def test_reverse_complement(ref_bytes):
     assert fastq.reverse_complement(b"AACGTN") == b"NACGTT"
     with pytest.raises(ValueError):
         fastq.reverse_complement(b"ACGX")
+
+
+def test_native_runner_prints_what_the_mirror_prints(tmp_path, ref_bytes):
+    """bwt_run_fastq (threaded reader -> pipe -> pick -> sink, all native) against master.run (the per-QseqList Python mirror):
+    the same result lines in the same order on a FASTQ that spans several workloads and batches, with repeats (several
+    alignments per read, equal scores), indels and N; and the same counts."""
+    import io
+    import numpy as np
+    from bwt_amd import fm_index, master
+    from conftest import GOLDEN, synth_reads
+    rng = np.random.default_rng(3)
+    reads = synth_reads(ref_bytes, 5300, 100, 901, indel_frac=0.15, n_frac=0.05) + [ref_bytes[i:i + 100] for i in range(0, 3000, 37)]
+    fq = tmp_path / "r.fastq"
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@read.%d some words\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    fm_index.set_env("fm_indices", GOLDEN + "/fm_indices")
+    buf = io.StringIO()
+    n_reads, n_lines, _ = master.run(str(fq), "GL000193.1", out=buf, threshold=100)
+    text = buf.getvalue()
+    want = text[: text.index("\n\nReads: ")]
+    out = tmp_path / "native.txt"
+    st = master.run_native(str(fq), "GL000193.1", str(out), threshold=100, batch_reads=4000)
+    got = open(out, "r", encoding="latin1").read()
+    assert st["reads"] == n_reads == len(reads) and st["lines"] == n_lines > 2000
+    assert got == want
+    st2 = master.run_native(str(fq), "GL000193.1", None, threshold=265)
+    assert st2["lines"] == 0 and st2["cigars"] == st["cigars"] and st2["no_cigar"] == st["no_cigar"]
