@@ -11,6 +11,7 @@
 #include "otp_sort.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -69,9 +70,16 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
     std::vector<int64_t> gwoff; std::vector<int32_t> gwlen; std::vector<uint64_t> goff; std::vector<uint8_t> gwin;
     std::vector<int32_t> sc;
 
+    double t_parse = 0, t_wait = 0, t_pick = 0, t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     auto consume = [&]() -> int {
         bwt_pipe_result r;
+        const auto tw0 = now();
         int rc2 = bwt_pipe_wait(pipe, &r);
+        const auto tw1 = now();
+        t_wait += secs(tw0, tw1);
+        struct PickTimer { double &acc; std::chrono::steady_clock::time_point a; ~PickTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); } } pt{t_pick, tw1};
         if (rc2) return rc2;
         SlotHost &h = host[r.slot];
         const uint32_t n = r.n_reads;
@@ -149,7 +157,9 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
             h.names.resize((size_t)batch_reads * 48 + 4096);
             h.name_off.resize((size_t)batch_reads + 1);
             uint32_t k = 0; int state = 0; uint64_t need[2] = {0, 0};
+            const auto tp0 = now();
             rc = bwt_fastq_read_seqs(fq, batch_reads, pb, bases_cap, po, h.names.data(), h.names.size(), h.name_off.data(), &k, &state, need);
+            t_parse += secs(tp0, now());
             if (rc == BWT_ENOSPC) {                                         // longer reads / names than assumed: grow and take the slot again
                 bases_cap = std::max<uint64_t>(bases_cap, need[0] + 4096);
                 h.names.resize((size_t)need[1] + 4096);
@@ -170,6 +180,9 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
             return rc;
     }
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("BWT_RUN_DEBUG"))
+        fprintf(stderr, "[libbwtgpu] bwt_run_fastq: %.3f s = set-up %.3f + reader %.3f + waiting for the GPU %.3f + pick / sink %.3f + rest\n", st.seconds, t_setup,
+                t_parse, t_wait, t_pick);
     if (stats) *stats = st;
     return 0;
 }

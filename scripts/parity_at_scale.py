@@ -23,16 +23,36 @@ def main():
     ap.add_argument("--reads", type=int, default=4_000_000)
     ap.add_argument("--genome-len", type=int, default=3_100_000_000)
     ap.add_argument("--length", type=int, default=100)
+    ap.add_argument("--max-subs", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=0, help="plant this many copies of 40 segments of 600 bp each (reads from them: many seeds, several clusters)")
+    ap.add_argument("--seed", type=int, default=91)
     a = ap.parse_args()
     t0 = time.perf_counter()
     ref = bench.synth_genome(a.genome_len, seed=5)
+    rep_starts = []
+    if a.repeats:
+        ref = ref.copy()
+        rr = np.random.default_rng(a.seed + 7)
+        for s_ in range(40):
+            src = int(rr.integers(0, a.genome_len - 700))
+            seg = ref[src:src + 600].copy()
+            for _ in range(a.repeats):
+                dst = int(rr.integers(0, a.genome_len - 700))
+                ref[dst:dst + 600] = seg
+                rep_starts.append(dst)
     ix = lib.Index.build(ref, shift=1, device=0)
     n, L = a.reads, a.length
     # three quarters like the bench batch (0/1/2 substitutions), the rest with an indel; a sprinkle of N and IUPAC bases on top
-    b1, _ = bench.synth_reads(ref, n * 3 // 4, L, seed=91, max_subs=2)
-    b2, _ = bench.synth_reads(ref, n - n * 3 // 4, L, seed=92, max_subs=2, indel_p=1.0)
+    b1, _ = bench.synth_reads(ref, n * 3 // 4, L, seed=a.seed, max_subs=a.max_subs)
+    b2, _ = bench.synth_reads(ref, n - n * 3 // 4, L, seed=a.seed + 1, max_subs=a.max_subs, indel_p=1.0)
     bases = np.concatenate([b1, b2])
-    rng = np.random.default_rng(93)
+    rng = np.random.default_rng(a.seed + 2)
+    if rep_starts:                                   # a tenth of the reads from the planted repeats
+        k = n // 10
+        st = np.array(rep_starts, np.int64)[rng.integers(0, len(rep_starts), k)] + rng.integers(0, 600 - L, k)
+        rows = rng.choice(n, k, replace=False)
+        blk = ref[st[:, None] + np.arange(L)[None, :]]
+        bases.reshape(n, L)[rows] = blk
     dirty = rng.integers(0, n, n // 50)
     bases[dirty * L + rng.integers(0, L, len(dirty))] = np.frombuffer(b"NNNNRYKM", np.uint8)[rng.integers(0, 8, len(dirty))]
     off = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
@@ -58,8 +78,9 @@ def main():
         print("cpu %d / %d" % (hi, n), file=sys.stderr, flush=True)
     t_cpu = time.perf_counter() - t0
     bad = np.nonzero(gpu != cpu)[0]
-    out = {"workload": "i.i.d. genome of %d bp, %d reads of %d bp: 3/4 with 0-2 substitutions, 1/4 with an indel of 1-5 bp "
-                       "as well, 2 %% of the reads with an N or IUPAC base" % (a.genome_len, n, L),
+    out = {"workload": "i.i.d. genome of %d bp%s, %d reads of %d bp: 3/4 with 0-%d substitutions, 1/4 with an indel of 1-5 bp "
+                       "as well, 2 %% of the reads with an N or IUPAC base%s" % (a.genome_len, (" with 40 segments of 600 bp in %d copies each" % a.repeats) if a.repeats else "",
+                                                                                 n, L, a.max_subs, ", a tenth of the reads from the repeats" if a.repeats else ""),
            "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order)",
            "reads": n, "reads_with_hits": int((np.diff(hits["hit_off"].astype(np.int64)) > 0).sum()), "hits": int(c["n_hits"]),
            "reads_status_minus1": int((hits["read_status"] == -1).sum()), "dp_candidates": int(c["n_dp"]), "fp64_candidates": int(c["n_float"]),
