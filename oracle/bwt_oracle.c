@@ -404,15 +404,17 @@ typedef struct { const orc_fm *fm; const uint8_t *ref1; int64_t ref1_len; const 
                  uint32_t lo, hi; uint64_t *dig; } djob_t;
 static void *djob_run(void *p) {
     djob_t *j = (djob_t *)p;
-    enum { CAP = 256 };
-    int32_t score[CAP]; int64_t pos[CAP], woff[CAP]; int32_t wlen[CAP];
-    char *cig = (char *)malloc(1 << 16);
+    enum { CAP = 4096, CIGCAP = 1 << 20 };             /* (a read from a 300-copy repeat has 300 alignments; orc_sga itself stops at 4096 clusters) */
+    int32_t *score = (int32_t *)malloc(sizeof(int32_t) * CAP), *wlen = (int32_t *)malloc(sizeof(int32_t) * CAP);
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * CAP), *woff = (int64_t *)malloc(sizeof(int64_t) * CAP);
+    char *cig = (char *)malloc(CIGCAP);
     for (uint32_t r = j->lo; r < j->hi; r++) {
         const uint8_t *q = j->bases + j->off[r];
         int lq = (int)(j->off[r + 1] - j->off[r]);
-        int n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen, cig, 1 << 16, CAP, 0);
+        int n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen, cig, CIGCAP, CAP, 0);
         uint64_t d = 0;
-        if (n < -1) d = 1;
+        if (n == -4) d = 2;                              /* the oracle's own capacity: not an answer (never equals a GPU digest) */
+        else if (n < -1) d = 1;
         const char *t = cig;
         for (int k = 0; k < n; k++) {
             uint64_t th = 0;
@@ -424,7 +426,7 @@ static void *djob_run(void *p) {
         }
         j->dig[r] = d;
     }
-    free(cig);
+    free(cig); free(score); free(wlen); free(pos); free(woff);
     return 0;
 }
 int orc_batch_digest(const orc_fm *fm, const uint8_t *ref1, int64_t ref1_len, const uint8_t *bases, const uint32_t *off,
