@@ -322,6 +322,8 @@ struct bwt_batch {
     uint32_t cig_stride = 32;
     // sw slabs
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
+    DevBuf bq, slab_band;              // k_sw_band: the queue of what it passes on, its direction slab
+    bool band_ran = false;
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig;
@@ -433,7 +435,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -808,6 +810,21 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     }
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
 
+    // the DP queue first goes through the banded kernel: what its certificate covers is settled there (traceback included),
+    // the rest -- candidates far from any clean alignment, wide clusters -- moves on in a second queue that takes dq's place
+    const char *env_band = getenv("BWT_SW_BAND");                 // experiments / tests: 0 = full-rectangle kernels only (read per call)
+    b->band_ran = false;
+    if (io.dq && max_lq >= 2 && max_lq <= 4096 && !(env_band && env_band[0] == '0')) {
+        const uint32_t rows = max_lq + 1;
+        const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * 8));
+        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->slab_band.ensure((uint64_t)bblocks * 4 * rows * 128 * 4))) return rc;
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 8, b->stream));
+        KLAUNCH(b, "sw_band", k_sw_band<24>, bblocks, 256, io, b->bq.as<uint32_t>(), b->slab_band.as<uint32_t>(), rows);
+        HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->dq_count, &b->ctr.as<Counters>()->band_left, 4, hipMemcpyDeviceToDevice, b->stream));
+        io.dq = b->bq.as<uint32_t>();
+        b->band_ran = true;
+    }
+
     // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
     // lane-per-alignment work would run a handful of waves for the full serial length of a DP
     const char *env_wv = getenv("BWT_SW_WAVE");                   // experiments / tests: 0 = lane-per-alignment kernels only (read per call)
@@ -1000,7 +1017,10 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
         // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
         if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
-        counts->n_dp = b->hctr.dq_count; counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
+        counts->n_dp = b->band_ran ? b->hctr.band_in : b->hctr.dq_count;
+        counts->n_banded = b->band_ran ? b->hctr.band_in - b->hctr.band_left : 0;
+        counts->n_traced += counts->n_banded;
+        counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
         counts->n_handed_back = b->hctr.n_gq;
     }
     return 0;

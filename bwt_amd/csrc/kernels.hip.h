@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels_index.h"
 
@@ -2712,6 +2713,142 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
             io.c_score[c] = score;
             io.c_ciglen[c] = (uint32_t)len;
             io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sw_band<B>: the same DP on a band of B diagonals, with a certificate that makes the result the full rectangle's.
+//
+// Cells in diagonal coordinates: o = j - i, band o in [lo, lo + B) with lo = -x, x = (B - 1 - D) div 2, D = W - Lq (the
+// window is the read length plus the cluster's width: an alignment the cluster stands for starts and ends on diagonals
+// 0..D).  A lane owns one candidate and keeps the band's row in B registers; in place, from k = 0 upwards, cell k takes its
+// diagonal source from old[k], its up source from old[k+1] and its left source from new[k-1]; neighbours outside the band
+// count as minus infinity.  Directions: 2 bits per cell, two words per row into a per-wave HBM slab ([row][half][lane]).
+//
+// Why that is exact when the band's best last-row value S* is at least 2 Lq - 3x - 3 (DESIGN.md section 4b has the proof):
+// every value of the reference's table is the affine score (open -2, extend -1) of a real path, so whatever reaches a
+// band cell through cells outside the band is bounded: from the left (diagonal < -x: at least x + 1 more insertions than
+// deletions) by Z_L(i, o) = 2i - 3x - 5 - (o - lo), from the right (diagonal > D + x, to come back: insertions again) by
+// Z_R(i, o) = 2i - 3 (hi + 1 - o) - 1.  By induction over the cells in table order, a band cell either has the same value
+// AND direction in both tables or both values are <= Z = max(Z_L, Z_R); T - Z never decreases along a traceback walked
+// backwards; so with S* > max Z(last row) = 2 Lq - 3x - 4 the maximum, its leftmost column and the whole traceback are
+// those of the full table, and every row's maximum stays above the early-exit threshold of sw.erl:69 (3x + 3 <= 2 (Lq div 2)
+// is checked).  Candidates that are not eligible or whose S* is lower go on to the full-rectangle kernels untouched.
+#define SWB_XMIN 3
+template <int B>
+__global__ __launch_bounds__(256) void k_sw_band(SwIO io, uint32_t *__restrict__ rest, uint32_t *__restrict__ slab, uint32_t slab_rows) {
+    static_assert(B > 16 && B <= 32, "two direction words per row");
+    constexpr int XMAX = (B - 1) / 2;
+    constexpr int NEG = -(1 << 28);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_items = io.ctr->dq_count;
+    if (wave == 0 && lane == 0) io.ctr->band_in = n_items;
+    uint32_t *const dirs = slab + (uint64_t)wave * slab_rows * 128 + lane;           // [(i * 2 + half) * 64]
+    for (uint32_t g = wave; (uint64_t)g * 64 < n_items; g += nwaves) {
+        const uint32_t item = g * 64 + lane;
+        const bool have = item < n_items;
+        uint32_t c = 0, lq = 0, w = 0;
+        int64_t wo = 0;
+        uint64_t qo = 0;
+        if (have) { c = io.dq[item]; lq = io.c_qlen[c]; w = io.c_wlen[c]; wo = io.c_woff[c]; qo = io.c_qoff[c]; }
+        const int D = (int)w - (int)lq;
+        const int x = (B - 1 - D) >> 1;
+        const bool run = have && D >= 0 && D <= B - 1 - 2 * SWB_XMIN && lq >= 2 && lq < slab_rows &&
+                         3 * x + 3 <= 2 * (int)(lq / 2) && wo >= 32 && (uint64_t)wo + w <= io.rbuf_len;
+        bool settled = false;
+        if (run) {
+            int H[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) H[k] = 1;                                    // row 0: V = 0, stored as `left` (Uvalue -2 like undef)
+            uint32_t qlw = 0, qhw = 0, rl0 = 0, rh0 = 0, rl1, rh1;
+            const uint64_t P0 = (uint64_t)wo - (uint32_t)x;                          // Ref1 base of cell (1, k = 0)'s column
+            { const uint4 v = planes4(io.wplanes, P0); rl1 = v.x; rh1 = v.y; }
+            auto row = [&](uint32_t i, auto first) {
+                const uint32_t b = i - 1, sh = b & 31u;
+                if (sh == 0) {
+                    const uint4 qv = planes4(io.qplanes, qo + b);
+                    qlw = qv.x; qhw = qv.y;
+                    rl0 = rl1; rh0 = rh1;
+                    const uint4 v = planes4(io.wplanes, P0 + b + 32);
+                    rl1 = v.x; rh1 = v.y;
+                }
+                const uint32_t QL = 0u - ((qlw >> sh) & 1u), QH = 0u - ((qhw >> sh) & 1u);
+                const uint32_t rl = __builtin_amdgcn_alignbit(rl1, rl0, sh), rh = __builtin_amdgcn_alignbit(rh1, rh0, sh);
+                const uint32_t e = ~((rl ^ QL) | (rh ^ QH));                         // bit k: the row's base equals the base of cell k's column
+                const int kc = x - (int)i;                                           // column 0 sits at k = kc in this row (rows <= x)
+                int left = NEG;
+                uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const int old = H[k];
+                    const int cd = (old & ~7) - 4 + 24 * (int)((e >> k) & 1u);       // 8 sigma + 4
+                    int h = cd > left ? cd : left;
+                    if (k + 1 < B) {
+                        const int up = H[k + 1];
+                        const int cu = (up & ~7) + 4 * (up & 2) - 14;                // 8 (-2 + [up]) + 2
+                        h = h > cu ? h : cu;
+                    }
+                    if (decltype(first)::value && k < XMAX) { if (k == kc) h = -(int)(i + 1) * 8 + 2; }   // V(i, 0) = -(i + 1), up (sw.erl:73-77)
+                    H[k] = h;
+                    left = (h & ~7) + 8 * (h & 1) - 15;                              // 8 (-2 + [left]) + 1
+                    const uint32_t code = ((uint32_t)h >> 1) & 3u;                   // one-hot 1/2/4 -> 0/1/2
+                    if (k < 16) d0 |= code << (2 * k); else d1 |= code << (2 * (k - 16));
+                }
+                dirs[(uint64_t)(i * 2) * 64] = d0; dirs[(uint64_t)(i * 2 + 1) * 64] = d1;
+            };
+            const uint32_t nfirst = lq < (uint32_t)XMAX ? lq : (uint32_t)XMAX;
+            for (uint32_t i = 1; i <= nfirst; i++) row(i, std::true_type{});
+            for (uint32_t i = nfirst + 1; i <= lq; i++) row(i, std::false_type{});
+            // last row: columns 1..W are k <= D + x; leftmost maximum (sw.erl get_starting_point)
+            int best = NEG, kb = 0;
+            const int kmax = D + x;
+#pragma unroll
+            for (int k = 0; k < B; k++) { const int v = H[k] >> 3; if (k <= kmax && v > best) { best = v; kb = k; } }
+            if (best >= 2 * (int)lq - 3 * x - 3) {
+                uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
+                int p = (int)io.cig_stride, len = 0;
+                uint32_t i = lq;
+                int k = kb, runop = -1;
+                uint32_t runlen = 0;
+                bool ok = true;
+                for (;;) {
+                    int code = -1;
+                    if (i > 0) {
+                        if ((int)i - x + k == 0) code = DIR_UP;                      // column 0
+                        else {
+                            const uint32_t wd = dirs[(uint64_t)(i * 2 + (k >> 4)) * 64];
+                            code = (int)((wd >> (2 * (k & 15))) & 3u);
+                        }
+                    }
+                    if (code == runop) runlen++;
+                    else {
+                        if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
+                        runop = code; runlen = 1;
+                    }
+                    if (code < 0) break;
+                    if (code == DIR_UL) i--; else if (code == DIR_UP) { i--; k++; } else k--;
+                    if (k < 0 || k >= B) { ok = false; break; }                      // (cannot happen under the certificate)
+                }
+                if (ok) {
+                    io.c_score[c] = best;
+                    io.c_ciglen[c] = (uint32_t)len;
+                    io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                    settled = true;
+                }
+            }
+        }
+        // what is left goes on, in queue order within the wave
+        const bool pass = have && !settled;
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == first) base = atomicAdd(&io.ctr->band_left, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, first, 64);
+            if (pass) rest[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
         }
     }
 }

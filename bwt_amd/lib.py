@@ -40,7 +40,7 @@ class Constants(C.Structure):
 class BatchCounts(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_reads", "n_tasks", "lf_steps", "sa_reads", "n_clusters", "sw_cells",
                                           "n_hits", "cigar_bytes", "window_bytes", "n_float", "n_traced", "n_dp", "n_lookups", "n_small",
-                                          "n_handed_back")]
+                                          "n_handed_back", "n_banded")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -34,7 +34,7 @@ def check_against_oracle(out, reads, orc_fm, ref1):
     return nh
 
 
-MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
+MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_SW_BAND": "0"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
          {"BWT_SW_TRACE_ALL": "0", "BWT_SW_WAVE": "0"}, {"BWT_SW_WAVE": "0", "BWT_SW_PREFILTER": "0"},
          {"BWT_SEARCH_ILP": "2"}]
 
@@ -252,3 +252,33 @@ def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
     # the fast kernel really took groups (on this small genome the 8..10-base last sub-reads of the longest reads alone bring ~30
     # seeds: past 64 per read for the one-register variant); the two-register variant keeps at least as many
     assert kept[1] > 0 and kept[1] >= kept[0]
+
+
+@pytest.mark.parametrize("length", [48, 64, 100, 150, 175])
+def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_bytes, length, monkeypatch):
+    """k_sw_band runs the DP on 24 diagonals around the cluster and keeps its result only when the best score proves that
+    nothing outside the band can matter (kernels.hip.h); everything else goes on to the full-rectangle kernels.
+    Reads with one indel and up to 4 substitutions (most are settled by the band), reads with up to 14 substitutions (few are):
+    every answer must be the oracle's, and both routes must have been taken."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = (synth_reads(ref_bytes, 500, length, 900 + length, max_subs=4, indel_frac=1.0) +
+             synth_reads(ref_bytes, 300, length, 901 + length, max_subs=14, indel_frac=0.5))
+    b = lib.Batch(gpu_index)
+    try:
+        b.set_reads(*lib.pack_reads(reads))
+        c = b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        assert check_against_oracle(out, reads, orc_fm, ref1) > 200
+        assert c["n_banded"] > 100 and c["n_dp"] > c["n_banded"], c
+        # the same batch without the band: the same tables
+        monkeypatch.setenv("BWT_SW_BAND", "0")
+        c0 = b.run(lib.STAGE_EXTEND)
+        out0 = b.fetch_hits()
+        assert c0["n_banded"] == 0 and c0["n_dp"] == c["n_dp"]
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(out[k], out0[k]), k
+        assert out["cigar"] == out0["cigar"]
+    finally:
+        b.destroy()
