@@ -810,21 +810,6 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     }
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
 
-    // the DP queue first goes through the banded kernel: what its certificate covers is settled there (traceback included),
-    // the rest -- candidates far from any clean alignment, wide clusters -- moves on in a second queue that takes dq's place
-    const char *env_band = getenv("BWT_SW_BAND");                 // experiments / tests: 0 = full-rectangle kernels only (read per call)
-    b->band_ran = false;
-    if (io.dq && max_lq >= 2 && max_lq <= 4096 && !(env_band && env_band[0] == '0')) {
-        const uint32_t rows = max_lq + 1;
-        const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * 8));
-        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->slab_band.ensure((uint64_t)bblocks * 4 * rows * 128 * 4))) return rc;
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 8, b->stream));
-        KLAUNCH(b, "sw_band", k_sw_band<24>, bblocks, 256, io, b->bq.as<uint32_t>(), b->slab_band.as<uint32_t>(), rows);
-        HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->dq_count, &b->ctr.as<Counters>()->band_left, 4, hipMemcpyDeviceToDevice, b->stream));
-        io.dq = b->bq.as<uint32_t>();
-        b->band_ran = true;
-    }
-
     // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
     // lane-per-alignment work would run a handful of waves for the full serial length of a DP
     const char *env_wv = getenv("BWT_SW_WAVE");                   // experiments / tests: 0 = lane-per-alignment kernels only (read per call)
@@ -833,6 +818,23 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     const uint32_t wv_thresh = (io.dq && wv_lds <= 60 * 1024 && !(env_wv && env_wv[0] == '0')) ? 32768u : 0u;
     io.wave_upto = wv_thresh;
     b->wave_upto = wv_thresh;
+    // the DP queue first goes through the banded kernel: what its certificate covers is settled there (traceback included),
+    // the rest -- candidates far from any clean alignment, wide clusters -- moves on in a second queue that takes dq's place
+    const char *env_band = getenv("BWT_SW_BAND");                 // experiments / tests: 0 = full-rectangle kernels only (read per call)
+    b->band_ran = false;
+    const char *env_bm = getenv("BWT_SW_BAND_MIN");               // tests: queues up to this size are left to k_sw_wave (default 16384)
+    const uint32_t band_min = std::min<uint32_t>(wv_thresh, env_bm ? (uint32_t)atoi(env_bm) : 16384u);
+    if (io.dq && max_lq >= 2 && max_lq <= 4096 && !(env_band && env_band[0] == '0')) {
+        const uint32_t rows = max_lq + 1;
+        const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4));   // resident: 4 waves per SIMD
+        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->slab_band.ensure((uint64_t)bblocks * 4 * rows * 3 * 64 * 4))) return rc;
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 16, b->stream));
+        KLAUNCH(b, "sw_band", k_sw_band<24>, bblocks, 256, io, b->bq.as<uint32_t>(), b->slab_band.as<uint32_t>(), rows, band_min);
+        HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->dq_count, &b->ctr.as<Counters>()->band_left, 4, hipMemcpyDeviceToDevice, b->stream));
+        io.dq = b->bq.as<uint32_t>();
+        b->band_ran = true;
+    }
+
     if (wv_thresh) {
         ProfScope ps(b, "sw_wave");
         hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),

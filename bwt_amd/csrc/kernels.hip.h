@@ -1175,15 +1175,29 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             // seeds that did not come with the entry -- everything of a task that ended below the top level, the seeds past the
             // first 14 of a top-level task -- are read from the SA, the whole wave on one task's range at a time (rare)
             const uint32_t inl = wide ? KT_INLINE : 0u;
+            // (up to four ranges per round: their loads are all issued before the first one is waited for)
             unsigned long long more = __ballot(fuse_read && c > inl);
             while (more) {
-                const int src = __ffsll((long long)more) - 1;
-                more &= more - 1ull;
-                const uint32_t sp_s = (uint32_t)__builtin_amdgcn_readlane((int)own.x, src), c_s = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
-                const uint32_t add_s = (uint32_t)__builtin_amdgcn_readlane((int)nadd, src), from_s = (uint32_t)__builtin_amdgcn_readlane((int)inl, src);
-                const uint32_t dst_s = (uint32_t)__builtin_amdgcn_readlane((int)(lread * ROW + dst), src);
-                if (lane >= from_s && lane < c_s) rows[dst_s + lane] = ix.sa[sp_s - 1 + lane] + add_s;
-                if (BIG && lane + 64 < c_s) rows[dst_s + 64 + lane] = ix.sa[sp_s - 1 + 64 + lane] + add_s;
+                uint32_t gv[4], gv2[4], gdst[4], gadd[4], gc[4], gfrom[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    gc[t] = 0; gfrom[t] = 0; gdst[t] = 0; gadd[t] = 0; gv[t] = 0; gv2[t] = 0;
+                    if (more) {
+                        const int src = __ffsll((long long)more) - 1;
+                        more &= more - 1ull;
+                        const uint32_t sp_s = (uint32_t)__builtin_amdgcn_readlane((int)own.x, src);
+                        gc[t] = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
+                        gadd[t] = (uint32_t)__builtin_amdgcn_readlane((int)nadd, src); gfrom[t] = (uint32_t)__builtin_amdgcn_readlane((int)inl, src);
+                        gdst[t] = (uint32_t)__builtin_amdgcn_readlane((int)(lread * ROW + dst), src);
+                        if (lane >= gfrom[t] && lane < gc[t]) gv[t] = ix.sa[sp_s - 1 + lane];
+                        if (BIG && lane + 64 < gc[t]) gv2[t] = ix.sa[sp_s - 1 + 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (lane >= gfrom[t] && lane < gc[t]) rows[gdst[t] + lane] = gv[t] + gadd[t];
+                    if (BIG && lane + 64 < gc[t]) rows[gdst[t] + 64 + lane] = gv2[t] + gadd[t];
+                }
             }
             const uint32_t cw = fuse_read ? (c < inl ? c : inl) : 0u;
             if (cw > 0) row[0] = own.z + nadd;
@@ -2736,119 +2750,210 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 // those of the full table, and every row's maximum stays above the early-exit threshold of sw.erl:69 (3x + 3 <= 2 (Lq div 2)
 // is checked).  Candidates that are not eligible or whose S* is lower go on to the full-rectangle kernels untouched.
 #define SWB_XMIN 3
+#define SWB_MAX_LQ 1500            // 8 V + code of both candidates of a lane in 16 bits each
+// Two candidates per lane (low / high 16 bits of every register, the cell algebra of k_sw_pk): they share the row loop and
+// the cell index k, each has its own band offset x, window and last row.
 template <int B>
-__global__ __launch_bounds__(256) void k_sw_band(SwIO io, uint32_t *__restrict__ rest, uint32_t *__restrict__ slab, uint32_t slab_rows) {
-    static_assert(B > 16 && B <= 32, "two direction words per row");
-    constexpr int XMAX = (B - 1) / 2;
-    constexpr int NEG = -(1 << 28);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sw_band(SwIO io, uint32_t *__restrict__ rest, uint32_t *__restrict__ slab, uint32_t slab_rows,
+                                                                                                uint32_t skip_upto) {
+    static_assert(B > 16 && B <= 32, "cells 16.. come from the second match word");
+    constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    constexpr int RB = 8;                                                           // rows of directions a traceback stages in LDS at a time
+    __shared__ uint32_t tb_lds[4][RB * NDW * 64];
+    uint32_t *const tb = tb_lds[threadIdx.x >> 6] + lane;                           // [(r * NDW + k / 8) * 64]: every lane its own column
     const uint32_t n_items = io.ctr->dq_count;
+    if (n_items <= skip_upto) {
+        // a short queue is k_sw_wave's (a lane per alignment would run a handful of waves for the serial length of a DP): passed through
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = io.dq[t];
+        if (wave == 0 && lane == 0) { io.ctr->band_in = n_items; io.ctr->band_left = n_items; }
+        return;
+    }
     if (wave == 0 && lane == 0) io.ctr->band_in = n_items;
-    uint32_t *const dirs = slab + (uint64_t)wave * slab_rows * 128 + lane;           // [(i * 2 + half) * 64]
-    for (uint32_t g = wave; (uint64_t)g * 64 < n_items; g += nwaves) {
-        const uint32_t item = g * 64 + lane;
-        const bool have = item < n_items;
-        uint32_t c = 0, lq = 0, w = 0;
-        int64_t wo = 0;
-        uint64_t qo = 0;
-        if (have) { c = io.dq[item]; lq = io.c_qlen[c]; w = io.c_wlen[c]; wo = io.c_woff[c]; qo = io.c_qoff[c]; }
-        const int D = (int)w - (int)lq;
-        const int x = (B - 1 - D) >> 1;
-        const bool run = have && D >= 0 && D <= B - 1 - 2 * SWB_XMIN && lq >= 2 && lq < slab_rows &&
-                         3 * x + 3 <= 2 * (int)(lq / 2) && wo >= 32 && (uint64_t)wo + w <= io.rbuf_len;
-        bool settled = false;
-        if (run) {
-            int H[B];
+    uint32_t *const dirs = slab + (uint64_t)wave * slab_rows * NDW * 64 + lane;     // [(i * NDW + k / 8) * 64]: 8 cells x 2 candidates per word
+    const uint32_t F8 = 0xFFF8FFF8u, K8 = 0x00080008u, K4 = 0x00040004u, K24 = 0x00180018u, KM4 = 0xFFFCFFFCu, KM15 = 0xFFF1FFF1u,
+                   KM14 = 0xFFF2FFF2u;
+    // groups of 128 candidates are handed out by a counter: a group's time varies with its tracebacks, and the queue is a few
+    // groups per resident wave (every wave leaves when the counter has passed the end of the queue)
+    for (;;) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(&io.ctr->band_next, 1u);
+        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        if ((uint64_t)g * 128 >= n_items) break;
+        uint32_t c[2], lq[2], w[2];
+        int64_t wo[2];
+        uint64_t qo[2];
+        int x[2], D[2];
+        bool have[2], run[2], settled[2] = {false, false};
 #pragma unroll
-            for (int k = 0; k < B; k++) H[k] = 1;                                    // row 0: V = 0, stored as `left` (Uvalue -2 like undef)
-            uint32_t qlw = 0, qhw = 0, rl0 = 0, rh0 = 0, rl1, rh1;
-            const uint64_t P0 = (uint64_t)wo - (uint32_t)x;                          // Ref1 base of cell (1, k = 0)'s column
-            { const uint4 v = planes4(io.wplanes, P0); rl1 = v.x; rh1 = v.y; }
+        for (int h = 0; h < 2; h++) {
+            const uint32_t item = g * 128 + h * 64 + lane;
+            have[h] = item < n_items;
+            c[h] = 0; lq[h] = 0; w[h] = 0; wo[h] = 0; qo[h] = 0;
+            if (have[h]) { c[h] = io.dq[item]; lq[h] = io.c_qlen[c[h]]; w[h] = io.c_wlen[c[h]]; wo[h] = io.c_woff[c[h]]; qo[h] = io.c_qoff[c[h]]; }
+            D[h] = (int)w[h] - (int)lq[h];
+            x[h] = (B - 1 - D[h]) >> 1;
+            run[h] = have[h] && D[h] >= 0 && D[h] <= B - 1 - 2 * SWB_XMIN && lq[h] >= 2 && lq[h] < slab_rows && lq[h] <= SWB_MAX_LQ &&
+                     3 * x[h] + 3 <= 2 * (int)(lq[h] / 2) && wo[h] >= 32 && (uint64_t)wo[h] + w[h] <= io.rbuf_len;
+            if (!run[h]) { lq[h] = 0; wo[h] = 64; qo[h] = 0; x[h] = XMAX; D[h] = 0; }     // (its half computes on, harmlessly, on words that exist)
+        }
+        int best[2] = {-(1 << 28), -(1 << 28)}, kb[2] = {0, 0};
+        if (run[0] || run[1]) {
+            uint32_t H[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) H[k] = 0x00010001u;                            // row 0: V = 0, stored as `left` (Uvalue -2 like undef)
+            uint32_t qlw[2] = {0, 0}, qhw[2] = {0, 0}, rl0[2] = {0, 0}, rh0[2] = {0, 0}, rl1[2], rh1[2];
+            uint64_t P0[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                P0[h] = (uint64_t)wo[h] - (uint32_t)x[h];                                // Ref1 base of cell (1, k = 0)'s column
+                const uint4 v = planes4(io.wplanes, P0[h]);
+                rl1[h] = v.x; rh1[h] = v.y;
+            }
             auto row = [&](uint32_t i, auto first) {
                 const uint32_t b = i - 1, sh = b & 31u;
-                if (sh == 0) {
-                    const uint4 qv = planes4(io.qplanes, qo + b);
-                    qlw = qv.x; qhw = qv.y;
-                    rl0 = rl1; rh0 = rh1;
-                    const uint4 v = planes4(io.wplanes, P0 + b + 32);
-                    rl1 = v.x; rh1 = v.y;
+                uint32_t e[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (sh == 0) {
+                        const uint4 qv = planes4(io.qplanes, qo[h] + b);
+                        qlw[h] = qv.x; qhw[h] = qv.y;
+                        rl0[h] = rl1[h]; rh0[h] = rh1[h];
+                        const uint4 v = planes4(io.wplanes, P0[h] + b + 32);
+                        rl1[h] = v.x; rh1[h] = v.y;
+                    }
+                    const uint32_t QL = 0u - ((qlw[h] >> sh) & 1u), QH = 0u - ((qhw[h] >> sh) & 1u);
+                    const uint32_t rl = __builtin_amdgcn_alignbit(rl1[h], rl0[h], sh), rh = __builtin_amdgcn_alignbit(rh1[h], rh0[h], sh);
+                    e[h] = ~((rl ^ QL) | (rh ^ QH));                                     // bit k: the row's base equals the base of cell k's column
                 }
-                const uint32_t QL = 0u - ((qlw >> sh) & 1u), QH = 0u - ((qhw >> sh) & 1u);
-                const uint32_t rl = __builtin_amdgcn_alignbit(rl1, rl0, sh), rh = __builtin_amdgcn_alignbit(rh1, rh0, sh);
-                const uint32_t e = ~((rl ^ QL) | (rh ^ QH));                         // bit k: the row's base equals the base of cell k's column
-                const int kc = x - (int)i;                                           // column 0 sits at k = kc in this row (rows <= x)
-                int left = NEG;
-                uint32_t d0 = 0, d1 = 0;
+                const uint32_t E0 = (e[0] & 0xffffu) | (e[1] << 16), E1 = (e[0] >> 16) | (e[1] & 0xffff0000u);
+                const int kc0 = x[0] - (int)i, kc1 = x[1] - (int)i;                      // column 0 sits at k = kc in this row (rows <= x)
+                const uint32_t col0 = (uint32_t)(-(int)(i + 1) * 8 + 2) & 0xffffu;       // V(i, 0) = -(i + 1), up (sw.erl:73-77)
+                uint32_t left = 0x80008000u;
+                uint32_t dacc = 0;
 #pragma unroll
                 for (int k = 0; k < B; k++) {
-                    const int old = H[k];
-                    const int cd = (old & ~7) - 4 + 24 * (int)((e >> k) & 1u);       // 8 sigma + 4
-                    int h = cd > left ? cd : left;
+                    const uint32_t old = H[k];
+                    const uint32_t xk = ((k < 16 ? E0 >> k : E1 >> (k - 16))) & 0x00010001u;
+                    const uint32_t cd = pk_add(old & F8, pk_mad(xk, K24, KM4));          // 8 sigma + 4
+                    uint32_t hh = pk_max(cd, left);
                     if (k + 1 < B) {
-                        const int up = H[k + 1];
-                        const int cu = (up & ~7) + 4 * (up & 2) - 14;                // 8 (-2 + [up]) + 2
-                        h = h > cu ? h : cu;
+                        const uint32_t up = H[k + 1];
+                        hh = pk_max(hh, pk_add(pk_mad(up & 0x00020002u, K4, up & F8), KM14));   // 8 (-2 + [up]) + 2
                     }
-                    if (decltype(first)::value && k < XMAX) { if (k == kc) h = -(int)(i + 1) * 8 + 2; }   // V(i, 0) = -(i + 1), up (sw.erl:73-77)
-                    H[k] = h;
-                    left = (h & ~7) + 8 * (h & 1) - 15;                              // 8 (-2 + [left]) + 1
-                    const uint32_t code = ((uint32_t)h >> 1) & 3u;                   // one-hot 1/2/4 -> 0/1/2
-                    if (k < 16) d0 |= code << (2 * k); else d1 |= code << (2 * (k - 16));
+                    if (decltype(first)::value && k < XMAX) {
+                        if (k == kc0) hh = (hh & 0xffff0000u) | col0;
+                        if (k == kc1) hh = (hh & 0x0000ffffu) | (col0 << 16);
+                    }
+                    H[k] = hh;
+                    left = pk_add(pk_mad(hh & 0x00010001u, K8, hh & F8), KM15);          // 8 (-2 + [left]) + 1
+                    const uint32_t code2 = hh & 0x00060006u;                             // one-hot 1/2/4 -> 0/1/2, still shifted left by one
+                    dacc = (k & 7) == 0 ? code2 >> 1 : dacc | (code2 << (2 * (k & 7) - 1));
+                    if ((k & 7) == 7 || k == B - 1) dirs[(uint64_t)(i * NDW + (k >> 3)) * 64] = dacc;
                 }
-                dirs[(uint64_t)(i * 2) * 64] = d0; dirs[(uint64_t)(i * 2 + 1) * 64] = d1;
             };
-            const uint32_t nfirst = lq < (uint32_t)XMAX ? lq : (uint32_t)XMAX;
-            for (uint32_t i = 1; i <= nfirst; i++) row(i, std::true_type{});
-            for (uint32_t i = nfirst + 1; i <= lq; i++) row(i, std::false_type{});
-            // last row: columns 1..W are k <= D + x; leftmost maximum (sw.erl get_starting_point)
-            int best = NEG, kb = 0;
-            const int kmax = D + x;
+            // a candidate's last row: columns 1..W are k <= D + x; leftmost maximum (sw.erl get_starting_point)
+            auto last_row = [&](int h) {
+                const int kmax = D[h] + x[h];
 #pragma unroll
-            for (int k = 0; k < B; k++) { const int v = H[k] >> 3; if (k <= kmax && v > best) { best = v; kb = k; } }
-            if (best >= 2 * (int)lq - 3 * x - 3) {
-                uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
-                int p = (int)io.cig_stride, len = 0;
-                uint32_t i = lq;
-                int k = kb, runop = -1;
-                uint32_t runlen = 0;
-                bool ok = true;
-                for (;;) {
-                    int code = -1;
-                    if (i > 0) {
-                        if ((int)i - x + k == 0) code = DIR_UP;                      // column 0
-                        else {
-                            const uint32_t wd = dirs[(uint64_t)(i * 2 + (k >> 4)) * 64];
-                            code = (int)((wd >> (2 * (k & 15))) & 3u);
-                        }
-                    }
-                    if (code == runop) runlen++;
-                    else {
-                        if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
-                        runop = code; runlen = 1;
-                    }
-                    if (code < 0) break;
-                    if (code == DIR_UL) i--; else if (code == DIR_UP) { i--; k++; } else k--;
-                    if (k < 0 || k >= B) { ok = false; break; }                      // (cannot happen under the certificate)
+                for (int k = 0; k < B; k++) {
+                    const int v = (h ? (int)H[k] >> 19 : (int)(int16_t)(H[k] & 0xffffu) >> 3);
+                    if (k <= kmax && v > best[h]) { best[h] = v; kb[h] = k; }
                 }
-                if (ok) {
-                    io.c_score[c] = best;
-                    io.c_ciglen[c] = (uint32_t)len;
-                    io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
-                    settled = true;
+            };
+            // rows up to the shorter candidate's last one, then on to the longer one's 
+            const uint32_t lqm = lq[0] > lq[1] ? lq[0] : lq[1];
+            const uint32_t lqs = run[0] && run[1] ? (lq[0] < lq[1] ? lq[0] : lq[1]) : lqm;
+            const uint32_t nfirst = lqs < (uint32_t)XMAX ? lqs : (uint32_t)XMAX;
+            for (uint32_t i = 1; i <= nfirst; i++) row(i, std::true_type{});
+            for (uint32_t i = nfirst + 1; i <= lqs; i++) row(i, std::false_type{});
+            if (run[0] && lq[0] == lqs) last_row(0);
+            if (run[1] && lq[1] == lqs) last_row(1);
+            if (lqm > lqs) {
+                for (uint32_t i = lqs + 1; i <= lqm; i++) row(i, std::false_type{});
+                if (lq[0] == lqm) last_row(0); else last_row(1);
+            }
+            // tracebacks (sw.erl:116-160) of the candidates the certificate covers, both of the lane side by side: the directions
+            // come back from the slab RB rows at a time (one round trip per RB rows instead of one per step), parked in LDS
+            bool tr[2];
+            uint32_t ti[2];
+            int tk[2], trun[2] = {-1, -1}, tp[2], tlen[2] = {0, 0};
+            uint32_t trl[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                tr[h] = run[h] && best[h] >= 2 * (int)lq[h] - 3 * x[h] - 3;
+                ti[h] = tr[h] ? lq[h] : 0; tk[h] = kb[h]; tp[h] = (int)io.cig_stride;
+            }
+            const uint32_t top = ti[0] > ti[1] ? ti[0] : ti[1];
+            for (int blk = top ? (int)((top - 1) / RB) : -1; blk >= 0; blk--) {
+                const uint32_t r0 = (uint32_t)blk * RB + 1;                              // rows r0 .. r0 + RB - 1
+#pragma unroll
+                for (int r = 0; r < RB; r++)
+#pragma unroll
+                    for (int gq = 0; gq < NDW; gq++)
+                        tb[(r * NDW + gq) * 64] = r0 + r <= top ? dirs[(uint64_t)((r0 + r) * NDW + gq) * 64] : 0u;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint8_t *const slot = io.cig + (uint64_t)c[h] * io.cig_stride;
+                    while (tr[h] && ti[h] >= r0) {
+                        // a diagonal run keeps k: the codes of this k in all staged rows at once, then as many up_left steps as
+                        // there are in a row from row i downwards (stopping short of column 0, whose direction is not stored)
+                        {
+                            const uint32_t gsel = ((uint32_t)tk[h] >> 3) * 64, shb = 16 * h + 2 * (tk[h] & 7);
+                            uint32_t ul = 0;
+#pragma unroll
+                            for (int r = 0; r < RB; r++) ul |= (((tb[r * NDW * 64 + gsel] >> shb) & 3u) == (uint32_t)DIR_UL ? 1u : 0u) << r;
+                            const int rowmin = x[h] - tk[h] + 1;                          // rows below this one are column 0 or left of it
+                            if (rowmin > (int)r0) ul &= ~0u << (rowmin - (int)r0);
+                            const uint32_t top1 = ~(ul << (31u - (ti[h] - r0)));          // bit 31 = row i, zeros where up_left
+                            const uint32_t nrun = top1 ? (uint32_t)__clz((int)top1) : 32u;
+                            if (nrun) {
+                                if (trun[h] == DIR_UL) trl[h] += nrun;
+                                else {
+                                    if (trun[h] >= 0) cig_emit(slot, tp[h], tlen[h], trl[h], trun[h] == DIR_UP ? 'I' : 'D');
+                                    trun[h] = DIR_UL; trl[h] = nrun;
+                                }
+                                ti[h] -= nrun;
+                                continue;
+                            }
+                        }
+                        int code = DIR_UP;                                               // column 0
+                        if ((int)ti[h] - x[h] + tk[h] != 0)
+                            code = (int)((tb[((ti[h] - r0) * NDW + ((uint32_t)tk[h] >> 3)) * 64] >> (16 * h + 2 * (tk[h] & 7))) & 3u);
+                        if (code == trun[h]) trl[h]++;
+                        else {
+                            if (trun[h] >= 0) cig_emit(slot, tp[h], tlen[h], trl[h], trun[h] == DIR_UL ? 'M' : trun[h] == DIR_UP ? 'I' : 'D');
+                            trun[h] = code; trl[h] = 1;
+                        }
+                        if (code == DIR_UL) ti[h]--; else if (code == DIR_UP) { ti[h]--; tk[h]++; } else tk[h]--;
+                        if (tk[h] < 0 || tk[h] >= B) tr[h] = false;                      // (cannot happen under the certificate)
+                    }
                 }
             }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (tr[h]) {
+                    uint8_t *const slot = io.cig + (uint64_t)c[h] * io.cig_stride;
+                    cig_emit(slot, tp[h], tlen[h], trl[h], trun[h] == DIR_UL ? 'M' : trun[h] == DIR_UP ? 'I' : 'D');
+                    io.c_score[c[h]] = best[h];
+                    io.c_ciglen[c[h]] = (uint32_t)tlen[h];
+                    io.c_status[c[h]] = tlen[h] > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                    settled[h] = true;
+                }
         }
-        // what is left goes on, in queue order within the wave
-        const bool pass = have && !settled;
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            const int first = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == first) base = atomicAdd(&io.ctr->band_left, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, first, 64);
-            if (pass) rest[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
+        // what is left goes on
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool pass = have[h] && !settled[h];
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                const int first = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(&io.ctr->band_left, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, first, 64);
+                if (pass) rest[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c[h];
+            }
         }
     }
 }

@@ -140,6 +140,6 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned int n_gq, pad_;   // groups k_seed_fast handed back to k_seed_tasks
     unsigned int max_D, pad2_; // largest cluster width D the seed kernels staged (window = Lq + D: sizes the extend stage without a round trip)
     unsigned int why[6];       // ... by reason: [0] base outside ACGT, [1] table overflow, [4] > 64 seeds in a read, [5] > CL_STAGE clusters
-    unsigned int band_in, band_left;   // k_sw_band: DP candidates it was given, and those it passed on to the full-rectangle kernels
+    unsigned int band_in, band_left, band_next, pad3_;   // k_sw_band: DP candidates it was given, those it passed on to the full-rectangle kernels, its work counter
 };
 

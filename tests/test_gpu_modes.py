@@ -34,7 +34,7 @@ def check_against_oracle(out, reads, orc_fm, ref1):
     return nh
 
 
-MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_SW_BAND": "0"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
+MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_SW_BAND": "0"}, {"BWT_SW_BAND_MIN": "0"}, {"BWT_SW_BAND_MIN": "0", "BWT_SW_WAVE": "0"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
          {"BWT_SW_TRACE_ALL": "0", "BWT_SW_WAVE": "0"}, {"BWT_SW_WAVE": "0", "BWT_SW_PREFILTER": "0"},
          {"BWT_SEARCH_ILP": "2"}]
 
@@ -262,6 +262,7 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
     every answer must be the oracle's, and both routes must have been taken."""
     from bwt_amd import lib
     from oracle import erl_literal as E
+    monkeypatch.setenv("BWT_SW_BAND_MIN", "0")                  # (queues this short are k_sw_wave's otherwise)
     ref1 = E.make_ref1(ref_bytes)
     reads = (synth_reads(ref_bytes, 500, length, 900 + length, max_subs=4, indel_frac=1.0) +
              synth_reads(ref_bytes, 300, length, 901 + length, max_subs=14, indel_frac=0.5))
