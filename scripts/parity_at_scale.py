@@ -84,7 +84,7 @@ def main():
            "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order)",
            "reads": n, "reads_with_hits": int((np.diff(hits["hit_off"].astype(np.int64)) > 0).sum()), "hits": int(c["n_hits"]),
            "reads_status_minus1": int((hits["read_status"] == -1).sum()), "dp_candidates": int(c["n_dp"]), "fp64_candidates": int(c["n_float"]),
-           "handed_back_groups": int(c["n_handed_back"]), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
+           "handed_back_groups": int(c["n_handed_back"]), "banded": int(c.get("n_banded", 0)), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
            "gpu_s": t_gpu, "cpu_s": t_cpu, "cpu_threads": cores}
     print(json.dumps(out))
     batch.destroy(); ix.close()
