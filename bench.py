@@ -365,6 +365,8 @@ def main():
         fast = "fm_lookup_rest" in per                     # k_seed_fast took the ordinary groups, k_seed_tasks the handed-back ones
         rw_ = 64 // max(1, length // 8)
         back = min(1.0, counts.get("n_handed_back", 0) * rw_ / max(counts["n_reads"], 1)) if fast else 1.0
+        # (of the groups k_seed_fast hands back, its two-register pass over that list keeps most; the general kernel takes the rest)
+        back2 = min(back, counts.get("n_general_groups", counts.get("n_handed_back", 0)) * rw_ / max(counts["n_reads"], 1)) if fast else 1.0
         narrow = counts["n_reads"] * sum(1 for k in range(length // 8) if 8 <= length - 8 * k < kdepth) if kdepth else 0
         wide_l = max(0, counts["n_lookups"] - narrow) if kwide else 0
         narrow_l = counts["n_lookups"] - wide_l
@@ -375,7 +377,8 @@ def main():
         general_extra = 4 * counts["n_tasks"] + int(16 * counts["n_tasks"] * unfused)
         models = {
             "fm_lookup": (("k_seed_fast", int(seed_common * (1.0 - back))) if fast else ("k_seed_tasks", seed_common + general_extra)),
-            "fm_lookup_rest": ("k_seed_tasks", int((seed_common + general_extra) * back)),
+            "fm_lookup_big": ("k_seed_fast_list", int(seed_common * (back - back2))),
+            "fm_lookup_rest": ("k_seed_tasks", int((seed_common + general_extra) * back2)),
             "fm_search": ("k_search_pending" if "fm_lookup" in per else "k_search",
                           128 * counts["lf_steps"] + (0 if "fm_lookup" in per else io_terms)),
             "cluster_small": ("k_cluster_small", 4 * counts["sa_reads"] + 16 * counts["n_tasks"] + 8 * counts["n_clusters"]),
@@ -401,6 +404,14 @@ def main():
                                   "unit": "Tlane-op/s", "frac": ops / VALU_PEAK_TOPS, "traffic": traffic.get("k_sw"),
                                   "cells_per_launch": dp_cells, "valu_lane_ops_per_cell": ops_per_cell, "avg_launch_ms": per["sw_extend"],
                                   "share_of_step": kt["sw_extend"]["ms"] / total_ms}
+        if "sw_band" in per and counts.get("n_banded", 0) > 0:
+            # banded DP: 24 cells per row, 17.6 instructions per cell PAIR (two candidates per lane) = 8.8 lane-ops per cell
+            bcells = counts["n_banded"] * length * 24.0
+            ops = bcells * 8.8 / (per["sw_band"] / 1e3) / 1e12
+            roofs["sw_band"] = {"kernel": "k_sw_band", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS, "unit": "Tlane-op/s",
+                                "frac": ops / VALU_PEAK_TOPS, "traffic": traffic.get("k_sw_band"), "cells_per_launch": bcells,
+                                "valu_lane_ops_per_cell": 8.8, "avg_launch_ms": per["sw_band"], "share_of_step": kt["sw_band"]["ms"] / total_ms,
+                                "settled": counts["n_banded"], "of_dp_candidates": counts["n_dp"]}
         roof = roofs.get(dom) or roofs[max(roofs, key=lambda k: kt[k]["ms"])]
         line = {
             "metric": "aligned reads/sec (100 bp, GRCh38 FM-index) at 1/2/4/8 MI355X",
@@ -418,11 +429,15 @@ def main():
             "counts_per_step": counts,
         }
         if "sw_extend" in per or "sw_wave" in per:
-            t_dp = (per.get("sw_wave", 0.0) if counts["n_dp"] <= 32768 else per.get("sw_extend", 0.0)) / 1e3
+            banded = counts.get("n_banded", 0) > 0
+            left = counts["n_dp"] - counts.get("n_banded", 0)
+            t_dp = ((per.get("sw_band", 0.0) if banded else 0.0) + (per.get("sw_wave", 0.0) if left <= 32768 else per.get("sw_extend", 0.0))) / 1e3
             line["extend"] = {"candidates": counts["n_clusters"],
                               "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"],
                               "dp_candidates": counts["n_dp"],
-                              "dp_kernel": "k_sw_wave (wave per alignment: short queue)" if counts["n_dp"] <= 32768 else "k_sw_pk",
+                              "settled_by_banded_dp": counts.get("n_banded", 0),
+                              "dp_kernel": ("k_sw_band (24 diagonals + certificate), then " if banded else "") +
+                                           ("k_sw_wave (wave per alignment: short queue)" if left <= 32768 else "k_sw_pk"),
                               "dp_cells_per_s": dp_cells / t_dp if t_dp else None}
         # PCIe-inclusive rate (never `value`): host buffers in, host hit tables out, one untimed-extra pass
         t0 = time.perf_counter()
