@@ -326,7 +326,7 @@ struct bwt_batch {
     bool band_ran = false;
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
-    DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig;
+    DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig, pairs;
     // counters
     DevBuf ctr;
     Counters hctr{};
@@ -436,7 +436,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
-                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq};
+                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -521,6 +521,112 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
     b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
     b->ulen = (n && minlq == maxlq) ? maxlq : 0;       // every read the same length: offsets are r * ulen (no offset load in the seed kernel)
     b->total_bases = total;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reverse strand and pairing: what the reference does not have (src/fastq.erl:43-50 is an unused helper).
+// Nothing here changes the path above: a batch set with bwt_batch_set_reads_both_strands simply holds 2n reads -- read
+// n + i is the reverse complement of read i, made on the device -- and every read goes through the same kernels.
+__global__ __launch_bounds__(256) static void k_strand_copy(uint8_t *__restrict__ bases, uint64_t *__restrict__ off, uint32_t n, uint64_t total) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n; r += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+        const uint64_t a = off[r], len = off[r + 1] - a;
+        for (uint64_t i = lane; i < len; i += 64) {
+            const uint8_t c = bases[a + len - 1 - i];
+            uint8_t d = c;                                        // IUPAC complements; anything else stays (the read fails as it would forward)
+            switch (c) {
+            case 'A': d = 'T'; break; case 'T': d = 'A'; break; case 'C': d = 'G'; break; case 'G': d = 'C'; break;
+            case 'R': d = 'Y'; break; case 'Y': d = 'R'; break; case 'K': d = 'M'; break; case 'M': d = 'K'; break;
+            case 'B': d = 'V'; break; case 'V': d = 'B'; break; case 'D': d = 'H'; break; case 'H': d = 'D'; break;
+            default: break;                                       // N, S, W are their own complements
+            }
+            bases[total + a + i] = d;
+        }
+        if (lane == 0) off[n + r + 1] = total + off[r + 1];
+    }
+}
+
+extern "C" int bwt_batch_set_reads_both_strands(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n) {
+    if (!b || !off) return fail(BWT_EINVAL, "bwt_batch_set_reads_both_strands: null argument");
+    if (n > 0x7fffffffu) return fail(BWT_EINVAL, "bwt_batch_set_reads_both_strands: too many reads");
+    HIPCHK(hipSetDevice(b->device));
+    const uint64_t total = n ? off[n] - off[0] : 0;
+    int rc;
+    // room for both strands first (bwt_batch_set_reads keeps what is large enough), then the forward reads as usual
+    if ((rc = b->bases.ensure(2 * total + 16)) || (rc = b->off.ensure(((size_t)2 * n + 1) * 8))) return rc;
+    if ((rc = bwt_batch_set_reads(b, bases, off, n))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_strand_copy, dim3((uint32_t)std::min<uint64_t>(cdiv((uint64_t)n * 64, 256), 4096)), dim3(256), 0, b->stream,
+                           b->bases.as<uint8_t>(), b->off.as<uint64_t>(), n, total);
+        HIPCHK(hipGetLastError());
+    }
+    b->n = 2 * n;
+    b->total_bases = 2 * total;
+    return 0;
+}
+
+// Proper pairs.  Mates are interleaved (reads 2p and 2p + 1 of the n = 2 n_pairs forward reads; their reverse complements are
+// reads n + 2p and n + 2p + 1).  A combination is proper when one mate's forward read and the other mate's reverse
+// complement both have hits, the forward one starts first, and the fragment they span -- from the forward hit's position to
+// the end of the reverse hit (its position + the reference bases its CIGAR consumes) -- is min_insert..max_insert long.
+// Among the proper combinations the one with the highest score sum wins; the first in enumeration order (mate 1 forward
+// before mate 2 forward, then the forward mate's hits in table order, then the other's) among equals.
+struct PairRec { uint32_t hit1, hit2; int32_t insert, score; uint32_t n_proper, flags; };
+__device__ static int64_t cigar_ref_span(const uint8_t *cig, uint64_t a, uint64_t e) {
+    int64_t span = 0, num = 0;
+    for (uint64_t i = a; i < e; i++) {
+        const uint8_t c = cig[i];
+        if (c >= '0' && c <= '9') num = num * 10 + (c - '0');
+        else { if (c == 'M' || c == 'D') span += num; num = 0; }
+    }
+    return span;
+}
+__global__ __launch_bounds__(256) static void k_pair_hits(uint32_t n_pairs, uint32_t n_fwd, const uint64_t *__restrict__ hit_off,
+                                                           const HitRec *__restrict__ rec, const uint64_t *__restrict__ cigoff,
+                                                           const uint8_t *__restrict__ cig, int32_t min_ins, int32_t max_ins,
+                                                           PairRec *__restrict__ out) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
+        PairRec best{0xffffffffu, 0xffffffffu, 0, 0, 0, 0};
+        for (uint32_t o = 0; o < 2; o++) {                        // o = 0: mate 1 forward, mate 2 reverse; o = 1: the other way round
+            const uint32_t rf = 2 * p + o, rr = n_fwd + 2 * p + (1 - o);
+            for (uint64_t hf = hit_off[rf]; hf < hit_off[rf + 1]; hf++) {
+                const HitRec f = rec[hf];
+                for (uint64_t hr = hit_off[rr]; hr < hit_off[rr + 1]; hr++) {
+                    const HitRec r = rec[hr];
+                    if (r.pos < f.pos) continue;
+                    const int64_t ins = r.pos + cigar_ref_span(cig, cigoff[hr], cigoff[hr + 1]) - f.pos;
+                    if (ins < min_ins || ins > max_ins) continue;
+                    best.n_proper++;
+                    const int32_t sc = f.score + r.score;
+                    if (best.hit1 == 0xffffffffu || sc > best.score) {
+                        best.hit1 = (uint32_t)(o == 0 ? hf : hr); best.hit2 = (uint32_t)(o == 0 ? hr : hf);
+                        best.insert = (int32_t)ins; best.score = sc; best.flags = o;
+                    }
+                }
+            }
+        }
+        out[p] = best;
+    }
+}
+
+extern "C" int bwt_batch_pair_hits(bwt_batch *b, uint32_t n_pairs, int32_t min_insert, int32_t max_insert, bwt_pair_rec *pairs) {
+    static_assert(sizeof(bwt_pair_rec) == sizeof(PairRec), "bwt_pair_rec is the device record");
+    if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_pair_hits: extend stage not run");
+    if ((uint64_t)n_pairs * 4 != b->n) return fail(BWT_EINVAL, "bwt_batch_pair_hits: the batch must hold both strands of 2 * n_pairs interleaved mates");
+    if (min_insert < 0 || max_insert < min_insert) return fail(BWT_EINVAL, "bwt_batch_pair_hits: bad insert range");
+    if (!pairs && n_pairs) return fail(BWT_EINVAL, "bwt_batch_pair_hits: null argument");
+    if (b->n_hits > 0xfffffffeull) return fail(BWT_EINVAL, "bwt_batch_pair_hits: more than 2^32 - 2 hits");
+    if (!n_pairs) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    int rc;
+    if ((rc = b->pairs.ensure((size_t)n_pairs * sizeof(PairRec)))) return rc;
+    hipLaunchKernelGGL(k_pair_hits, dim3(std::min<uint32_t>(cdiv(n_pairs, 256), 4096)), dim3(256), 0, b->stream, n_pairs, b->n / 2,
+                       b->hit_off.as<uint64_t>(), b->h_rec.as<HitRec>(), b->h_cigoff.as<uint64_t>(), b->h_cig.as<uint8_t>(), min_insert,
+                       max_insert, b->pairs.as<PairRec>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(pairs, b->pairs.p, (size_t)n_pairs * sizeof(PairRec), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
 

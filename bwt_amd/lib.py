@@ -21,7 +21,7 @@ EXPORTS = [
     "bwt_batch_fetch_hits_raw", "bwt_pipe_create", "bwt_pipe_destroy", "bwt_pipe_acquire", "bwt_pipe_submit", "bwt_pipe_wait",
     "bwt_pipe_release", "bwt_reverse_complement_batch", "bwt_batch_hits_to_device_global",
     "bwt_index_save_native", "bwt_index_open_native", "bwt_native_check", "bwt_fastq_set_threads",
-    "bwt_run_fastq", "bwt_otp_pick",
+    "bwt_run_fastq", "bwt_otp_pick", "bwt_batch_set_reads_both_strands", "bwt_batch_pair_hits",
 ]
 
 
@@ -51,6 +51,9 @@ class RunStats(C.Structure):
 
 
 HIT_REC = np.dtype([("read", np.uint32), ("score", np.int32), ("pos", np.int64)])
+PAIR_REC = np.dtype([("hit1", np.uint32), ("hit2", np.uint32), ("insert", np.int32), ("score", np.int32), ("n_proper", np.uint32),
+                     ("flags", np.uint32)])
+NO_HIT = 0xFFFFFFFF
 
 
 class PipeResult(C.Structure):
@@ -395,6 +398,21 @@ class Batch:
         off = np.ascontiguousarray(off, np.uint64)
         self.n = len(off) - 1
         _chk(load().bwt_batch_set_reads(self.h, _p(bases), _p(off), C.c_uint32(self.n)))
+
+    def set_reads_both_strands(self, bases, off):
+        """SURVEY 8f-4 (not in the reference): the batch then holds 2n reads, read n + i = reverse complement of read i."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        _chk(load().bwt_batch_set_reads_both_strands(self.h, _p(bases), _p(off), C.c_uint32(n)))
+        self.n = 2 * n
+
+    def pair_hits(self, min_insert, max_insert):
+        """Best proper combination per pair of interleaved mates (include/bwt_gpu.h: bwt_batch_pair_hits) -> PAIR_REC array."""
+        n_pairs = self.n // 4
+        out = np.empty(n_pairs, PAIR_REC)
+        _chk(load().bwt_batch_pair_hits(self.h, C.c_uint32(n_pairs), C.c_int32(min_insert), C.c_int32(max_insert), _p(out)))
+        return out
 
     def run(self, stages):
         c = BatchCounts()

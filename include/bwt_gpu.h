@@ -244,6 +244,22 @@ int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, 
                          int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off,
                          char *cigar, uint64_t hit_cap, uint64_t cig_cap, uint64_t needed[2]);
 
+/* ------------------------------------------------------------------ reverse strand and pairing
+ * Functionality the reference does NOT have (its only trace is the unused fastq:reverse_complement/1, src/fastq.erl:43-50);
+ * nothing changes unless these entry points are called.
+ * bwt_batch_set_reads_both_strands: as bwt_batch_set_reads, and the batch then holds 2n reads -- read n + i is the reverse
+ *   complement of read i (IUPAC codes complemented, made on the device).  Every stage and every fetch works on the 2n reads:
+ *   a hit of read n + i is an alignment of read i's reverse strand (position and CIGAR are those of the reverse complement
+ *   on the forward reference, as in SAM).
+ * bwt_batch_pair_hits: after the extend stage of such a batch of 2 * n_pairs INTERLEAVED mates (reads 2p, 2p + 1): per pair
+ *   the best proper combination -- one mate forward, the other reverse, the forward one first, fragment length (forward
+ *   position to the end of the reverse hit on the reference) within min_insert..max_insert; highest score sum, the first in
+ *   enumeration order (mate 1 forward first, then hits in table order) among equals.  hit1 / hit2 index the hit tables
+ *   (0xffffffff: no proper combination); flags bit 0: mate 2 is the forward one. */
+typedef struct { uint32_t hit1, hit2; int32_t insert, score; uint32_t n_proper, flags; } bwt_pair_rec;
+int bwt_batch_set_reads_both_strands(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n);
+int bwt_batch_pair_hits(bwt_batch *b, uint32_t n_pairs, int32_t min_insert, int32_t max_insert, bwt_pair_rec *pairs /* n_pairs */);
+
 /* the hit tables as they sit in HBM, copied without any host-side reshaping: hits[h] = {read, score, pos} (the 16-byte
  * record that is also gathered over RCCL).  Any output pointer may be NULL (skipped); with pinned destination buffers
  * the copies run at full DMA speed.  BWT_ENOSPC + needed = {hits, cigar bytes} when a capacity is too small. */
