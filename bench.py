@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-batch", action="store_true", help="one resident batch instead of two alternating ones")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the host-buffer pipeline measurement")
+    ap.add_argument("--overlap", action="store_true", help="also measure the two resident batches in flight at once (experiment)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -446,6 +447,26 @@ def main():
         if stages == lib.STAGE_EXTEND:
             batch.fetch_hits()
         line["pcie_inclusive_reads_per_s"] = n_reads / (time.perf_counter() - t0)
+        if len(batches) > 1 and args.overlap:
+            # experiment (never `value`): the two resident batches in flight at once, each on its own stream and host thread
+            import threading
+            for b_ in batches:
+                b_.profile(False)
+            def runner(b_, k):
+                for _ in range(k):
+                    b_.run(stages)
+            k_each = max(1, args.steps // 2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=runner, args=(b_, k_each)) for b_ in batches]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            line["two_batches_in_flight"] = {"reads_per_s": n_reads * k_each * len(batches) / dt2, "ms_per_step": dt2 / (k_each * len(batches)) * 1e3,
+                                             "what": "both resident batches run concurrently (own stream + host thread each)"}
         if stages == lib.STAGE_EXTEND and not args.no_pipeline:
             line["host_pipeline"] = host_pipeline(ix, [(bases, off)] + ([(bases2, off2)] if len(batches) > 1 else []), n_reads)
         if not args.no_cpu_baseline and world == 1:
