@@ -283,3 +283,72 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
         assert out["cigar"] == out0["cigar"]
     finally:
         b.destroy()
+
+
+@pytest.fixture(scope="module")
+def tandem_index():
+    """A 1 M-row genome with 240 tandem repeats (periods 1..31, 120..300 bp each): alignments there have many equally good
+    placements of a gap and near-perfect matches a few diagonals away -- the case a banded DP must not get wrong."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(4242)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 1_000_000, dtype=np.uint8)].tobytes())
+    regions = []
+    for k in range(240):
+        period = int(rng.choice([1, 2, 3, 4, 5, 7, 11, 17, 23, 31]))
+        ln = int(rng.integers(120, 301))
+        st = 2000 + 4000 * k
+        unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, period, dtype=np.uint8)].tobytes())
+        body = bytearray((unit * (ln // period + 2))[:ln])
+        for _ in range(int(rng.integers(0, 4))):                       # a few impurities
+            body[int(rng.integers(0, ln))] = int(rng.choice(list(b"ACGT")))
+        g[st:st + ln] = body
+        regions.append((st, ln, period))
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=0)
+    ix.set_ktable(15, 1)
+    L, SA = ix.export()
+    ptr, shift = ix.meta()
+    yield ix, ref, regions, orc.OrcFM.from_L_SA(L, SA, ptr, shift), E.make_ref1(ref)
+    ix.close()
+
+
+@pytest.mark.parametrize("length", [100, 150])
+def test_banded_dp_in_tandem_repeats(tandem_index, monkeypatch, length):
+    from bwt_amd import lib
+    ix, ref, regions, ofm, ref1 = tandem_index
+    rng = np.random.default_rng(99 + length)
+    reads = []
+    for (st, ln, period) in regions:
+        for _ in range(4):
+            a = int(rng.integers(st - length + 30, st + ln - 30))
+            q = bytearray(ref[a:a + length + 40])
+            kind = rng.random()
+            if kind < 0.7:                                               # an indel inside (or next to) the repeat
+                p = int(np.clip(int(rng.integers(st, st + ln)) - a, 5, length - 5))
+                k = period * int(rng.integers(1, 3)) if rng.random() < 0.6 else int(rng.integers(1, 6))
+                k = max(1, min(k, 12))
+                if rng.random() < 0.5:
+                    del q[p:p + k]
+                else:
+                    q[p:p] = q[max(0, p - k):p] if rng.random() < 0.6 else bytes(rng.choice(list(b"ACGT"), k).tolist())
+            q = q[:length]
+            for _ in range(int(rng.integers(0, 3))):
+                q[int(rng.integers(0, length))] = int(rng.choice(list(b"ACGT")))
+            reads.append(bytes(q))
+    monkeypatch.setenv("BWT_SW_BAND_MIN", "0")
+    b = lib.Batch(ix)
+    try:
+        b.set_reads(*lib.pack_reads(reads))
+        c = b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        assert check_against_oracle(out, reads, ofm, ref1) > 200
+        assert c["n_banded"] > 100, c
+        monkeypatch.setenv("BWT_SW_BAND", "0")
+        b.run(lib.STAGE_EXTEND)
+        out0 = b.fetch_hits()
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(out[k], out0[k]), k
+        assert out["cigar"] == out0["cigar"]
+    finally:
+        b.destroy()
