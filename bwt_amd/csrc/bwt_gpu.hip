@@ -324,6 +324,7 @@ struct bwt_batch {
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
     DevBuf bq, slab_band;              // k_sw_band: the queue of what it passes on, its direction slab
     bool band_ran = false;
+    int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig, pairs;
@@ -907,7 +908,14 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             src.clus_off = b->clus_off.as<uint64_t>(); src.pos = b->pos.as<uint32_t>(); src.r_qty = b->r_qty.as<uint32_t>();
             src.r_cl = b->r_cl.as<uint32_t>(); src.c_S = b->c_S.as<uint32_t>(); src.c_D = b->c_D.as<uint32_t>(); src.c_qoff = b->c_qoff.as<uint64_t>();
             src.c_qlen = b->c_qlen.as<uint32_t>(); src.c_woff = b->c_woff.as<int64_t>(); src.c_wlen = b->c_wlen.as<uint32_t>();
-            KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, std::min<uint32_t>(cdiv((uint64_t)b->n * 4, 256), 2048), 256, io, b->n, src);
+            // grid = what is resident at once (the passes are uniform: a second, partly filled round of blocks would cost a quarter)
+            if (!b->occ_prefilter) {
+                int per_cu = 5;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sw_prefilter<true>, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 5; }
+                b->occ_prefilter = std::max(1, std::min(per_cu, 8));
+                if (const char *e = getenv("BWT_PF_BLOCKS_PER_CU")) b->occ_prefilter = std::max(1, std::min(atoi(e), b->occ_prefilter));   // experiments
+            }
+            KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, (uint32_t)std::min<uint64_t>(cdiv((uint64_t)b->n * 4, 256), (uint64_t)dev_cus * b->occ_prefilter), 256, io, b->n, src);
             b->cand_pending = false;
             if (!b->max_w_known && (rc = fetch_counters(b))) return rc;    // max_w / max_lq size the DP kernels' LDS and slabs
             max_w = b->hctr.max_w; max_lq = b->hctr.max_lq;

@@ -2179,14 +2179,25 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
         uint64_t co_r = 0, qo_r = 0;
         uint32_t lq_r = 0;
         const uint32_t *cl_r = nullptr;
+        uint2 cl0 = make_uint2(0u, 0u);
+        bool cl0_ok = false;
         if (FROM_READS) {
-            K_r = item < n_items ? src.r_K[item] : 0u;
+            // everything a read's first candidate needs is asked for at once -- its cluster count, offsets, flags and the first
+            // staged cluster of its r_cl row, whether or not that row turns out to be in use -- so that the window planes are the
+            // second round trip of the pass, not the fourth (the kernel is bound by the latency of its dependent loads)
+            const bool inr = item < n_items;
+            K_r = inr ? src.r_K[item] : 0u;
+            const uint64_t o0 = inr ? src.off[item] : 0ull, o1 = inr ? src.off[item + 1] : 0ull;
+            const uint64_t co = inr ? src.clus_off[item] : 0ull;
+            const uint32_t rq = inr ? src.r_qty[item] : 0u;
+            if (inr && src.r_cl) cl0 = *(const uint2 *)(src.r_cl + (uint64_t)item * (2 * CL_STAGE));
             kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(K_r));
             if (K_r) {
-                qo_r = src.off[item]; lq_r = (uint32_t)(src.off[item + 1] - qo_r);
-                co_r = src.clus_off[item];
+                qo_r = o0; lq_r = (uint32_t)(o1 - o0);
+                co_r = co;
                 // clusters staged by the seed kernels (RQ_DONE) sit in the read's r_cl row, the cluster kernels' in its slice of pos
-                cl_r = (src.r_qty[item] & RQ_DONE) ? src.r_cl + (uint64_t)item * (2 * CL_STAGE) : src.pos + src.seed_off[item];
+                cl0_ok = (rq & RQ_DONE) != 0 && src.r_cl != nullptr;
+                cl_r = (rq & RQ_DONE) ? src.r_cl + (uint64_t)item * (2 * CL_STAGE) : src.pos + src.seed_off[item];
                 maxlq = lq_r > maxlq ? lq_r : maxlq;
             }
         }
@@ -2199,7 +2210,8 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
             int64_t wo;
             uint64_t qo;
             if (FROM_READS) {
-                const uint32_t S = have ? cl_r[2 * kc] : 0u, D = have ? cl_r[2 * kc + 1] : 0u;
+                const bool spec = kc == 0 && cl0_ok;
+                const uint32_t S = !have ? 0u : spec ? cl0.x : cl_r[2 * kc], D = !have ? 0u : spec ? cl0.y : cl_r[2 * kc + 1];
                 lq = have ? lq_r : 0u; w = have ? lq_r + D : 0u; qo = qo_r;
                 wo = (int64_t)S - (int64_t)w + BWT_REF_EXT;
                 if (have && ql == 0) {
