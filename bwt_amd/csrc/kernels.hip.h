@@ -836,6 +836,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         const unsigned long long pend = (bp >> seg0) & segmask;
         const uint32_t qty = (uint32_t)__popcll((bs >> seg0) & segmask), crash = ((bc >> seg0) & segmask) ? 1u : 0u;
         const bool leader = valid && slot == 0;
+        if (__ballot(leader && pend != 0) && lane == 0) atomicAdd(&ctr->n_pend, 1u);    // (never with a full-depth table and clean reads)
         if (leader) {
             r_pend[r] = pend;
             if (pend) {                                           // k_search_pending adds its share and finishes the read
@@ -1378,6 +1379,7 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                                                          uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                          uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
                                                          uint32_t *__restrict__ mid4q, Counters *ctr) {
+    if (ctr->n_pend == 0) return;                                 // no seed-kernel pass left a task behind: no need to look through r_pend
     extern __shared__ uint16_t pend_list_[];                      // 4 waves x 64 reads x maxT pending tasks (dynamic)
     __shared__ unsigned long long accP_[4][64];
     __shared__ uint32_t accQ_[4][64];                             // qty | crash << 31

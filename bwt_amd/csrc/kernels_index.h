@@ -138,7 +138,7 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned long long lf_steps, sa_reads, n_tasks, sw_cells, window_bytes, n_float, err_flags, kt_lookups;
     unsigned int max_w, max_lq, n_big, fp_count, tq_count, dq_count, tq2_count, n_mid2, n_mid4, n_small;
     unsigned int n_gq, pad_;   // groups k_seed_fast handed back to k_seed_tasks
-    unsigned int max_D, pad2_; // largest cluster width D the seed kernels staged (window = Lq + D: sizes the extend stage without a round trip)
+    unsigned int max_D, n_pend;  // (n_pend: wave passes of the seed kernels that left a task to k_search_pending; 0 = it has nothing to do) // largest cluster width D the seed kernels staged (window = Lq + D: sizes the extend stage without a round trip)
     unsigned int why[6];       // ... by reason: [0] base outside ACGT, [1] table overflow, [4] > 64 seeds in a read, [5] > CL_STAGE clusters
     unsigned int band_in, band_left, band_next, pad3_;   // k_sw_band: DP candidates it was given, those it passed on to the full-rectangle kernels, its work counter
 };
