@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     // glist != null: only the groups k_seed_fast handed back (it wrote nothing for them)
     const uint32_t groups = glist ? *gcount : (n + rw - 1) / rw;
-    uint32_t live = 0, looked = 0, nsmall = 0, dmax = 0;
+    uint32_t live = 0, looked = 0, nsmall = 0, dmax = 0, had_pend = 0;
     unsigned long long Psum = 0;
     for (uint32_t gi = wave; gi < groups; gi += nwaves) {
         const uint32_t g = glist ? glist[gi] : gi;
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         const unsigned long long pend = (bp >> seg0) & segmask;
         const uint32_t qty = (uint32_t)__popcll((bs >> seg0) & segmask), crash = ((bc >> seg0) & segmask) ? 1u : 0u;
         const bool leader = valid && slot == 0;
-        if (__ballot(leader && pend != 0) && lane == 0) atomicAdd(&ctr->n_pend, 1u);    // (never with a full-depth table and clean reads)
+        if (leader && pend != 0) had_pend = 1u;                  // (never with a full-depth table and clean reads)
         if (leader) {
             r_pend[r] = pend;
             if (pend) {                                           // k_search_pending adds its share and finishes the read
@@ -996,6 +996,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
     readq_drain(rq, bigq, mid2q, mid4q, ctr);
     dmax = wave_max_u32(dmax);
     if (lane == 0 && dmax) atomicMax(&ctr->max_D, dmax);
+    if (__ballot(had_pend != 0) && lane == 0) ctr->n_pend = 1u;        // (a plain store: every writer writes the same)
     unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
     if (lane == 0 && (l | k | s | ns)) {
         atomicAdd(&ctr->n_tasks, l);
