@@ -10,7 +10,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$WL -o trace -- \
-    python3 $ROOT/bench.py --steps 10 --warmup 2 --workload $WL --no-cpu-baseline --no-pipeline > $OUT/$WL.bench.json 2> $OUT/$WL.err || exit 1
+    python3 $ROOT/bench.py --steps 30 --warmup 2 --workload $WL --no-cpu-baseline --no-pipeline > $OUT/$WL.bench.json 2> $OUT/$WL.err || exit 1
+[ -n "${STATS_ONLY:-}" ] && exit 0
 # HBM traffic counters, separate passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel-trace only
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${WL}_pmc_$C -o pmc -- \
