@@ -130,9 +130,13 @@ __device__ __forceinline__ SortMasks sort_masks() {
     M.mirror63 = (int)((l ^ 63u) << 2); M.x32 = (int)((l ^ 32u) << 2);
     return M;
 }
+// (as ONE instruction: the median of {p, o, K} with K = 0 in the lanes that keep the smaller value -- nothing is below 0 --
+// and K = ~0 in those that keep the larger; `lower` holds ~K.  v_med3_u32 comes out of the min / max form below.)
 __device__ __forceinline__ uint32_t ms_keep(uint32_t p, uint32_t o, uint32_t lower) {
+    const uint32_t K = ~lower;
     const uint32_t mn = p < o ? p : o, mx = p < o ? o : p;
-    return (mn & lower) | (mx & ~lower);
+    const uint32_t c = mx < K ? mx : K;
+    return mn > c ? mn : c;
 }
 template <int CTRL, int N>
 __device__ __forceinline__ void ms_dpp(uint32_t (&p)[N], uint32_t lower) {
