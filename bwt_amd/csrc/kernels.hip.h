@@ -183,8 +183,28 @@ __device__ __forceinline__ void mirror_sort64(uint32_t (&p)[N], const SortMasks 
 }
 // The general kernels keep the compare / ballot / select form: with the mirror form k_seed_tasks needs 127 VGPRs and spills
 // SGPRs, and is slower (6.9 against 6.7 ms at GRCh38 scale, 12.6 against 12.0 ms on 150-bp reads).
-__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) { return bitonic_sort_upto<64>(p); }
-__device__ __forceinline__ void wave_sort2_u32(uint32_t &a, uint32_t &b) { bitonic_sort_upto2<64>(a, b); }
+#ifndef BWT_GENERIC_MIRROR_SORT
+#define BWT_GENERIC_MIRROR_SORT 1
+#endif
+// (one register / two independent registers side by side)
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t p) {
+#if BWT_GENERIC_MIRROR_SORT
+    uint32_t a[1] = {p};
+    mirror_sort64(a, sort_masks());
+    return a[0];
+#else
+    return bitonic_sort_upto<64>(p);
+#endif
+}
+__device__ __forceinline__ void wave_sort2_u32(uint32_t &a, uint32_t &b) {
+#if BWT_GENERIC_MIRROR_SORT
+    uint32_t v[2] = {a, b};
+    mirror_sort64(v, sort_masks());
+    a = v[0]; b = v[1];
+#else
+    bitonic_sort_upto2<64>(a, b);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // exclusive scan  u32 -> u64   (3 kernels: tile sums, scan of the sums, tile scans + offset: the input is read
@@ -949,7 +969,11 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                     wave_sort2_u32(p0, p1);
                     const uint32_t rv = (uint32_t)__shfl((int)p1, 63 - (int)lane, 64);
                     p1 = p0 < rv ? rv : p0; p0 = p0 < rv ? p0 : rv;
+#if BWT_GENERIC_MIRROR_SORT
+                    { uint32_t v[2] = {p0, p1}; bitonic_merge64(v, sort_masks()); p0 = v[0]; p1 = v[1]; }
+#else
                     bitonic_merge2<64, 32>(p0, p1);
+#endif
                     __builtin_amdgcn_wave_barrier();
                     row[lane] = p0; row[64 + lane] = p1;
                     __builtin_amdgcn_wave_barrier();
