@@ -397,8 +397,10 @@ def main():
             glines = counts["n_lookups"] * ((1.0 - back) if fast else 1.0) / (per["fm_lookup"] / 1e3) / 1e9
             roofs["fm_lookup"]["random_lines"] = {"achieved_Glines_per_s": glines, "measured_ceiling_Glines_per_s": 47.0,
                                                   "frac": glines / 47.0}
-        dp_cells = counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1)
-        if "sw_extend" in per and counts["n_dp"] > 32768:
+        # (cells of the full-rectangle kernels: the DP candidates the banded kernel did not settle)
+        dp_left = counts["n_dp"] - counts.get("n_banded", 0)
+        dp_cells = counts["sw_cells"] * dp_left / max(counts["n_clusters"], 1)
+        if "sw_extend" in per and dp_left > 32768:
             ops_per_cell = 7.4 if "sw_trace_pk" in per else 9.4      # score-only pass / the traced DP run on the whole DP queue
             ops = dp_cells * ops_per_cell / (per["sw_extend"] / 1e3) / 1e12
             roofs["sw_extend"] = {"kernel": "k_sw_pk", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS,
@@ -439,7 +441,9 @@ def main():
                               "settled_by_banded_dp": counts.get("n_banded", 0),
                               "dp_kernel": ("k_sw_band (24 diagonals + certificate), then " if banded else "") +
                                            ("k_sw_wave (wave per alignment: short queue)" if left <= 32768 else "k_sw_pk"),
-                              "dp_cells_per_s": dp_cells / t_dp if t_dp else None}
+                              # cells of the reference's full rectangles for these candidates, per second of DP kernels (the banded
+                              # kernel fills 24 diagonals of them)
+                              "dp_cells_per_s": counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1) / t_dp if t_dp else None}
         # PCIe-inclusive rate (never `value`): host buffers in, host hit tables out, one untimed-extra pass
         t0 = time.perf_counter()
         batch.set_reads(bases, off)
