@@ -17,7 +17,7 @@ for d in ("a","b"):
     for f in glob.glob(root+"/"+d+"/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"].split("(")[0]
-            if ("k_sw_pk" in k) or k.startswith("k_search") or k.startswith("k_cluster_small") or ("k_seed_tasks" in k) or ("k_seed_fast" in k) or k.startswith("k_sw_prefilter") or ("k_sw_band" in k):
+            if ("k_sw_pk" in k) or k.startswith("k_search") or k.startswith("k_cluster_small") or ("k_seed_tasks" in k) or ("k_seed_fast" in k) or ("k_sw_prefilter" in k) or ("k_sw_band" in k):
                 agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])]+=1
     for k in agg:
         print(k, {c: "%.4g"%(v/n[(k,c)]) for c,v in agg[k].items()})
