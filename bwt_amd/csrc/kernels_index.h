@@ -62,8 +62,8 @@ __device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anyt
 // keys, the extend prefilter) works on 16..32-bit windows of these planes instead of bytes.
 // Lane = 16 bases (one 16-byte load); the plane bits come out of each 4-byte word by SWAR arithmetic:
 //   code bits: hi = bit 2, lo = bit 1 ^ bit 2 of the ASCII code (A 41, C 43, G 47, T 54);
-//   is-ACGT: the byte equals 40 | (bits 1,2) | T << 4 | !T  (T = bit 2 & ~bit 1), by an exact zero-byte test;
-//   one multiply by 0x01020408 gathers the flag bits of two words' eight bytes into a byte.
+//   is-ACGTN: the byte equals the entry of an 8-byte table (v_perm_b32) picked by its bits 1..3, by an exact zero-byte test;
+//   a dot product with the weights 1 2 4 8 (16 32 64 128) gathers the flag bits of a word's four bytes (v_dot4_u32_u8).
 #define RP_LO 0
 #define RP_HI 1
 #define RP_N 2
@@ -71,15 +71,25 @@ __device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anyt
 __device__ __forceinline__ uint32_t rp_zero_bytes(uint32_t d) {            // 1 in bit 0 of every byte of d that is zero
     return (~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
 }
+// One 4-byte word: v_perm_b32 as an 8-entry table -- sel = bits 1..3 of the ASCII code (A 0, C 1, T 2, G 3, N 7) picks the
+// byte the code would have to be ('A' 'C' 'T' 'G' 0 0 0 'N'); one exact zero-byte test of x ^ expected then says "one of ACGTN",
+// and among those only N has bit 2 of sel.  Code bits as before: hi = sel bit 1, lo = sel bit 0 ^ sel bit 1.
 __device__ __forceinline__ void rp_word(uint32_t x, uint32_t &l, uint32_t &h, uint32_t &nb, uint32_t &ob) {
-    h = (x >> 2) & 0x01010101u;
-    l = ((x >> 1) ^ (x >> 2)) & 0x01010101u;
-    const uint32_t t = h & ~(x >> 1);
-    const uint32_t expect = 0x40404040u | (x & 0x06060606u) | (t << 4) | (t ^ 0x01010101u);
+    const uint32_t sel = (x >> 1) & 0x07070707u;
+    const uint32_t expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, sel);
     const uint32_t a = rp_zero_bytes(x ^ expect);
-    nb = rp_zero_bytes(x ^ 0x4E4E4E4Eu);
-    ob = (a | nb) ^ 0x01010101u;
-    l &= a; h &= a;
+    const uint32_t s1 = sel >> 1;
+    nb = a & (sel >> 2);
+    const uint32_t acgt = a ^ nb;
+    ob = a ^ 0x01010101u;
+    h = s1 & acgt;
+    l = (sel ^ s1) & acgt;
+}
+// the flag bits (bit 0 of every byte) of four words = 16 bases as 16 bits: one dot product per word (weights 1 2 4 8 / 16 32 64 128)
+__device__ __forceinline__ uint32_t rp_gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    const uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+    return lo | (hi << 8);
 }
 static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
                                                       uint32_t *__restrict__ planes) {
@@ -95,17 +105,14 @@ static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__res
             for (uint32_t i = 0; p0 + i < total; i++)
                 x[i >> 2] = (x[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)bases[p0 + i] << (8 * (i & 3)));
         }
-        uint32_t out[4] = {0, 0, 0, 0};
+        uint32_t fl[4], fh[4], fn[4], fo[4];
 #pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-            uint32_t l0, h0, n0, o0, l1, h1, n1, o1;
-            rp_word(x[k], l0, h0, n0, o0);
-            rp_word(x[k + 1], l1, h1, n1, o1);
-            out[RP_LO] |= (((l0 | (l1 << 4)) * 0x01020408u) >> 24) << (4 * k);
-            out[RP_HI] |= (((h0 | (h1 << 4)) * 0x01020408u) >> 24) << (4 * k);
-            out[RP_N] |= (((n0 | (n1 << 4)) * 0x01020408u) >> 24) << (4 * k);
-            out[RP_O] |= (((o0 | (o1 << 4)) * 0x01020408u) >> 24) << (4 * k);
-        }
+        for (int k = 0; k < 4; k++) rp_word(x[k], fl[k], fh[k], fn[k], fo[k]);
+        uint32_t out[4];
+        out[RP_LO] = rp_gather16(fl[0], fl[1], fl[2], fl[3]);
+        out[RP_HI] = rp_gather16(fh[0], fh[1], fh[2], fh[3]);
+        out[RP_N] = rp_gather16(fn[0], fn[1], fn[2], fn[3]);
+        out[RP_O] = rp_gather16(fo[0], fo[1], fo[2], fo[3]);
         // the odd lane's 16 bits complete the even lane's word
         uint4 w;
         w.x = out[0] | ((uint32_t)__shfl_xor((int)out[0], 1, 64) << 16);
