@@ -938,9 +938,11 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     b->band_ran = false;
     const char *env_bm = getenv("BWT_SW_BAND_MIN");               // tests: queues up to this size are left to k_sw_wave (default 16384)
     const uint32_t band_min = std::min<uint32_t>(wv_thresh, env_bm ? (uint32_t)atoi(env_bm) : 16384u);
-    if (io.dq && max_lq >= 2 && max_lq <= 4096 && !(env_band && env_band[0] == '0')) {
+    if (io.dq && max_lq >= 2 && max_lq <= SWB_MAX_LQ && !(env_band && env_band[0] == '0')) {
         const uint32_t rows = max_lq + 1;
-        const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4));   // resident: 4 waves per SIMD
+        // resident: 4 waves per SIMD; the direction slab (rows x 768 B per wave) stays under 1 GiB for long reads
+        const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4),
+                                                                                  (1ull << 30) / ((uint64_t)4 * rows * 3 * 64 * 4)));
         if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->slab_band.ensure((uint64_t)bblocks * 4 * rows * 3 * 64 * 4))) return rc;
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 16, b->stream));
         KLAUNCH(b, "sw_band", k_sw_band<24>, bblocks, 256, io, b->bq.as<uint32_t>(), b->slab_band.as<uint32_t>(), rows, band_min);

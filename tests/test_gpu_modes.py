@@ -254,7 +254,7 @@ def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
     assert kept[1] > 0 and kept[1] >= kept[0]
 
 
-@pytest.mark.parametrize("length", [48, 64, 100, 150, 175])
+@pytest.mark.parametrize("length", [48, 64, 100, 150, 175, 400])
 def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_bytes, length, monkeypatch):
     """k_sw_band runs the DP on 24 diagonals around the cluster and keeps its result only when the best score proves that
     nothing outside the band can matter (kernels.hip.h); everything else goes on to the full-rectangle kernels.
