@@ -395,6 +395,26 @@ static int dev_scan(bwt_batch *b, const uint32_t *in, uint64_t *out, uint64_t n)
     return 0;
 }
 
+// two scans of the same length (the hit and CIGAR-byte offsets of a batch): one set of launches
+static int dev_scan_pair(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, uint64_t n) {
+    if (n <= SCAN_TILE) {
+        int rc = dev_scan(b, in0, out0, n);
+        return rc ? rc : dev_scan(b, in1, out1, n);
+    }
+    const uint32_t nb = std::max<uint32_t>(1, cdiv(n, SCAN_TILE));
+    int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8 * 2);
+    if (rc) return rc;
+    ScanPair p;
+    p.in[0] = in0; p.in[1] = in1; p.out[0] = out0; p.out[1] = out1;
+    p.bsum[0] = b->scan_tmp.as<uint64_t>(); p.bsum[1] = p.bsum[0] + nb + 1;
+    ProfScope ps(b, "scan");
+    hipLaunchKernelGGL(k_scan1_pair, dim3(nb, 2), dim3(SCAN_BLOCK), 0, b->stream, p, n);
+    hipLaunchKernelGGL(k_scan2_pair, dim3(1, 2), dim3(SCAN_BLOCK), 0, b->stream, p, nb);
+    hipLaunchKernelGGL(k_scan3_pair, dim3(nb, 2), dim3(SCAN_BLOCK), 0, b->stream, p, n, nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int bwt_batch_create(bwt_index *ix, bwt_batch **out) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_batch_create: null argument");
     HIPCHK(hipSetDevice(ix->device));
@@ -878,7 +898,7 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
 // SW_TRACE over the candidates whose alignment is not the plain diagonal (and those too wide for the
 // LDS pass), then SW_FP over the candidates that met a base outside ACGT.
 static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64_t rbuf_len, uint32_t max_w,
-                  uint32_t max_lq, const uint32_t *qplanes, const uint32_t *wplanes) {
+                  uint32_t max_lq, const uint32_t *qplanes, const uint32_t *wplanes, bool first) {
     const uint64_t nc = b->n_cand;
     int rc;
     if ((rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) ||
@@ -889,7 +909,11 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, b->device);
     if ((rc = b->cig.ensure(nc * b->cig_stride + 16))) return rc;
-    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
+    // the queue counters: zero since the stage that started this run zeroed the whole block; a retry (wider CIGAR slots) resets them
+    if (!first) {
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 16, b->stream));
+    }
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
     io.c_qoff = b->c_qoff.as<uint64_t>(); io.c_qlen = b->c_qlen.as<uint32_t>();
@@ -944,7 +968,6 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4),
                                                                                   (1ull << 30) / ((uint64_t)4 * rows * 3 * 64 * 4)));
         if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->slab_band.ensure((uint64_t)bblocks * 4 * rows * 3 * 64 * 4))) return rc;
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 16, b->stream));
         KLAUNCH(b, "sw_band", k_sw_band<24>, bblocks, 256, io, b->bq.as<uint32_t>(), b->slab_band.as<uint32_t>(), rows, band_min);
         HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->dq_count, &b->ctr.as<Counters>()->band_left, 4, hipMemcpyDeviceToDevice, b->stream));
         io.dq = b->bq.as<uint32_t>();
@@ -1060,8 +1083,7 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
     KLAUNCH(b, "hits_count", k_hits_count, cdiv(n, 256), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
             b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_cigb.as<uint32_t>(),
             b->r_status.as<int32_t>(), b->ctr.as<Counters>());
-    if ((rc = dev_scan(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), n))) return rc;
-    if ((rc = dev_scan(b, b->r_cigb.as<uint32_t>(), b->cigb_off.as<uint64_t>(), n))) return rc;
+    if ((rc = dev_scan_pair(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), b->r_cigb.as<uint32_t>(), b->cigb_off.as<uint64_t>(), n))) return rc;
     // the hit tables are sized by their bounds (a hit per candidate, a full text slot per hit), so that nothing has to come
     // back to the host before k_hits_write: the totals are read once, together with the counters, when everything is queued
     const size_t nh = (size_t)b->n_cand + 1;
@@ -1087,7 +1109,7 @@ static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, 
                         const uint32_t *wplanes = nullptr) {
     for (int attempt = 0; attempt < 8; attempt++) {
         if (attempt && b->ix) { max_w = b->hctr.max_w; max_lq = b->hctr.max_lq; }    // (known since the first attempt's prefilter)
-        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq, qplanes, wplanes);
+        int rc = run_sw(b, qbuf, rbuf, rbuf_len, max_w, max_lq, qplanes, wplanes, attempt == 0);
         if (rc) return rc;
         // clear the sticky CIGAR-overflow flag before counting
         Counters *dc = b->ctr.as<Counters>();

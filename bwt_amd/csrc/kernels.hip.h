@@ -228,7 +228,7 @@ __device__ __forceinline__ uint64_t block_scan_u64(uint64_t s, uint64_t &excl) {
     excl = before + incl - s;
     return total;
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict__ in, uint64_t *__restrict__ bsum, uint64_t n) {
+__device__ __forceinline__ void scan1_body(const uint32_t *__restrict__ in, uint64_t *__restrict__ bsum, uint64_t n) {
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint64_t s = 0;
     if ((uint64_t)(blockIdx.x + 1) * SCAN_TILE <= n) {             // a full tile: two 16-byte loads per thread
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 // single block: exclusive scan of bsum[0..nb) in place, total to bsum[nb]
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t nb) {
+__device__ __forceinline__ void scan2_body(uint64_t *bsum, uint32_t nb) {
     __shared__ uint64_t sh[SCAN_BLOCK];
     __shared__ uint64_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t n
     }
     if (threadIdx.x == 0) bsum[nb] = carry;
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                       const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) {
+__device__ __forceinline__ void scan3_body(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                           const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) {
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     const bool full = (uint64_t)(blockIdx.x + 1) * SCAN_TILE <= n;  // a full tile: 16-byte loads and stores
     uint32_t v[SCAN_ITEMS];
@@ -296,6 +296,18 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict
         for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(const uint32_t *__restrict__ in, uint64_t *__restrict__ bsum, uint64_t n) { scan1_body(in, bsum, n); }
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t nb) { scan2_body(bsum, nb); }
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                       const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) { scan3_body(in, out, bsum, n, nb); }
+// two arrays of the same length in one set of launches (blockIdx.y picks the array): half the launches of two scans
+struct ScanPair { const uint32_t *in[2]; uint64_t *out[2]; uint64_t *bsum[2]; };
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1_pair(ScanPair p, uint64_t n) { scan1_body(p.in[blockIdx.y], p.bsum[blockIdx.y], n); }
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan2_pair(ScanPair p, uint32_t nb) { scan2_body(p.bsum[blockIdx.y], nb); }
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3_pair(ScanPair p, uint64_t n, uint32_t nb) {
+    scan3_body(p.in[blockIdx.y], p.out[blockIdx.y], p.bsum[blockIdx.y], n, nb);
 }
 
 // ... and when everything fits one tile (batches of up to 2048 reads: the size a worker's message has): one launch
