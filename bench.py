@@ -408,8 +408,9 @@ def main():
                                   "cells_per_launch": dp_cells, "valu_lane_ops_per_cell": ops_per_cell, "avg_launch_ms": per["sw_extend"],
                                   "share_of_step": kt["sw_extend"]["ms"] / total_ms}
         if "sw_band" in per and counts.get("n_banded", 0) > 0:
-            # banded DP: 24 cells per row, 17.6 instructions per cell PAIR (two candidates per lane) = 8.8 lane-ops per cell
-            bcells = counts["n_banded"] * length * 24.0
+            # banded DP: 20 cells per row in the first tier (nearly everything it settles is settled there), 17.6 instructions per
+            # cell PAIR (two candidates per lane) = 8.8 lane-ops per cell
+            bcells = counts["n_banded"] * length * 20.0
             ops = bcells * 8.8 / (per["sw_band"] / 1e3) / 1e12
             roofs["sw_band"] = {"kernel": "k_sw_band", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS, "unit": "Tlane-op/s",
                                 "frac": ops / VALU_PEAK_TOPS, "traffic": traffic.get("k_sw_band"), "cells_per_launch": bcells,
@@ -439,7 +440,7 @@ def main():
                               "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"],
                               "dp_candidates": counts["n_dp"],
                               "settled_by_banded_dp": counts.get("n_banded", 0),
-                              "dp_kernel": ("k_sw_band (24 diagonals + certificate), then " if banded else "") +
+                              "dp_kernel": ("k_sw_band (20, then 32 diagonals + certificate), then " if banded else "") +
                                            ("k_sw_wave (wave per alignment: short queue)" if left <= 32768 else "k_sw_pk"),
                               # cells of the reference's full rectangles for these candidates, per second of DP kernels (the banded
                               # kernel fills 24 diagonals of them)

@@ -322,7 +322,7 @@ struct bwt_batch {
     uint32_t cig_stride = 32;
     // sw slabs
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
-    DevBuf bq, slab_band;              // k_sw_band: the queue of what it passes on, its direction slab
+    DevBuf bq, bq2, slab_band;         // k_sw_band: the queues of what its two tiers pass on, the direction slab
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     // hits
@@ -456,7 +456,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->bq2, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -912,7 +912,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     // the queue counters: zero since the stage that started this run zeroed the whole block; a retry (wider CIGAR slots) resets them
     if (!first) {
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 16, b->stream));
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 32, b->stream));
     }
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
@@ -964,13 +964,24 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     const uint32_t band_min = std::min<uint32_t>(wv_thresh, env_bm ? (uint32_t)atoi(env_bm) : 16384u);
     if (io.dq && max_lq >= 2 && max_lq <= SWB_MAX_LQ && !(env_band && env_band[0] == '0')) {
         const uint32_t rows = max_lq + 1;
-        // resident: 4 waves per SIMD; the direction slab (rows x 768 B per wave) stays under 1 GiB for long reads
-        const uint32_t bblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4),
-                                                                                  (1ull << 30) / ((uint64_t)4 * rows * 3 * 64 * 4)));
-        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->slab_band.ensure((uint64_t)bblocks * 4 * rows * 3 * 64 * 4))) return rc;
-        KLAUNCH(b, "sw_band", k_sw_band<24>, bblocks, 256, io, b->bq.as<uint32_t>(), b->slab_band.as<uint32_t>(), rows, band_min);
-        HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->dq_count, &b->ctr.as<Counters>()->band_left, 4, hipMemcpyDeviceToDevice, b->stream));
-        io.dq = b->bq.as<uint32_t>();
+        // resident grids: 4 (3 for the wide tier) waves per SIMD; the direction slab (rows x up to 1 KiB per wave) stays under 1 GiB
+        const uint64_t cap_blocks = (1ull << 30) / ((uint64_t)4 * rows * 4 * 64 * 4);
+        const uint32_t blocks1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4), cap_blocks));
+        const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 3), cap_blocks));
+        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->bq2.ensure(nc * 4 + 4)) ||
+            (rc = b->slab_band.ensure((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4)))
+            return rc;
+        Counters *dc = b->ctr.as<Counters>();
+        {
+            ProfScope ps(b, "sw_band");
+            hipLaunchKernelGGL(k_sw_band<20>, dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
+                               b->bq.as<uint32_t>(), &dc->band_in, b->slab_band.as<uint32_t>(), rows, band_min);
+            hipLaunchKernelGGL(k_sw_band<32>, dim3(blocks2), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq.as<uint32_t>(),
+                               (const unsigned int *)&dc->band_left, b->bq2.as<uint32_t>(), &dc->band2_in, b->slab_band.as<uint32_t>(), rows, band_min);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&dc->dq_count, &dc->band2_left, 4, hipMemcpyDeviceToDevice, b->stream));
+        io.dq = b->bq2.as<uint32_t>();
         b->band_ran = true;
     }
 
@@ -1158,7 +1169,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
         if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
         counts->n_dp = b->band_ran ? b->hctr.band_in : b->hctr.dq_count;
-        counts->n_banded = b->band_ran ? b->hctr.band_in - b->hctr.band_left : 0;
+        counts->n_banded = b->band_ran ? b->hctr.band_in - b->hctr.band2_left : 0;
         counts->n_traced += counts->n_banded;
         counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
         counts->n_handed_back = b->hctr.n_gq;

@@ -2808,9 +2808,15 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 #define SWB_MAX_LQ 1500            // 8 V + code of both candidates of a lane in 16 bits each
 // Two candidates per lane (low / high 16 bits of every register, the cell algebra of k_sw_pk): they share the row loop and
 // the cell index k, each has its own band offset x, window and last row.
+// The queue goes through two tiers: B = 20 first (a sixth fewer cells than 24; with D = 5 it covers a loss of 24 against the
+// perfect score, e.g. a 5-base insertion and two substitutions), then B = 32 for what that certificate did not cover (a loss
+// of up to 39-42), then the full rectangle.  in_q / in_count: this tier's queue; rest / ctl[1]: what it passes on; ctl[0]: the
+// number of candidates it was given; ctl[2]: its work counter.
+#define SWB_WAVES(B) ((B) > 24 ? 3 : 4)
 template <int B>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sw_band(SwIO io, uint32_t *__restrict__ rest, uint32_t *__restrict__ slab, uint32_t slab_rows,
-                                                                                                uint32_t skip_upto) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWB_WAVES(B), SWB_WAVES(B))))
+void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count, uint32_t *__restrict__ rest,
+               unsigned int *__restrict__ ctl, uint32_t *__restrict__ slab, uint32_t slab_rows, uint32_t skip_upto) {
     static_assert(B > 16 && B <= 32, "cells 16.. come from the second match word");
     constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8;
     const uint32_t lane = threadIdx.x & 63;
@@ -2818,14 +2824,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int RB = 8;                                                           // rows of directions a traceback stages in LDS at a time
     __shared__ uint32_t tb_lds[4][RB * NDW * 64];
     uint32_t *const tb = tb_lds[threadIdx.x >> 6] + lane;                           // [(r * NDW + k / 8) * 64]: every lane its own column
-    const uint32_t n_items = io.ctr->dq_count;
+    const uint32_t n_items = *in_count;
     if (n_items <= skip_upto) {
         // a short queue is k_sw_wave's (a lane per alignment would run a handful of waves for the serial length of a DP): passed through
-        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = io.dq[t];
-        if (wave == 0 && lane == 0) { io.ctr->band_in = n_items; io.ctr->band_left = n_items; }
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = in_q[t];
+        if (wave == 0 && lane == 0) { ctl[0] = n_items; ctl[1] = n_items; }
         return;
     }
-    if (wave == 0 && lane == 0) io.ctr->band_in = n_items;
+    if (wave == 0 && lane == 0) ctl[0] = n_items;
     uint32_t *const dirs = slab + (uint64_t)wave * slab_rows * NDW * 64 + lane;     // [(i * NDW + k / 8) * 64]: 8 cells x 2 candidates per word
     const uint32_t F8 = 0xFFF8FFF8u, K8 = 0x00080008u, K4 = 0x00040004u, K24 = 0x00180018u, KM4 = 0xFFFCFFFCu, KM15 = 0xFFF1FFF1u,
                    KM14 = 0xFFF2FFF2u;
@@ -2833,7 +2839,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // groups per resident wave (every wave leaves when the counter has passed the end of the queue)
     for (;;) {
         uint32_t g = 0;
-        if (lane == 0) g = atomicAdd(&io.ctr->band_next, 1u);
+        if (lane == 0) g = atomicAdd(&ctl[2], 1u);
         g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         if ((uint64_t)g * 128 >= n_items) break;
         uint32_t c[2], lq[2], w[2];
@@ -2846,7 +2852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const uint32_t item = g * 128 + h * 64 + lane;
             have[h] = item < n_items;
             c[h] = 0; lq[h] = 0; w[h] = 0; wo[h] = 0; qo[h] = 0;
-            if (have[h]) { c[h] = io.dq[item]; lq[h] = io.c_qlen[c[h]]; w[h] = io.c_wlen[c[h]]; wo[h] = io.c_woff[c[h]]; qo[h] = io.c_qoff[c[h]]; }
+            if (have[h]) { c[h] = in_q[item]; lq[h] = io.c_qlen[c[h]]; w[h] = io.c_wlen[c[h]]; wo[h] = io.c_woff[c[h]]; qo[h] = io.c_qoff[c[h]]; }
             D[h] = (int)w[h] - (int)lq[h];
             x[h] = (B - 1 - D[h]) >> 1;
             run[h] = have[h] && D[h] >= 0 && D[h] <= B - 1 - 2 * SWB_XMIN && lq[h] >= 2 && lq[h] < slab_rows && lq[h] <= SWB_MAX_LQ &&
@@ -3005,7 +3011,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (m) {
                 const int first = __ffsll((long long)m) - 1;
                 uint32_t base = 0;
-                if ((int)lane == first) base = atomicAdd(&io.ctr->band_left, (uint32_t)__popcll(m));
+                if ((int)lane == first) base = atomicAdd(&ctl[1], (uint32_t)__popcll(m));
                 base = (uint32_t)__shfl((int)base, first, 64);
                 if (pass) rest[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c[h];
             }

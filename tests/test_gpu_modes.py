@@ -256,7 +256,7 @@ def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
 
 @pytest.mark.parametrize("length", [48, 64, 100, 150, 175, 400])
 def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_bytes, length, monkeypatch):
-    """k_sw_band runs the DP on 24 diagonals around the cluster and keeps its result only when the best score proves that
+    """k_sw_band runs the DP on 20 (then 32) diagonals around the cluster and keeps its result only when the best score proves that
     nothing outside the band can matter (kernels.hip.h); everything else goes on to the full-rectangle kernels.
     Reads with one indel and up to 4 substitutions (most are settled by the band), reads with up to 14 substitutions (few are):
     every answer must be the oracle's, and both routes must have been taken."""
