@@ -738,6 +738,8 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
                     b->occ_seed_maxT = maxT | (big ? 0x100u : 0u);
                 }
                 const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
+                HIPCHK(hipMemsetAsync(b->r_pend.p, 0, (size_t)n * 8, b->stream));
+                HIPCHK(hipMemsetAsync(b->r_P.p, 0, (size_t)n * 4, b->stream));
                 ProfScope ps(b, "fm_lookup");
                 if (big)
                     hipLaunchKernelGGL(k_seed_fast<true>, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,

@@ -1386,8 +1386,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             }
         }
         if (valid && slot == 0) {
-            r_pend[r] = 0ull;
-            r_P[r] = 0;
+            // (r_pend and r_P of the reads this kernel keeps are zero: the host cleared both arrays before the launch)
             r_qty[r] = qty | (fuse_read ? RQ_DONE : 0u);
             if (fuse_read) { r_K[r] = Kc; Pacc += P; }
         }
