@@ -73,8 +73,8 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
     std::unique_lock<std::shared_mutex> lk(ix->mu);        // waits for running batches; none starts while the table is swapped
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->d.ktab = nullptr; ix->d.ktw = nullptr; ix->d.kt_k = 0;
-    ix->ktab.release(); ix->ktw.release();
+    ix->d.ktab = nullptr; ix->d.ktw = nullptr; ix->d.kt_k = 0; ix->d.ktsum = nullptr; ix->d.ktsum_levels = 0;
+    ix->ktab.release(); ix->ktw.release(); ix->ktsum.release();
     if (K == 0) return 0;
     const uint64_t wide_bytes = 64ull << (2 * K);
     if (wide < 0) {
@@ -101,6 +101,32 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
     HIPCHK(hipGetLastError());
     ix->d.ktab = ix->ktab.as<uint64_t>(); ix->d.kt_k = K;
     ix->d.ktw = wide ? ix->ktw.as<uint4>() : nullptr;
+    // Summary of the 8-byte levels (one bit per 64 entries: "not all plain too-many-seeds entries"): on a large genome every
+    // 12-mer occurs far more than MAX_RANGE times, and the lookup of a read's short last sub-read is answered by a cached
+    // bit instead of a random table line.  Used per level only where fewer than a quarter of the bits are set.
+    const char *env_sum = getenv("BWT_KTAB_SUMMARY");             // experiments / tests: 0 = no summary
+    const int top8 = wide ? K - 1 : K;                            // highest level kept as 8-byte entries
+    if (top8 >= KT_MIN && !(env_sum && env_sum[0] == '0')) {
+        const uint64_t words = (kt_level_off(top8 + 1) >> 11) + 2;
+        if ((rc = ix->ktsum.exact(words * 4 + 64 * 4))) return rc;
+        HIPCHK(hipMemsetAsync(ix->ktsum.p, 0, words * 4 + 64 * 4, ix->stream));
+        unsigned int *nset = ix->ktsum.as<unsigned int>() + words;                       // 16 counters behind the bitmap
+        for (int m = KT_MIN; m <= top8; m++) {
+            const uint64_t groups = (1ull << (2 * m)) >> 6;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((groups * 64 + 255) / 256, (uint64_t)cus * 8);
+            hipLaunchKernelGGL(k_kt_summary, dim3(grid), dim3(256), 0, ix->stream, (const uint64_t *)ix->ktab.as<uint64_t>(), m,
+                               ix->ktsum.as<uint32_t>(), nset);
+        }
+        unsigned int hset[16] = {0};
+        HIPCHK(hipMemcpyAsync(hset, nset, sizeof hset, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        HIPCHK(hipGetLastError());
+        uint32_t levels = 0;
+        for (int m = KT_MIN; m <= top8; m++)
+            if ((uint64_t)hset[m] * 4 < ((1ull << (2 * m)) >> 6) || (env_sum && env_sum[0] == '2')) levels |= 1u << m;    // (2: every level, for tests)
+        if (levels) { ix->d.ktsum = ix->ktsum.as<uint32_t>(); ix->d.ktsum_levels = levels; }
+        else ix->ktsum.release();
+    }
     return 0;
 }
 extern "C" int bwt_index_ktable(const bwt_index *ix) { return ix ? (ix->d.kt_k | (ix->d.ktw ? 16 : 0)) : 0; }

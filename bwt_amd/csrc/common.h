@@ -51,7 +51,7 @@ struct DevBuf {
 struct bwt_index {
     int device = 0;
     DevIndex d{};
-    DevBuf blocks, sa, ref1, refplanes, ktab, ktw;
+    DevBuf blocks, sa, ref1, refplanes, ktab, ktw, ktsum;
     uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
     int32_t shift = 0;
     uint64_t ref1_len = 0;

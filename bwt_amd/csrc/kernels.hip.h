@@ -636,6 +636,28 @@ __global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restric
     }
 }
 
+// k_kt_summary: level m of the 8-byte table, one bit per 64 entries (DevIndex::ktsum): set unless all 64 entries are plain
+// "too many seeds" entries (n = m steps done, MAX_RANGE < width, not the overflow mark).  A wave per 64 entries, grid-stride;
+// nset[m] counts the set bits (how sparse the level is decides whether checking the bit first pays).
+__global__ __launch_bounds__(256) void k_kt_summary(const uint64_t *__restrict__ tab, int m, uint32_t *__restrict__ sum,
+                                                     unsigned int *__restrict__ nset) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t groups = (1ull << (2 * m)) >> 6, base = kt_level_off(m);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t mine = 0;
+    for (uint64_t g = wave; g < groups; g += nwaves) {
+        const uint64_t ent = tab[base + g * 64 + lane];
+        const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF, nn = (uint32_t)(ent >> 60);
+        const bool plain = (int)nn >= m && wd > BWT_MAX_RANGE && wd != KT_OVF;
+        if (__ballot(!plain)) {
+            mine++;
+            const uint64_t bit = (base >> 6) + g;
+            if (lane == 0) atomicOr(&sum[bit >> 5], 1u << (bit & 31));
+        }
+    }
+    if (lane == 0 && mine) atomicAdd(&nset[m], mine);
+}
+
 // What a finished read hands to the cluster stage: P = seeds in all, Qty = sub-reads that returned a seed list
 // (sga.erl:32); reads with Qty < 2 cluster to [] (sga.erl:42-43) and get P = 0; reads with more than 64 seeds go to
 // the queues of the wider cluster kernels.  Reached by whole waves (wave_append); `active` lanes carry a read.
@@ -1110,6 +1132,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     const uint32_t inread = e >= 16 ? 0xffffu : ((0xffffu << (16 - e)) & 0xffffu);
     const bool wide = m == BWT_MAX_LEN;
     const uint64_t loff = kt_level_off(m > KT_MIN ? m : KT_MIN);
+    const bool usesum = !wide && m >= KT_MIN && ix.ktsum != nullptr && ((ix.ktsum_levels >> m) & 1u);   // check the summary bit before the 8-byte entry
     const uint32_t shsk = BWT_MIN_LEN * slot;
     const int hi_l = (int)(((seg0 + maxT - 1) & 63u) << 2), lo_l = (int)(((seg0 - 1) & 63u) << 2);
     const SortMasks SM = sort_masks();
@@ -1145,13 +1168,22 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t wz = __builtin_amdgcn_alignbit(pb.z, pa.z, sh), ww = __builtin_amdgcn_alignbit(pb.w, pa.w, sh);
         const uint32_t key = ((wx >> ksh) & kmask) | (((wy >> ksh) & kmask) << m);
         abn0_c = act2 && (endp2 < 16 || ((wz | ww) & inread) != 0);
+        // (the summary word of a lane below the top level: asked for first, so that it can be waited for with the table loads
+        // behind it still in flight)
+        const uint64_t nidx = loff + key;
+        uint32_t sword = 0xffffffffu;
+        if (act2 && usesum) sword = ix.ktsum[nidx >> 11];
         // lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
         const uint32_t aw = act2 && wide ? 1u : 0u;
         { const uint32_t kt = quad_bcast<0>(key); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         { const uint32_t kt = quad_bcast<1>(key); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         { const uint32_t kt = quad_bcast<2>(key); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        if (act2 && !wide) nent = ix.ktab[loff + key];
+        if (act2 && !wide) {
+            // summary bit clear: the entry is a plain "too many seeds" one -- said so without its table line
+            if ((sword >> ((nidx >> 6) & 31u)) & 1u) nent = ix.ktab[nidx];
+            else nent = ((unsigned long long)(uint32_t)m << 60) | ((unsigned long long)(BWT_MAX_RANGE + 1u) << 32) | 1ull;
+        }
     };
     uint4 wa, wb;
     planes_raw(wave, wa, wb);

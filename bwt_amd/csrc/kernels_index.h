@@ -47,6 +47,11 @@ struct DevIndex {
     const uint64_t *ktab;  // suffix-interval table, levels 8..kt_k (kernels.hip.h: kt_build); null when kt_k == 0
     const uint4 *ktw;      // level kt_k as 64-byte entries that also carry the first 14 SA values, or null (then ktab holds it)
     int kt_k;
+    // one bit per 64 entries of the 8-byte levels of ktab: clear = all 64 are plain "too many seeds" entries (the search ran its
+    // full length and the interval is wider than MAX_RANGE), so a lookup that finds the bit clear knows its answer without the
+    // table line.  ktsum_levels: bit m set = level m is sparse enough for the check to pay (kernels.hip.h: k_kt_summary).
+    const uint32_t *ktsum = nullptr;
+    uint32_t ktsum_levels = 0;
 };
 
 // byte-stream bit-planes (reads, Ref1) ---------------------------------------------------------------

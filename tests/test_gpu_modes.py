@@ -34,7 +34,7 @@ def check_against_oracle(out, reads, orc_fm, ref1):
     return nh
 
 
-MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_SW_BAND": "0"}, {"BWT_SW_BAND_MIN": "0"}, {"BWT_SW_BAND_MIN": "0", "BWT_SW_WAVE": "0"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
+MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_KTAB_SUMMARY": "2"}, {"BWT_KTAB_SUMMARY": "0"}, {"BWT_SW_BAND": "0"}, {"BWT_SW_BAND_MIN": "0"}, {"BWT_SW_BAND_MIN": "0", "BWT_SW_WAVE": "0"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
          {"BWT_SW_TRACE_ALL": "0", "BWT_SW_WAVE": "0"}, {"BWT_SW_WAVE": "0", "BWT_SW_PREFILTER": "0"},
          {"BWT_SEARCH_ILP": "2"}]
 
