@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     // words travel raw, two 16-byte loads per lane, and are aligned to the window when the next pass picks them up.)
     uint4 Q0, Q1, Q2, Q3;
     unsigned long long nent;
-    bool abn0_c = false;
+    bool abn0_c = false, nplain_c = false;
     auto planes_raw = [&](uint32_t g2, uint4 &pa, uint4 &pb) {     // plane words around the window [e - 16, e) of my sub-read in group g2
         const uint32_t r2 = g2 * rw + lread;
         const uint64_t endp2 = (uint64_t)r2 * ulen + (uint64_t)e;
@@ -1179,11 +1179,10 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         { const uint32_t kt = quad_bcast<1>(key); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         { const uint32_t kt = quad_bcast<2>(key); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        if (act2 && !wide) {
-            // summary bit clear: the entry is a plain "too many seeds" one -- said so without its table line
-            if ((sword >> ((nidx >> 6) & 31u)) & 1u) nent = ix.ktab[nidx];
-            else nent = ((unsigned long long)(uint32_t)m << 60) | ((unsigned long long)(BWT_MAX_RANGE + 1u) << 32) | 1ull;
-        }
+        // summary bit clear: the entry is a plain "too many seeds" one -- known without its table line.  (The load stays a bare
+        // conditional load: giving nent a value on the other path would merge right behind the load, i.e. wait for it here.)
+        nplain_c = act2 && !wide && !((sword >> ((nidx >> 6) & 31u)) & 1u);
+        if (act2 && !wide && !nplain_c) nent = ix.ktab[nidx];
     };
     uint4 wa, wb;
     planes_raw(wave, wa, wb);
@@ -1206,7 +1205,11 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         stag[qb] = Q0; stag[qb + SF_SLOT] = Q1; stag[qb + 2 * SF_SLOT] = Q2; stag[qb + 3 * SF_SLOT] = Q3;
         __builtin_amdgcn_wave_barrier();
         uint4 own = stag[lane * SF_SLOT];
-        if (!wide) { own.x = act ? (uint32_t)nent : 0u; own.y = act ? (uint32_t)(nent >> 32) : 0u; }
+        if (!wide) {
+            // (a plain too-many-seeds entry of level m: n = m steps, width MAX_RANGE + 1)
+            const unsigned long long ne = nplain_c ? (((unsigned long long)(uint32_t)m << 60) | ((unsigned long long)(BWT_MAX_RANGE + 1u) << 32) | 1ull) : nent;
+            own.x = act ? (uint32_t)ne : 0u; own.y = act ? (uint32_t)(ne >> 32) : 0u;
+        }
         if (!act) own.y = 0;
         // the next group's table loads, the plane loads of the group after it
         issue_table(g + nwaves, wa, wb);
