@@ -374,7 +374,8 @@ def main():
         # seed stage, both kernels: Lq per read in, one table entry per task (64 B / 8 B), 16 B per read (r_pend, r_P, r_qty) + 4 B (r_K)
         # + 8 B per cluster out; the general kernel also writes the sub-read table (4 B per task) and the rows of the reads it
         # does not cluster itself (16 B per task)
-        seed_common = counts["n_reads"] * (length + 20) + 64 * wide_l + 8 * narrow_l + 8 * counts["n_clusters"]
+        # (the fast kernel writes r_qty and r_K only -- the host clears r_pend / r_P before it: 8 B per read, not 20)
+        seed_common = counts["n_reads"] * (length + (8 if fast else 20)) + 64 * wide_l + 8 * narrow_l + 8 * counts["n_clusters"]
         general_extra = 4 * counts["n_tasks"] + int(16 * counts["n_tasks"] * unfused)
         models = {
             "fm_lookup": (("k_seed_fast", int(seed_common * (1.0 - back))) if fast else ("k_seed_tasks", seed_common + general_extra)),
