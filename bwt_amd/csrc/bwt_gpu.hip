@@ -755,26 +755,30 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
                 const char *env_big = getenv("BWT_SEED_BIG");           // experiments: 0 / 1 force the variant
                 const bool big = env_big ? env_big[0] == '1' : maxT > 14;
                 const size_t lds = sf_lds_bytes(maxT, big);
-                const void *kern = big ? (const void *)k_seed_fast<true> : (const void *)k_seed_fast<false>;
+                // the summary bit is looked at only when the index has one for the level of this batch's short last sub-read
+                const int mn = (int)(b->ulen % BWT_MIN_LEN) + BWT_MIN_LEN;
+                const bool sum = b->ix->d.ktsum && mn < BWT_MAX_LEN && ((b->ix->d.ktsum_levels >> mn) & 1u);
+                const void *kern = big ? (sum ? (const void *)k_seed_fast<true, true> : (const void *)k_seed_fast<true, false>)
+                                       : (sum ? (const void *)k_seed_fast<false, true> : (const void *)k_seed_fast<false, false>);
                 int &per_cu = b->occ_seed[3];
-                if (!per_cu || b->occ_seed_maxT != (maxT | (big ? 0x100u : 0u))) {
+                if (!per_cu || b->occ_seed_maxT != (maxT | (big ? 0x100u : 0u) | (sum ? 0x200u : 0u))) {
                     per_cu = 8;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 4; }
                     per_cu = std::max(1, std::min(per_cu, 8));
-                    b->occ_seed_maxT = maxT | (big ? 0x100u : 0u);
+                    b->occ_seed_maxT = maxT | (big ? 0x100u : 0u) | (sum ? 0x200u : 0u);
                 }
                 const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
                 HIPCHK(hipMemsetAsync(b->r_pend.p, 0, (size_t)n * 8, b->stream));
                 HIPCHK(hipMemsetAsync(b->r_P.p, 0, (size_t)n * 4, b->stream));
                 ProfScope ps(b, "fm_lookup");
-                if (big)
-                    hipLaunchKernelGGL(k_seed_fast<true>, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
-                                       b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
-                                       b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
-                else
-                    hipLaunchKernelGGL(k_seed_fast<false>, dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen,
-                                       b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),
-                                       b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>());
+                {
+#define SF_LAUNCH(BIGV, SUMV) hipLaunchKernelGGL((k_seed_fast<BIGV, SUMV>), dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen, \
+                                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_K.as<uint32_t>(),                      \
+                                   b->r_cl.as<uint32_t>(), b->gq.as<uint32_t>(), b->ctr.as<Counters>())
+                    if (big) { if (sum) SF_LAUNCH(true, true); else SF_LAUNCH(true, false); }
+                    else { if (sum) SF_LAUNCH(false, true); else SF_LAUNCH(false, false); }
+#undef SF_LAUNCH
+                }
             }
             KLAUNCH(b, "fm_lookup_rest", (k_seed_tasks<false, true>), resident(1, (const void *)k_seed_tasks<false, true>), 256, SEED_ARGS, b->r_K.as<uint32_t>(), b->r_cl.as<uint32_t>(), b->ctr.as<Counters>(), 1, b->ulen,
                     (const uint32_t *)b->gq.as<uint32_t>(), (const unsigned int *)&b->ctr.as<Counters>()->n_gq);

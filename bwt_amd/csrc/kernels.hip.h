@@ -1105,7 +1105,8 @@ __host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT, bool big) {
 }
 // BIG: reads of up to 128 seeds (two registers per read; 106 VGPRs, 4 waves per SIMD); else up to 64 (95 VGPRs, 5 waves -- worth
 // 5 % on batches whose reads rarely pass 64 seeds, e.g. 100-bp reads)
-template <bool BIG>
+// SUM: the batch's sub-read below the top level looks at the summary bit first (DevIndex::ktsum covers its level)
+template <bool BIG, bool SUM>
 __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
@@ -1132,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
     const uint32_t inread = e >= 16 ? 0xffffu : ((0xffffu << (16 - e)) & 0xffffu);
     const bool wide = m == BWT_MAX_LEN;
     const uint64_t loff = kt_level_off(m > KT_MIN ? m : KT_MIN);
-    const bool usesum = !wide && m >= KT_MIN && ix.ktsum != nullptr && ((ix.ktsum_levels >> m) & 1u);   // check the summary bit before the 8-byte entry
+    const bool usesum = SUM && !wide && m >= KT_MIN && ix.ktsum != nullptr && ((ix.ktsum_levels >> m) & 1u);   // check the summary bit before the 8-byte entry
     const uint32_t shsk = BWT_MIN_LEN * slot;
     const int hi_l = (int)(((seg0 + maxT - 1) & 63u) << 2), lo_l = (int)(((seg0 - 1) & 63u) << 2);
     const SortMasks SM = sort_masks();
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         // behind it still in flight)
         const uint64_t nidx = loff + key;
         uint32_t sword = 0xffffffffu;
-        if (act2 && usesum) sword = ix.ktsum[nidx >> 11];
+        if (SUM && act2 && usesum) sword = ix.ktsum[nidx >> 11];
         // lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
         const uint32_t aw = act2 && wide ? 1u : 0u;
         { const uint32_t kt = quad_bcast<0>(key); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
@@ -1181,8 +1182,10 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         // summary bit clear: the entry is a plain "too many seeds" one -- known without its table line.  (The load stays a bare
         // conditional load: giving nent a value on the other path would merge right behind the load, i.e. wait for it here.)
-        nplain_c = act2 && !wide && !((sword >> ((nidx >> 6) & 31u)) & 1u);
-        if (act2 && !wide && !nplain_c) nent = ix.ktab[nidx];
+        if (SUM) {
+            nplain_c = act2 && !wide && !((sword >> ((nidx >> 6) & 31u)) & 1u);
+            if (act2 && !wide && !nplain_c) nent = ix.ktab[nidx];
+        } else if (act2 && !wide) nent = ix.ktab[nidx];
     };
     uint4 wa, wb;
     planes_raw(wave, wa, wb);
@@ -1207,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         uint4 own = stag[lane * SF_SLOT];
         if (!wide) {
             // (a plain too-many-seeds entry of level m: n = m steps, width MAX_RANGE + 1)
-            const unsigned long long ne = nplain_c ? (((unsigned long long)(uint32_t)m << 60) | ((unsigned long long)(BWT_MAX_RANGE + 1u) << 32) | 1ull) : nent;
+            const unsigned long long ne = SUM && nplain_c ? (((unsigned long long)(uint32_t)m << 60) | ((unsigned long long)(BWT_MAX_RANGE + 1u) << 32) | 1ull) : nent;
             own.x = act ? (uint32_t)ne : 0u; own.y = act ? (uint32_t)(ne >> 32) : 0u;
         }
         if (!act) own.y = 0;

@@ -21,7 +21,7 @@ short = {"k_search": "k_search", "void k_search<1>": "k_search", "void k_search<
          "k_cluster_small": "k_cluster_small", "k_subreads": "k_subreads", "k_read_planes": "k_read_planes",
          "k_candidates": "k_candidates", "k_cluster_big": "k_cluster_big", "k_read_counts": "k_read_counts",
          "k_hits_write": "k_hits_write", "void k_seed_tasks<false, true>": "k_seed_tasks", "void k_seed_tasks<false, false>": "k_seed_tasks",
-         "void k_seed_tasks<true, false>": "k_seed_tasks", "k_search_pending": "k_search_pending", "k_seed_fast": "k_seed_fast", "void k_seed_fast<false>": "k_seed_fast", "void k_seed_fast<true>": "k_seed_fast", "void k_seed_fast<false, false>": "k_seed_fast", "void k_seed_fast<true, false>": "k_seed_fast", "void k_seed_fast<true, true>": "k_seed_fast_list", "void k_sw_band<24>": "k_sw_band", "void k_sw_band<20>": "k_sw_band", "void k_sw_band<32>": "k_sw_band_wide", "void k_sw_prefilter<true>": "k_sw_prefilter", "void k_sw_prefilter<false>": "k_sw_prefilter", "k_collect_small": "k_collect_small", "k_sw_wave": "k_sw_wave"}
+         "void k_seed_tasks<true, false>": "k_seed_tasks", "k_search_pending": "k_search_pending", "k_seed_fast": "k_seed_fast", "void k_seed_fast<false>": "k_seed_fast", "void k_seed_fast<true>": "k_seed_fast", "void k_seed_fast<false, false>": "k_seed_fast", "void k_seed_fast<false, true>": "k_seed_fast", "void k_seed_fast<true, false>": "k_seed_fast", "void k_seed_fast<true, true>": "k_seed_fast_list", "void k_sw_band<24>": "k_sw_band", "void k_sw_band<20>": "k_sw_band", "void k_sw_band<32>": "k_sw_band_wide", "void k_sw_prefilter<true>": "k_sw_prefilter", "void k_sw_prefilter<false>": "k_sw_prefilter", "k_collect_small": "k_collect_small", "k_sw_wave": "k_sw_wave"}
 per = collections.defaultdict(dict)
 rows = []
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
