@@ -17,6 +17,23 @@ static thread_local std::string g_err;
 extern "C" const char *bwt_last_error(void) { return g_err.c_str(); }
 int bwt_fail(int code, const std::string &msg) { g_err = msg; return code; }
 
+extern "C" void bwt_options_init(bwt_options *o) {
+    if (!o) return;
+    memset(o, 0xff, sizeof *o);                       // every field -1: the library's own choice
+    o->struct_size = (uint32_t)sizeof *o;
+}
+static int options_copy(bwt_options &dst, const bwt_options *src, const char *who) {
+    if (!src) return fail(BWT_EINVAL, std::string(who) + ": null argument");
+    if (src->struct_size != sizeof(bwt_options)) return fail(BWT_EINVAL, std::string(who) + ": bwt_options.struct_size does not match this library (call bwt_options_init)");
+    dst = *src;
+    return 0;
+}
+extern "C" int bwt_index_set_options(bwt_index *ix, const bwt_options *o) {
+    if (!ix) return fail(BWT_EINVAL, "bwt_index_set_options: null index");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    return options_copy(ix->opt, o, "bwt_index_set_options");
+}
+
 extern "C" void bwt_constants(bwt_constants_t *o) {
     o->tolerance = BWT_TOLERANCE; o->min_len = BWT_MIN_LEN; o->max_range = BWT_MAX_RANGE; o->max_len = BWT_MAX_LEN;
     o->match = 2; o->mismatch = -1; o->gap_penalty = -2; o->gap_ext_penalty = -1; o->unknown = 1.6;
@@ -49,18 +66,17 @@ int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream) {
 }
 
 // Suffix-interval table (kernels.hip.h: kt_build), levels 8..K.  K = 0 drops it; K < 0 picks the default: the
-// environment's BWT_KTAB if set, else the K in 8..15 with 4^K closest above the row count (deeper levels would mostly
+// K in 8..15 with 4^K closest above the row count (deeper levels would mostly
 // repeat "not found") -- raised to 15 = MAX_LEN, where the table answers every task, once that K is >= 13 (more than
 // 16.7 M rows) and the 11.5 GB leave >= 32 GB of HBM free.  GRCh38: K = 15.
 // wide: the top level as 64-byte entries that carry the first 14 SA values of the range (a task that ends there needs
 // no SA read, and the seed kernel clusters such reads itself); only useful at K = 15, where every full-length task
-// ends.  < 0: env BWT_KTAB_WIDE if set, else on when K = 15 and the 64 * 4^15 = 68.7 GB leave >= 32 GB of HBM free.
-extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
+// ends.  < 0: on when K = 15 and the 64 * 4^15 = 68.7 GB leave >= 32 GB of HBM free.
+extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) { return bwt_index_set_ktable_ex(ix, K, wide, 1); }
+extern "C" int bwt_index_set_ktable_ex(bwt_index *ix, int K, int wide, int summary) {
     if (!ix) return fail(BWT_EINVAL, "bwt_index_set_ktable: null index");
     if (K < 0) {
-        const char *env = getenv("BWT_KTAB");
-        if (env && *env) K = atoi(env);
-        else {
+        {
             K = KT_MIN;
             while (K < BWT_MAX_LEN && (1ull << (2 * K)) < (uint64_t)ix->Last) K++;
             size_t free_b = 0, total_b = 0;
@@ -78,9 +94,7 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
     if (K == 0) return 0;
     const uint64_t wide_bytes = 64ull << (2 * K);
     if (wide < 0) {
-        const char *env = getenv("BWT_KTAB_WIDE");
-        if (env && *env) wide = atoi(env) != 0;
-        else {
+        {
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
             wide = K == BWT_MAX_LEN && free_b >= wide_bytes + (32ull << 30);
@@ -104,9 +118,8 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
     // Summary of the 8-byte levels (one bit per 64 entries: "not all plain too-many-seeds entries"): on a large genome every
     // 12-mer occurs far more than MAX_RANGE times, and the lookup of a read's short last sub-read is answered by a cached
     // bit instead of a random table line.  Used per level only where fewer than a quarter of the bits are set.
-    const char *env_sum = getenv("BWT_KTAB_SUMMARY");             // experiments / tests: 0 = no summary
     const int top8 = wide ? K - 1 : K;                            // highest level kept as 8-byte entries
-    if (top8 >= KT_MIN && !(env_sum && env_sum[0] == '0')) {
+    if (top8 >= KT_MIN && summary != 0) {
         const uint64_t words = (kt_level_off(top8 + 1) >> 11) + 2;
         if ((rc = ix->ktsum.exact(words * 4 + 64 * 4))) return rc;
         HIPCHK(hipMemsetAsync(ix->ktsum.p, 0, words * 4 + 64 * 4, ix->stream));
@@ -123,7 +136,7 @@ extern "C" int bwt_index_set_ktable(bwt_index *ix, int K, int wide) {
         HIPCHK(hipGetLastError());
         uint32_t levels = 0;
         for (int m = KT_MIN; m <= top8; m++)
-            if ((uint64_t)hset[m] * 4 < ((1ull << (2 * m)) >> 6) || (env_sum && env_sum[0] == '2')) levels |= 1u << m;    // (2: every level, for tests)
+            if ((uint64_t)hset[m] * 4 < ((1ull << (2 * m)) >> 6) || summary == 2) levels |= 1u << m;    // (2: every level, for tests)
         if (levels) { ix->d.ktsum = ix->ktsum.as<uint32_t>(); ix->d.ktsum_levels = levels; }
         else ix->ktsum.release();
     }
@@ -319,6 +332,8 @@ struct KernelStat { double ms = 0; uint64_t launches = 0; };
 
 struct bwt_batch {
     bwt_index *ix = nullptr;         // may be null for the index-free SW entry point
+    bwt_options opt;                 // execution options (bwt_batch_set_options; a new batch takes its index's)
+    bwt_batch() { bwt_options_init(&opt); }
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -329,6 +344,10 @@ struct bwt_batch {
     uint32_t n = 0, maxT = 0, max_lq = 0;
     uint64_t total_bases = 0;
     DevBuf bases, off, rplanes;
+    DevBuf pk_codes, pk_exc;           // packed upload staging (bwt_batch_set_reads_packed)
+    uint64_t pk_nexc = 0;
+    bool planes_valid = false;         // rplanes already hold this batch's planes (packed upload): the search stage skips k_read_planes
+    bool ascii_valid = true;           // `bases` holds every read's bytes (false after a packed upload: only the exceptions' bytes)
     // tasks
     DevBuf t_def, t_sp, t_ep, t_info, t_cnt, r_pend, r_cl, smallq;
     bool counts_done = false;          // the search stage already totalled the reads (k_seed_tasks)
@@ -353,7 +372,10 @@ struct bwt_batch {
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
+    uint64_t n_extra = 0, xcig_bytes = 0;
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig, pairs;
+    DevBuf r_nx, r_xcb, x_off, xcb_off, x_rec, x_cig, h_xidx, h_len;    // compact table: extras of the hits that are not plain
+    bool expanded = false;             // h_woff / h_wlen / h_cigoff / h_cig hold the expansion of the current compact table
     // counters
     DevBuf ctr;
     Counters hctr{};
@@ -421,22 +443,24 @@ static int dev_scan(bwt_batch *b, const uint32_t *in, uint64_t *out, uint64_t n)
     return 0;
 }
 
-// two scans of the same length (the hit and CIGAR-byte offsets of a batch): one set of launches
-static int dev_scan_pair(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, uint64_t n) {
+// three scans of the same length (the hit, extra and CIGAR-byte offsets of a batch): one set of launches
+static int dev_scan3(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
+                     uint64_t *out2, uint64_t n) {
     if (n <= SCAN_TILE) {
         int rc = dev_scan(b, in0, out0, n);
-        return rc ? rc : dev_scan(b, in1, out1, n);
+        if (!rc) rc = dev_scan(b, in1, out1, n);
+        return rc ? rc : dev_scan(b, in2, out2, n);
     }
     const uint32_t nb = std::max<uint32_t>(1, cdiv(n, SCAN_TILE));
-    int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8 * 2);
+    int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8 * 3);
     if (rc) return rc;
     ScanPair p;
-    p.in[0] = in0; p.in[1] = in1; p.out[0] = out0; p.out[1] = out1;
-    p.bsum[0] = b->scan_tmp.as<uint64_t>(); p.bsum[1] = p.bsum[0] + nb + 1;
+    p.in[0] = in0; p.in[1] = in1; p.in[2] = in2; p.out[0] = out0; p.out[1] = out1; p.out[2] = out2;
+    p.bsum[0] = b->scan_tmp.as<uint64_t>(); p.bsum[1] = p.bsum[0] + nb + 1; p.bsum[2] = p.bsum[1] + nb + 1;
     ProfScope ps(b, "scan");
-    hipLaunchKernelGGL(k_scan1_pair, dim3(nb, 2), dim3(SCAN_BLOCK), 0, b->stream, p, n);
-    hipLaunchKernelGGL(k_scan2_pair, dim3(1, 2), dim3(SCAN_BLOCK), 0, b->stream, p, nb);
-    hipLaunchKernelGGL(k_scan3_pair, dim3(nb, 2), dim3(SCAN_BLOCK), 0, b->stream, p, n, nb);
+    hipLaunchKernelGGL(k_scan1_pair, dim3(nb, 3), dim3(SCAN_BLOCK), 0, b->stream, p, n);
+    hipLaunchKernelGGL(k_scan2_pair, dim3(1, 3), dim3(SCAN_BLOCK), 0, b->stream, p, nb);
+    hipLaunchKernelGGL(k_scan3_pair, dim3(nb, 3), dim3(SCAN_BLOCK), 0, b->stream, p, n, nb);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -446,6 +470,7 @@ extern "C" int bwt_batch_create(bwt_index *ix, bwt_batch **out) {
     HIPCHK(hipSetDevice(ix->device));
     bwt_batch *b = new bwt_batch();
     b->ix = ix; b->device = ix->device;
+    { std::shared_lock<std::shared_mutex> lk(ix->mu); b->opt = ix->opt; }
     // its own stream: batches of different host threads on one index do not serialise (or free each other's buffers)
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete b; return fail(BWT_EHIP, "hipStreamCreate failed"); }
@@ -472,13 +497,18 @@ static int batch_create_noindex(int device, bwt_batch **out) {
     return 0;
 }
 
+extern "C" int bwt_batch_set_options(bwt_batch *b, const bwt_options *o) {
+    if (!b) return fail(BWT_EINVAL, "bwt_batch_set_options: null batch");
+    return options_copy(b->opt, o, "bwt_batch_set_options");
+}
+
 extern "C" void bwt_batch_destroy(bwt_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
     prof_collect(b);
     for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
-    DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
+    DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->pk_codes, &b->pk_exc, &b->r_nx, &b->r_xcb, &b->x_off, &b->xcb_off, &b->x_rec, &b->x_cig, &b->h_xidx, &b->h_len, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
@@ -568,8 +598,96 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
     b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
     b->ulen = (n && minlq == maxlq) ? maxlq : 0;       // every read the same length: offsets are r * ulen (no offset load in the seed kernel)
     b->total_bases = total;
+    b->planes_valid = false; b->ascii_valid = true;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Packed upload (include/bwt_gpu.h): 2 bits per base + an exception list up, the planes made on the device.
+extern "C" uint64_t bwt_packed_words(uint64_t total_bases) { return 2 * ((total_bases + 31) / 32) + 2; }
+
+extern "C" int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, uint64_t total, uint32_t n, uint32_t read_len,
+                                          const uint64_t *off, const uint64_t *exc, uint64_t n_exc) {
+    if (!b || (!codes && total) || (!exc && n_exc)) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: null argument");
+    if (!read_len && !off) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: offsets are needed when the reads differ in length");
+    if (read_len > 65535) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: read longer than 65535 bases");
+    if (read_len && (uint64_t)n * read_len != total) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: total_bases must be n * read_len");
+    if (!read_len && (off[0] != 0 || off[n] != total)) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: off[0] must be 0 and off[n] the number of bases");
+    if (total >> 56) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: too many bases");
+    HIPCHK(hipSetDevice(b->device));
+    const uint64_t nwords = (total + 31) / 32;
+    int rc;
+    if ((rc = b->bases.ensure(nwords * 32 + 16)) || (rc = b->off.ensure(((size_t)n + 1) * 8)) || (rc = b->scan_tmp.ensure(64)) ||
+        (rc = b->pk_codes.ensure(nwords * 8 + 16)) || (rc = b->pk_exc.ensure(n_exc * 8 + 16)) ||
+        (rc = b->rplanes.ensure(rp_words(total) * 4)))
+        return rc;
+    b->n = 0; b->done = 0; b->n_cand = 0; b->n_hits = 0; b->cig_bytes = 0; b->n_extra = 0; b->xcig_bytes = 0;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+    if (nwords) HIPCHK(hipMemcpyAsync(b->pk_codes.p, codes, nwords * 8, hipMemcpyHostToDevice, b->stream));
+    if (n_exc) HIPCHK(hipMemcpyAsync(b->pk_exc.p, exc, n_exc * 8, hipMemcpyHostToDevice, b->stream));
+    unsigned int chk[4] = {0xffffffffu, 0u, 0u, 0u};           // {min length, max length, offset flags, exception flags}
+    unsigned int *dchk = b->scan_tmp.as<unsigned int>();
+    HIPCHK(hipMemcpyAsync(dchk, chk, sizeof chk, hipMemcpyHostToDevice, b->stream));
+    if (read_len) {
+        if (n) hipLaunchKernelGGL(k_off_uniform, dim3(std::min<uint32_t>(cdiv((uint64_t)n + 1, 256), (uint32_t)cus * 8)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, read_len);
+        else HIPCHK(hipMemsetAsync(b->off.p, 0, 8, b->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(b->off.p, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+        if (n) hipLaunchKernelGGL(k_off_check, dim3(std::min<uint32_t>(cdiv(n, 256), 1024)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, dchk);
+    }
+    {
+        ProfScope ps(b, "unpack_reads");
+        const uint64_t words = rp_words(total), used = nwords * 4;
+        HIPCHK(hipMemsetAsync(b->rplanes.as<uint32_t>() + used, 0, (words - used) * 4, b->stream));
+        // the ASCII copy is only made where something reads bytes: here for the whole batch when no prefilter will run in front of
+        // the DP kernels (it lists the candidates that reach them: stage_extend makes those reads' bytes then)
+        const bool all_ascii = b->opt.sw_prefilter == 0;
+        if (nwords)
+            hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), (uint64_t)cus * 16)), dim3(256), 0, b->stream,
+                               (const uint2 *)b->pk_codes.as<uint2>(), nwords, total, b->rplanes.as<uint32_t>(), all_ascii ? b->bases.as<uint8_t>() : (uint8_t *)nullptr);
+        if (n_exc)
+            hipLaunchKernelGGL(k_unpack_exc, dim3((uint32_t)std::min<uint64_t>(cdiv(n_exc, 256), (uint64_t)cus * 8)), dim3(256), 0, b->stream,
+                               (const uint64_t *)b->pk_exc.as<uint64_t>(), n_exc, total, b->rplanes.as<uint32_t>(), b->bases.as<uint8_t>(), dchk + 3);
+        b->ascii_valid = all_ascii;
+    }
+    HIPCHK(hipMemcpyAsync(chk, dchk, sizeof chk, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    if (!read_len) {
+        if (chk[2] & 1u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: offsets must be non-decreasing");
+        if (chk[2] & 2u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: read longer than 65535 bases");
+    }
+    if (chk[3] & 1u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: exception position behind the last base");
+    if (chk[3] & 2u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: an exception byte is one of ACGT");
+    const uint32_t maxlq = !n ? 0 : read_len ? read_len : chk[1], minlq = !n ? 0 : read_len ? read_len : chk[0];
+    b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
+    b->ulen = (n && minlq == maxlq) ? maxlq : 0;
+    b->total_bases = total;
+    b->planes_valid = true; b->pk_nexc = n_exc;
+    return 0;
+}
+
+// every read's bytes out of the codes (a packed batch that meets a stage which reads whole reads as bytes)
+static int ascii_all(bwt_batch *b) {
+    if (b->ascii_valid) return 0;
+    const uint64_t nwords = (b->total_bases + 31) / 32;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+    ProfScope ps(b, "unpack_reads");
+    if (nwords)
+        hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), (uint64_t)cus * 16)), dim3(256), 0, b->stream,
+                           (const uint2 *)b->pk_codes.as<uint2>(), nwords, b->total_bases, (uint32_t *)nullptr, b->bases.as<uint8_t>());
+    if (b->pk_nexc)            // the exceptions' bytes over the code bytes (their plane bits are set already; setting them again changes nothing)
+        hipLaunchKernelGGL(k_unpack_exc, dim3((uint32_t)std::min<uint64_t>(cdiv(b->pk_nexc, 256), (uint64_t)cus * 8)), dim3(256), 0, b->stream,
+                           (const uint64_t *)b->pk_exc.as<uint64_t>(), b->pk_nexc, b->total_bases, b->rplanes.as<uint32_t>(), b->bases.as<uint8_t>(),
+                           b->scan_tmp.as<unsigned int>() + 3);
+    HIPCHK(hipGetLastError());
+    b->ascii_valid = true;
+    return 0;
+}
+
+static int ensure_expanded(bwt_batch *b);
 
 // ------------------------------------------------------------------------------------------------
 // Reverse strand and pairing: what the reference does not have (src/fastq.erl:43-50 is an unused helper).
@@ -667,7 +785,7 @@ extern "C" int bwt_batch_pair_hits(bwt_batch *b, uint32_t n_pairs, int32_t min_i
     if (!n_pairs) return 0;
     HIPCHK(hipSetDevice(b->device));
     int rc;
-    if ((rc = b->pairs.ensure((size_t)n_pairs * sizeof(PairRec)))) return rc;
+    if ((rc = ensure_expanded(b)) || (rc = b->pairs.ensure((size_t)n_pairs * sizeof(PairRec)))) return rc;
     hipLaunchKernelGGL(k_pair_hits, dim3(std::min<uint32_t>(cdiv(n_pairs, 256), 4096)), dim3(256), 0, b->stream, n_pairs, b->n / 2,
                        b->hit_off.as<uint64_t>(), b->h_rec.as<HitRec>(), b->h_cigoff.as<uint64_t>(), b->h_cig.as<uint8_t>(), min_insert,
                        max_insert, b->pairs.as<PairRec>());
@@ -689,6 +807,7 @@ static uint32_t search_grid(bwt_batch *b, uint64_t n_tasks, bool u2 = true) {
 
 // reads -> bit-planes over the concatenated byte stream (k_read_planes); part of every search pass
 static int read_planes(bwt_batch *b) {
+    if (b->planes_valid) return 0;                          // a packed upload made them (k_unpack_reads)
     int rc = b->rplanes.ensure(rp_words(b->total_bases) * 4);
     if (rc) return rc;
     ProfScope ps(b, "read_planes");
@@ -722,8 +841,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
                   b->r_pend.as<unsigned long long>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->bigq.as<uint32_t>(),       \
                   b->mid2q.as<uint32_t>(), b->mid4q.as<uint32_t>()
         // with SA values in the table's top level (and 8..64 sub-reads per read) the seed kernel clusters what it can itself
-        const char *env_f = getenv("BWT_SEED_FUSE");
-        const bool fuse = !raw && b->ix->d.ktw && maxT >= 8 && !(env_f && env_f[0] == '0');
+        const bool fuse = !raw && b->ix->d.ktw && maxT >= 8 && b->opt.seed_fuse != 0;
         if (fuse) {
             if ((rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->r_cl.ensure((size_t)n * 8 * CL_STAGE + 16))) return rc;
             HIPCHK(hipMemsetAsync(b->r_K.p, 0, (size_t)n * 4, b->stream));      // k_cluster_small only runs if reads are left for it
@@ -743,8 +861,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         // Batches of one read length with the full-depth wide table: k_seed_fast takes the ordinary groups of reads and hands
         // the others back as a list for k_seed_tasks (results are k_seed_tasks' either way).  Up to 21 sub-reads per read (three
         // reads per wave pass), up to 128 seeds per read.
-        const char *env_fast = getenv("BWT_SEED_FAST");             // experiments / tests: 0 = general kernel only
-        const bool fast = fuse && lean && b->ulen && b->ix->d.kt_k == BWT_MAX_LEN && maxT <= 21 && !(env_fast && env_fast[0] == '0');
+        const bool fast = fuse && lean && b->ulen && b->ix->d.kt_k == BWT_MAX_LEN && maxT <= 21 && b->opt.seed_fast != 0;
         const uint32_t *nolist = nullptr;
         const unsigned int *nocount = nullptr;
         if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u, nolist, nocount);
@@ -752,8 +869,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
             if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
             {
                 // reads of up to 14 sub-reads rarely pass 64 seeds: the one-register variant runs a wave more per SIMD
-                const char *env_big = getenv("BWT_SEED_BIG");           // experiments: 0 / 1 force the variant
-                const bool big = env_big ? env_big[0] == '1' : maxT > 14;
+                const bool big = b->opt.seed_big >= 0 ? b->opt.seed_big == 1 : maxT > 14;
                 const size_t lds = sf_lds_bytes(maxT, big);
                 // the summary bit is looked at only when the index has one for the level of this batch's short last sub-read
                 const int mn = (int)(b->ulen % BWT_MIN_LEN) + BWT_MIN_LEN;
@@ -795,8 +911,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         if (!raw)
             KLAUNCH(b, "subreads", k_subreads, cdiv(n, 256), 256, b->rplanes.as<uint32_t>(), b->off.as<uint64_t>(), n, maxT,
                     b->t_def.as<uint32_t>());
-        const char *env_u = getenv("BWT_SEARCH_ILP");         // experiments: tasks advanced together per quad (1 or 2)
-        const bool u2 = env_u && env_u[0] == '2';                   // measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
+        const bool u2 = b->opt.search_ilp == 2;                     // tasks advanced together per quad; measured: 2 is no faster (36.1 vs 37.2 ms): VALU-bound
         KLAUNCH(b, "fm_search", (u2 ? k_search<2> : k_search<1>), search_grid(b, T, u2), 256, b->ix->d, b->rplanes.as<uint32_t>(),
                 b->off.as<uint64_t>(), T, maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_ep.as<uint32_t>(),
                 b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(), b->ctr.as<Counters>());
@@ -954,8 +1069,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
     io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.wave_upto = 0;
-    const char *env_pf = getenv("BWT_SW_PREFILTER");     // experiments: 0 disables the exact-match prefilter
-    if (qplanes && wplanes && !(env_pf && env_pf[0] == '0')) {
+    if (qplanes && wplanes && b->opt.sw_prefilter != 0) {
         io.dq = b->dq.as<uint32_t>();
         CandSrc src{};
         if (b->cand_pending) {
@@ -969,7 +1083,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
                 int per_cu = 5;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sw_prefilter<true>, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 5; }
                 b->occ_prefilter = std::max(1, std::min(per_cu, 8));
-                if (const char *e = getenv("BWT_PF_BLOCKS_PER_CU")) b->occ_prefilter = std::max(1, std::min(atoi(e), b->occ_prefilter));   // experiments
+                if (b->opt.pf_blocks_per_cu > 0) b->occ_prefilter = std::max(1, std::min((int)b->opt.pf_blocks_per_cu, b->occ_prefilter));   // experiments
             }
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, (uint32_t)std::min<uint64_t>(cdiv((uint64_t)b->n * 4, 256), (uint64_t)dev_cus * b->occ_prefilter), 256, io, b->n, src);
             b->cand_pending = false;
@@ -978,23 +1092,33 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         } else
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc, src);   // quad per candidate
     }
+    if (!b->ascii_valid) {
+        // a packed batch keeps no ASCII copy of its reads: the DP kernels that read bytes get those of the candidates the prefilter
+        // queued (fp64 queue, DP queue) -- or of every read when no prefilter ran
+        if (!io.dq) { if ((rc = ascii_all(b))) return rc; }
+        else {
+            ProfScope ps(b, "ascii_reads");
+            Counters *dc = b->ctr.as<Counters>();
+            hipLaunchKernelGGL(k_ascii_reads, dim3((uint32_t)dev_cus * 4), dim3(256), 0, b->stream, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
+                               (const uint64_t *)io.c_qoff, (const uint32_t *)io.c_qlen, qplanes, b->bases.as<uint8_t>());
+            hipLaunchKernelGGL(k_ascii_reads, dim3((uint32_t)dev_cus), dim3(256), 0, b->stream, (const uint32_t *)io.fpq, (const unsigned int *)&dc->fp_count,
+                               (const uint64_t *)io.c_qoff, (const uint32_t *)io.c_qlen, qplanes, b->bases.as<uint8_t>());
+        }
+    }
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
 
     // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
     // lane-per-alignment work would run a handful of waves for the full serial length of a DP
-    const char *env_wv = getenv("BWT_SW_WAVE");                   // experiments / tests: 0 = lane-per-alignment kernels only (read per call)
     const uint32_t wv_dwords = (max_w >> 4) + 1, wv_w1 = max_w + 1;
     const uint64_t wv_lds = ((uint64_t)wv_w1 + (uint64_t)max_lq * wv_dwords) * 4 * 4;            // 4 waves per block
-    const uint32_t wv_thresh = (io.dq && wv_lds <= 60 * 1024 && !(env_wv && env_wv[0] == '0')) ? 32768u : 0u;
+    const uint32_t wv_thresh = (io.dq && wv_lds <= 60 * 1024 && b->opt.sw_wave != 0) ? 32768u : 0u;
     io.wave_upto = wv_thresh;
     b->wave_upto = wv_thresh;
     // the DP queue first goes through the banded kernel: what its certificate covers is settled there (traceback included),
     // the rest -- candidates far from any clean alignment, wide clusters -- moves on in a second queue that takes dq's place
-    const char *env_band = getenv("BWT_SW_BAND");                 // experiments / tests: 0 = full-rectangle kernels only (read per call)
     b->band_ran = false;
-    const char *env_bm = getenv("BWT_SW_BAND_MIN");               // tests: queues up to this size are left to k_sw_wave (default 16384)
-    const uint32_t band_min = std::min<uint32_t>(wv_thresh, env_bm ? (uint32_t)atoi(env_bm) : 16384u);
-    if (io.dq && max_lq >= 2 && max_lq <= SWB_MAX_LQ && !(env_band && env_band[0] == '0')) {
+    const uint32_t band_min = std::min<uint32_t>(wv_thresh, b->opt.sw_band_min >= 0 ? (uint32_t)b->opt.sw_band_min : 16384u);   // queues up to this size are left to k_sw_wave
+    if (io.dq && max_lq >= 2 && max_lq <= SWB_MAX_LQ && b->opt.sw_band != 0) {
         const uint32_t rows = max_lq + 1;
         // resident grids: 4 (3 for the wide tier) waves per SIMD; the direction slab (rows x up to 1 KiB per wave) stays under 1 GiB
         const uint64_t cap_blocks = (1ull << 30) / ((uint64_t)4 * rows * 4 * 64 * 4);
@@ -1026,13 +1150,12 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and
     // non-diagonal alignments go on to the trace pass.  LDS per wave: planes + (wcap+1) x 128 B.
     const bool fits16 = 4ull * (2ull * max_lq + max_w + 4) < 32000ull;
-    const char *env_lds = getenv("BWT_SW_LDS");          // experiments: 0 forces the HBM boundary slab
+    const bool lds_off = b->opt.sw_lds == 0;             // experiments: the HBM boundary slab instead of LDS
     const uint32_t wcap = std::min<uint32_t>(max_w, 254), lqcap = std::min<uint32_t>(max_lq, 254);
     const uint32_t pwords = 2 * ((wcap + 31) / 32) + 2 * ((lqcap + 31) / 32);
     const uint64_t lds_wave = ((uint64_t)pwords * 64 + ((uint64_t)(wcap + 1) * 64 + 1) / 2) * 4;
     const uint64_t lds_bytes = lds_wave * 4;
-    const char *env_pk = getenv("BWT_SW_PK");            // experiments: 0 disables the packed-i16 kernels
-    const bool pk_ok = (max_lq == 100 || max_lq == 150) && !(env_pk && env_pk[0] == '0') && !(env_lds && env_lds[0] == '0');
+    const bool pk_ok = (max_lq == 100 || max_lq == 150) && b->opt.sw_pk != 0 && !lds_off;
     if (pk_ok) {
         // two alignments per lane, whole query column in registers; LDS holds only the bit-planes
         const uint32_t qw = (max_lq + 31) / 32;
@@ -1042,8 +1165,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         // After the prefilter the DP queue holds hardly any plain diagonal (those with <= 2 mismatches in a square window are
         // gone): a score-only pass would hand most of it on to the traced pass anyway (measured, 150 bp reads with indels:
         // 14.7 + 17.6 ms against 26.8 ms for tracing everything), so the traced DP runs on the DP queue directly.
-        const char *env_ta = getenv("BWT_SW_TRACE_ALL");     // experiments: 0 = score pass first
-        const bool trace_all = io.dq && !(env_ta && env_ta[0] == '0');
+        const bool trace_all = io.dq && b->opt.sw_trace_all != 0;     // 0 = score pass first
         if (trace_all) {
             io.tq2 = io.dq;
             HIPCHK(hipMemcpyAsync(&b->ctr.as<Counters>()->tq2_count, &b->ctr.as<Counters>()->dq_count, 4, hipMemcpyDeviceToDevice, b->stream));
@@ -1070,18 +1192,16 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
                 hipLaunchKernelGGL((k_sw_pk<150, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
                                    b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
         }
-    } else if (fits16 && lds_bytes <= 160 * 1024 && !(env_lds && env_lds[0] == '0')) {
-        const char *env_bpc = getenv("BWT_SW_BLOCKS_PER_CU");
+    } else if (fits16 && lds_bytes <= 160 * 1024 && !lds_off) {
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
-        if (env_bpc) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(env_bpc));
+        if (b->opt.sw_blocks_per_cu > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)b->opt.sw_blocks_per_cu);
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * per_cu);
         if (lds_bytes > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)k_sw_score, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         ProfScope ps(b, "sw_extend");
         hipLaunchKernelGGL(k_sw_score, dim3(blocks), dim3(256), (size_t)lds_bytes, b->stream, io, (uint32_t)nc, wcap, lqcap);
     } else {
-        const char *env_wpc = getenv("BWT_SW_WAVES_PER_CU");
-        const uint32_t wpc = env_wpc ? (uint32_t)atoi(env_wpc) : 8;
+        const uint32_t wpc = b->opt.sw_waves_per_cu > 0 ? (uint32_t)b->opt.sw_waves_per_cu : 8;
         uint64_t waves = std::min<uint64_t>(cdiv(nc, 64), (uint64_t)dev_cus * wpc);
         waves = std::max<uint64_t>(4, std::min<uint64_t>(waves, (4ull << 30) / ((uint64_t)maxW1 * 256)) / 4 * 4);
         if ((rc = b->slab_bnd.ensure(waves * maxW1 * 64 * 4))) return rc;
@@ -1106,44 +1226,79 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     return 0;
 }
 
+static int dev_scan3(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
+                     uint64_t *out2, uint64_t n);
+
 static int stage_hits(bwt_batch *b, int32_t shift) {
     const uint32_t n = b->n;
     int rc;
-    if ((rc = b->r_nhit.ensure((size_t)n * 4 + 4)) || (rc = b->r_cigb.ensure((size_t)n * 4 + 4)) ||
-        (rc = b->r_status.ensure((size_t)n * 4 + 4)) || (rc = b->hit_off.ensure(((size_t)n + 1) * 8)) ||
-        (rc = b->cigb_off.ensure(((size_t)n + 1) * 8)))
+    b->expanded = false;
+    if ((rc = b->r_nhit.ensure((size_t)n * 4 + 4)) || (rc = b->r_nx.ensure((size_t)n * 4 + 4)) || (rc = b->r_xcb.ensure((size_t)n * 4 + 4)) ||
+        (rc = b->r_status.ensure((size_t)n + 4)) || (rc = b->hit_off.ensure(((size_t)n + 1) * 8)) ||
+        (rc = b->x_off.ensure(((size_t)n + 1) * 8)) || (rc = b->xcb_off.ensure(((size_t)n + 1) * 8)))
         return rc;
     if (n == 0) {                                   // empty batch: empty, but well-formed, hit tables
-        b->n_hits = 0; b->cig_bytes = 0;
-        if ((rc = b->h_rec.ensure(16)) || (rc = b->h_woff.ensure(8)) || (rc = b->h_wlen.ensure(4)) ||
-            (rc = b->h_cigoff.ensure(8)) || (rc = b->h_cig.ensure(16)))
-            return rc;
+        b->n_hits = 0; b->cig_bytes = 0; b->n_extra = 0; b->xcig_bytes = 0;
+        if ((rc = b->h_rec.ensure(16)) || (rc = b->x_rec.ensure(16)) || (rc = b->x_cig.ensure(16))) return rc;
         HIPCHK(hipMemsetAsync(b->hit_off.p, 0, 8, b->stream));
-        HIPCHK(hipMemsetAsync(b->h_cigoff.p, 0, 8, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         return 0;
     }
+    HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->cig_total, 0, 8, b->stream));     // (a retry with wider CIGAR slots counts again)
     KLAUNCH(b, "hits_count", k_hits_count, cdiv(n, 256), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
-            b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_cigb.as<uint32_t>(),
-            b->r_status.as<int32_t>(), b->ctr.as<Counters>());
-    if ((rc = dev_scan_pair(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), b->r_cigb.as<uint32_t>(), b->cigb_off.as<uint64_t>(), n))) return rc;
+            b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_nx.as<uint32_t>(), b->r_xcb.as<uint32_t>(),
+            b->r_status.as<int8_t>(), b->ctr.as<Counters>());
+    if ((rc = dev_scan3(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), b->r_nx.as<uint32_t>(), b->x_off.as<uint64_t>(),
+                        b->r_xcb.as<uint32_t>(), b->xcb_off.as<uint64_t>(), n)))
+        return rc;
     // the hit tables are sized by their bounds (a hit per candidate, a full text slot per hit), so that nothing has to come
     // back to the host before k_hits_write: the totals are read once, together with the counters, when everything is queued
     const size_t nh = (size_t)b->n_cand + 1;
-    if ((rc = b->h_rec.ensure(nh * 16)) || (rc = b->h_woff.ensure(nh * 8)) || (rc = b->h_wlen.ensure(nh * 4)) ||
-        (rc = b->h_cigoff.ensure(nh * 8)) || (rc = b->h_cig.ensure((size_t)b->n_cand * b->cig_stride + 16)))
+    if ((rc = b->h_rec.ensure(nh * 16)) || (rc = b->x_rec.ensure(nh * 16)) || (rc = b->x_cig.ensure((size_t)b->n_cand * b->cig_stride + 16)))
         return rc;
     KLAUNCH(b, "hits_write", k_hits_write, cdiv(n, 256), 256, n, shift, b->clus_off.as<uint64_t>(),
-            b->hit_off.as<uint64_t>(), b->cigb_off.as<uint64_t>(), b->r_status.as<int32_t>(), b->c_status.as<int32_t>(),
+            b->hit_off.as<uint64_t>(), b->x_off.as<uint64_t>(), b->xcb_off.as<uint64_t>(), b->r_status.as<int8_t>(), b->c_status.as<int32_t>(),
             b->c_score.as<int32_t>(), b->c_ciglen.as<uint32_t>(), b->c_S.as<uint32_t>(), b->c_wlen.as<uint32_t>(),
-            b->c_woff.as<int64_t>(), b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->h_woff.as<int64_t>(),
-            b->h_wlen.as<int32_t>(), b->h_cigoff.as<uint64_t>(), b->h_cig.as<uint8_t>());
-    uint64_t tot[2] = {0, 0};
+            b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->x_rec.as<HitExtra>(), b->x_cig.as<uint8_t>());
+    uint64_t tot[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(&tot[0], b->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(&tot[1], b->cigb_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(&tot[1], b->x_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(&tot[2], b->xcb_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
     if ((rc = fetch_counters(b))) return rc;                                   // sync
     HIPCHK(hipGetLastError());
-    b->n_hits = tot[0]; b->cig_bytes = tot[1];
+    b->n_hits = tot[0]; b->n_extra = tot[1]; b->xcig_bytes = tot[2]; b->cig_bytes = b->hctr.cig_total;
+    return 0;
+}
+
+// the per-hit arrays of bwt_align_batch out of the compact table (kernels.hip.h: k_hits_expand), once per run, when a caller
+// asks for them
+static int ensure_expanded(bwt_batch *b) {
+    if (b->expanded) return 0;
+    const uint64_t nh = b->n_hits;
+    int rc;
+    if ((rc = b->h_woff.ensure((nh + 1) * 8)) || (rc = b->h_wlen.ensure((nh + 1) * 4)) || (rc = b->h_cigoff.ensure((nh + 2) * 8)) ||
+        (rc = b->h_cig.ensure(b->cig_bytes + 16)) || (rc = b->h_xidx.ensure((nh + 1) * 4)) || (rc = b->h_len.ensure((nh + 1) * 4)))
+        return rc;
+    if (!nh) {
+        HIPCHK(hipMemsetAsync(b->h_cigoff.p, 0, 8, b->stream));
+        b->expanded = true;
+        return 0;
+    }
+    if (nh > 0xfffffff0ull) return fail(BWT_EOVERFLOW, "more than 2^32 hits: split the batch");
+    const int32_t shift = b->ix ? b->ix->shift : 0;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(nh, 256), 8192);
+    HIPCHK(hipMemsetAsync(b->h_xidx.p, 0xff, nh * 4, b->stream));
+    if (b->n_extra)
+        KLAUNCH(b, "hits_expand", k_hits_xidx, (uint32_t)std::min<uint64_t>(cdiv(b->n_extra, 256), 8192), 256, (const HitExtra *)b->x_rec.as<HitExtra>(), b->n_extra,
+                b->h_xidx.as<uint32_t>());
+    KLAUNCH(b, "hits_expand", k_hits_len, grid, 256, nh, (const HitRec *)b->h_rec.as<HitRec>(), (const uint32_t *)b->h_xidx.as<uint32_t>(),
+            (const HitExtra *)b->x_rec.as<HitExtra>(), (const uint64_t *)b->off.as<uint64_t>(), b->ulen, b->h_len.as<uint32_t>());
+    if ((rc = dev_scan(b, b->h_len.as<uint32_t>(), b->h_cigoff.as<uint64_t>(), nh))) return rc;
+    KLAUNCH(b, "hits_expand", k_hits_expand, grid, 256, nh, shift, (const HitRec *)b->h_rec.as<HitRec>(), (const uint32_t *)b->h_xidx.as<uint32_t>(),
+            (const HitExtra *)b->x_rec.as<HitExtra>(), (const uint8_t *)b->x_cig.as<uint8_t>(), (const uint64_t *)b->off.as<uint64_t>(), b->ulen,
+            (const uint64_t *)b->h_cigoff.as<uint64_t>(), b->h_woff.as<int64_t>(), b->h_wlen.as<int32_t>(), b->h_cig.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    b->expanded = true;
     return 0;
 }
 
@@ -1177,8 +1332,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     }
     if (stages & (BWT_STAGE_CLUSTER | BWT_STAGE_EXTEND)) {
         {
-            const char *env_pf = getenv("BWT_SW_PREFILTER"), *env_fc = getenv("BWT_SW_FUSE_CAND");   // experiments: 0 = separate k_candidates
-            const bool to_extend = (stages & BWT_STAGE_EXTEND) && !(env_pf && env_pf[0] == '0') && !(env_fc && env_fc[0] == '0');
+            const bool to_extend = (stages & BWT_STAGE_EXTEND) && b->opt.sw_prefilter != 0 && b->opt.sw_fuse_cand != 0;   // 0 = separate k_candidates
             if ((rc = stage_cluster(b, to_extend))) return rc;
         }
         b->done |= BWT_STAGE_CLUSTER;
@@ -1190,7 +1344,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         b->done |= BWT_STAGE_EXTEND;
     }
     if (!(stages & BWT_STAGE_EXTEND) && (rc = fetch_counters(b))) return rc;     // (the extend stage ends with the counters on the host)
-    if (getenv("BWT_DEBUG_HANDBACK") && b->hctr.n_gq)
+    if (b->opt.debug > 0 && b->hctr.n_gq)
         fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u groups: non-ACGT %u, table overflow %u, >64 seeds in a read %u, >%d clusters %u\n",
                 b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
     if (counts) {
@@ -1264,6 +1418,16 @@ extern "C" int bwt_batch_fetch_clusters(bwt_batch *b, uint64_t *clus_off, int64_
     return 0;
 }
 
+// read_status: one signed byte per read on the device, int32 in the per-hit ABI
+static int fetch_status32(bwt_batch *b, int32_t *read_status) {
+    if (!read_status || !b->n) return 0;
+    std::vector<int8_t> st(b->n);
+    HIPCHK(hipMemcpyAsync(st.data(), b->r_status.p, b->n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t i = 0; i < b->n; i++) read_status[i] = st[i];
+    return 0;
+}
+
 extern "C" int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t *hit_off, int32_t *score, int64_t *pos,
                                     int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t hit_cap,
                                     uint64_t cig_cap, uint64_t needed[2]) {
@@ -1271,9 +1435,10 @@ extern "C" int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t
     HIPCHK(hipSetDevice(b->device));
     if (needed) { needed[0] = b->n_hits; needed[1] = b->cig_bytes; }
     int rc;
-    if ((rc = d2h(b, read_status, b->r_status, b->n)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1))) return rc;
+    if ((rc = fetch_status32(b, read_status)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1))) return rc;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->n_hits > hit_cap || b->cig_bytes > cig_cap) return fail(BWT_ENOSPC, "hit / cigar capacity too small");
+    if ((rc = ensure_expanded(b))) return rc;
     std::vector<HitRec> rec(b->n_hits);
     if ((rc = d2h(b, rec.data(), b->h_rec, b->n_hits)) || (rc = d2h(b, win_off, b->h_woff, b->n_hits)) ||
         (rc = d2h(b, win_len, b->h_wlen, b->n_hits)) || (rc = d2h(b, cig_off, b->h_cigoff, b->n_hits + 1)) ||
@@ -1295,12 +1460,69 @@ extern "C" int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint
     if (cigar && b->cig_bytes > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
     if (!read_status && !hit_off && !hits && !win_off && !win_len && !cig_off && !cigar) return b->n_hits || b->cig_bytes ? BWT_ENOSPC : 0;
     int rc;
-    if ((rc = d2h(b, read_status, b->r_status, b->n)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1)) ||
+    if ((win_off || win_len || cig_off || cigar) && (rc = ensure_expanded(b))) return rc;
+    if ((rc = fetch_status32(b, read_status)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1)) ||
         (rc = d2h(b, (HitRec *)hits, b->h_rec, b->n_hits)) || (rc = d2h(b, win_off, b->h_woff, b->n_hits)) ||
         (rc = d2h(b, win_len, b->h_wlen, b->n_hits)) || (rc = d2h(b, cig_off, b->h_cigoff, b->n_hits + 1)) ||
         (rc = d2h(b, cigar, b->h_cig, b->cig_bytes)))
         return rc;
     HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, bwt_hit_rec *hits, bwt_hit_extra *extra, char *cigar,
+                                            uint64_t hit_cap, uint64_t extra_cap, uint64_t cig_cap, uint64_t needed[3]) {
+    static_assert(sizeof(bwt_hit_extra) == sizeof(HitExtra), "bwt_hit_extra is the device record");
+    if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits_compact: extend stage not run");
+    HIPCHK(hipSetDevice(b->device));
+    if (needed) { needed[0] = b->n_hits; needed[1] = b->n_extra; needed[2] = b->xcig_bytes; }
+    if ((hits && b->n_hits > hit_cap) || (extra && b->n_extra > extra_cap) || (cigar && b->xcig_bytes > cig_cap))
+        return fail(BWT_ENOSPC, "hit / extra / cigar capacity too small");
+    if (!read_status && !hits && !extra && !cigar) return (b->n_hits || b->n_extra || b->xcig_bytes) ? BWT_ENOSPC : 0;
+    int rc;
+    if ((rc = d2h(b, read_status, b->r_status, b->n)) || (rc = d2h(b, (HitRec *)hits, b->h_rec, b->n_hits)) ||
+        (rc = d2h(b, (HitExtra *)extra, b->x_rec, b->n_extra)) || (rc = d2h(b, cigar, b->x_cig, b->xcig_bytes)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// the same expansion as k_hits_expand, on the host, for a compact table that has left the device (pipe results, gathered tables)
+extern "C" int bwt_hits_expand(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const bwt_hit_rec *hits, uint64_t n_hits,
+                               const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t *hit_off, int32_t *score,
+                               int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t cig_cap,
+                               uint64_t *cig_needed) {
+    if ((!hits && n_hits) || (!extra && n_extra) || (!read_len && !off && n_hits)) return fail(BWT_EINVAL, "bwt_hits_expand: null argument");
+    auto lq_of = [&](uint32_t r) { return read_len ? read_len : (uint32_t)(off[r + 1] - off[r]); };
+    auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; };
+    uint64_t xi = 0, co = 0, r_next = 0;
+    for (uint64_t h = 0; h < n_hits; h++) {
+        const bwt_hit_rec &hr = hits[h];
+        if (hr.read >= n || (h && hr.read < hits[h - 1].read)) return fail(BWT_EINVAL, "bwt_hits_expand: hits must be ascending by read");
+        if (hit_off) while (r_next <= hr.read) hit_off[r_next++] = h;
+        const bool ex = xi < n_extra && extra[xi].hit == h;
+        const uint32_t lq = lq_of(hr.read), cl = ex ? extra[xi].cig_len : digits(lq) + 1;
+        if (score) score[h] = hr.score;
+        if (pos) pos[h] = hr.pos;
+        if (win_off) win_off[h] = hr.pos - shift + BWT_REF_EXT;
+        if (win_len) win_len[h] = (int32_t)(ex ? extra[xi].win_len : lq);
+        if (cig_off) cig_off[h] = co;
+        if (cigar && co + cl <= cig_cap) {
+            if (ex) memcpy(cigar + co, xcigar + extra[xi].cig_off, cl);
+            else {
+                cigar[co + cl - 1] = 'M';
+                uint32_t v = lq;
+                for (uint32_t x = cl - 1; x-- > 0;) { cigar[co + x] = (char)('0' + v % 10); v /= 10; }
+            }
+        }
+        co += cl;
+        if (ex) xi++;
+    }
+    if (xi != n_extra) return fail(BWT_EINVAL, "bwt_hits_expand: extras must be ascending by hit and name existing hits");
+    if (hit_off) while (r_next <= n) hit_off[r_next++] = n_hits;
+    if (cig_off) cig_off[n_hits] = co;
+    if (cig_needed) *cig_needed = co;
+    if (cigar && co > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
     return 0;
 }
 
@@ -1507,9 +1729,13 @@ extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, 
         HIPCHK(hipMemsetAsync(b->c_S.p, 0, (size_t)n * 4, b->stream));
     }
     HIPCHK(hipMemcpyAsync(b->clus_off.p, co.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    // one "read" per pair, one candidate each; the queries' offsets are the batch's read offsets (the hit expansion wants Lq)
+    std::vector<uint64_t> hq1((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; i++) hq1[i] = qoff[i] - qoff[0];
+    if ((rc = b->off.ensure(((size_t)n + 1) * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(b->off.p, hq1.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    // one "read" per pair, one candidate each
-    b->n = n; b->n_cand = n;
+    b->n = n; b->n_cand = n; b->ulen = 0;
     // bit-planes of both byte streams so that the prefilter applies here as well
     DevBuf pq, pr;
     struct G3 { DevBuf &a, &b; ~G3() { a.release(); b.release(); } } g3{pq, pr};
@@ -1540,6 +1766,8 @@ extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, 
     if (cig_off) cig_off[n] = o;
     if (o > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
     if (o && cigar) {
+        if ((rc = ensure_expanded(b))) return rc;
+        if (o != b->cig_bytes) return fail(BWT_EHIP, "internal: CIGAR text size mismatch");
         HIPCHK(hipMemcpyAsync(cigar, b->h_cig.p, o, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }

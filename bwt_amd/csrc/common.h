@@ -55,6 +55,8 @@ struct bwt_index {
     uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
     int32_t shift = 0;
     uint64_t ref1_len = 0;
+    bwt_options opt;                  // defaults of the batches made on this index (bwt_index_set_options); -1 = library's choice
+    bwt_index() { bwt_options_init(&opt); }
     hipStream_t stream = nullptr;     // index-level work only (table build, RefSeq gathers); every batch has its own stream
     // Threading contract (include/bwt_gpu.h): any number of threads may run *_batch calls / their own bwt_batch on one
     // index at a time (shared lock while kernels read the index); bwt_index_set_ktable swaps device arrays under the

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t n
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
                                                        const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) { scan3_body(in, out, bsum, n, nb); }
 // two arrays of the same length in one set of launches (blockIdx.y picks the array): half the launches of two scans
-struct ScanPair { const uint32_t *in[2]; uint64_t *out[2]; uint64_t *bsum[2]; };
+struct ScanPair { const uint32_t *in[3]; uint64_t *out[3]; uint64_t *bsum[3]; };
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan1_pair(ScanPair p, uint64_t n) { scan1_body(p.in[blockIdx.y], p.bsum[blockIdx.y], n); }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2_pair(ScanPair p, uint32_t nb) { scan2_body(p.bsum[blockIdx.y], nb); }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3_pair(ScanPair p, uint64_t n, uint32_t nb) {
@@ -3170,63 +3170,179 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
 // ------------------------------------------------------------------------------------------------
 // hits: the reference keeps, per read, the non-no_match results, prepending while it walks the
 // clusters (descending position) => final list order is ascending position (worker_bwt.erl:84-97).
+// The hit tables.  The device's own format is the COMPACT one (include/bwt_gpu.h): h_rec (16 bytes per hit, ascending by read,
+// a read's hits in the reference's list order), one status byte per read, and an `extra` record + CIGAR text only for the hits
+// that are not "plain" -- plain = settled on a square window with CIGAR "<Lq>M" (CIG_DIAG), for which window and text follow
+// from the record.  The per-hit arrays of bwt_align_batch (window offset / length, CIGAR offsets, all texts) are expanded from
+// it on demand (k_hits_expand) -- a batch whose results leave as compact tables never writes them.
 __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *__restrict__ clus_off,
                                                      const int32_t *__restrict__ c_status,
                                                      const uint32_t *__restrict__ c_ciglen,
                                                      const uint32_t *__restrict__ r_qty,
-                                                     uint32_t *__restrict__ r_nhit, uint32_t *__restrict__ r_cigb,
-                                                     int32_t *__restrict__ r_status, Counters *ctr) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    uint32_t nh = 0, cb = 0;
-    int32_t st = 1;                                   // sga returned []
-    if (r_qty[r] >> 31) st = -1;
-    const uint64_t a = clus_off[r], b = clus_off[r + 1];
-    if (b > a) st = 0;
-    for (uint64_t k = a; k < b; k++) {
-        const int32_t cs = c_status[k];
-        if (cs == CS_OK) { nh++; cb += c_ciglen[k] & ~CIG_DIAG; }
-        else if (cs == CS_WINDOW_OOR) st = -2;
-        else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
+                                                     uint32_t *__restrict__ r_nhit, uint32_t *__restrict__ r_nx,
+                                                     uint32_t *__restrict__ r_xcb, int8_t *__restrict__ r_status, Counters *ctr) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cb = 0;                        // bytes of all CIGAR texts (plain ones included): bwt_batch_counts.cigar_bytes
+    if (r < n) {
+        uint32_t nh = 0, nx = 0, xcb = 0;
+        int32_t st = 1;                                   // sga returned []
+        if (r_qty[r] >> 31) st = -1;
+        const uint64_t a = clus_off[r], b = clus_off[r + 1];
+        if (b > a) st = 0;
+        for (uint64_t k = a; k < b; k++) {
+            const int32_t cs = c_status[k];
+            if (cs == CS_OK) {
+                const uint32_t clf = c_ciglen[k];
+                nh++; cb += clf & ~CIG_DIAG;
+                if (!(clf & CIG_DIAG)) { nx++; xcb += clf; }
+            } else if (cs == CS_WINDOW_OOR) st = -2;
+            else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
+        }
+        if (st == -2) { nh = 0; nx = 0; xcb = 0; cb = 0; }
+        r_nhit[r] = nh; r_nx[r] = nx; r_xcb[r] = xcb; r_status[r] = (int8_t)st;
     }
-    if (st == -2) { nh = 0; cb = 0; }
-    r_nhit[r] = nh; r_cigb[r] = cb; r_status[r] = st;
+    cb = wave_sum_u64(cb);
+    if ((threadIdx.x & 63) == 0 && cb) atomicAdd(&ctr->cig_total, cb);
 }
 
 struct HitRec { uint32_t read; int32_t score; int64_t pos; };   // the 16-byte record gathered over RCCL
+struct HitExtra { uint32_t hit, win_len, cig_off, cig_len; };   // bwt_hit_extra
 
 __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, const uint64_t *__restrict__ clus_off,
-                                                     const uint64_t *__restrict__ hit_off,
-                                                     const uint64_t *__restrict__ cigb_off,
-                                                     const int32_t *__restrict__ r_status,
+                                                     const uint64_t *__restrict__ hit_off, const uint64_t *__restrict__ x_off,
+                                                     const uint64_t *__restrict__ xcb_off,
+                                                     const int8_t *__restrict__ r_status,
                                                      const int32_t *__restrict__ c_status,
                                                      const int32_t *__restrict__ c_score,
                                                      const uint32_t *__restrict__ c_ciglen,
                                                      const uint32_t *__restrict__ c_S, const uint32_t *__restrict__ c_wlen,
-                                                     const int64_t *__restrict__ c_woff, const uint8_t *__restrict__ cig,
-                                                     uint32_t cig_stride, HitRec *__restrict__ h_rec,
-                                                     int64_t *__restrict__ h_woff, int32_t *__restrict__ h_wlen,
-                                                     uint64_t *__restrict__ h_cigoff, uint8_t *__restrict__ h_cig) {
+                                                     const uint8_t *__restrict__ cig, uint32_t cig_stride,
+                                                     HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec,
+                                                     uint8_t *__restrict__ x_cig) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    if (r == 0) h_cigoff[hit_off[n]] = cigb_off[n];     // the terminating offset of the CIGAR text
     if (r_status[r] != 0) return;
     const uint64_t a = clus_off[r], b = clus_off[r + 1];
-    uint64_t ho = hit_off[r], co = cigb_off[r];
+    uint64_t ho = hit_off[r];
+    if (ho == hit_off[r + 1]) return;
+    uint64_t xo = x_off[r], co = xcb_off[r];
     for (uint64_t k = b; k-- > a;) {                  // reverse of the cluster order
         if (c_status[k] != CS_OK) continue;
-        const uint32_t wl = c_wlen[k], clf = c_ciglen[k], cl = clf & ~CIG_DIAG;
+        const uint32_t wl = c_wlen[k], clf = c_ciglen[k];
         HitRec hr; hr.read = r; hr.score = c_score[k];
         hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
-        h_rec[ho] = hr; h_woff[ho] = c_woff[k]; h_wlen[ho] = (int32_t)wl; h_cigoff[ho] = co;
-        if (clf & CIG_DIAG) {                                      // "<W>M" with W = Lq (settled by the prefilter on a square window)
-            h_cig[co + cl - 1] = (uint8_t)'M';
-            uint32_t v = wl;
-            for (uint32_t x = cl - 1; x-- > 0;) { h_cig[co + x] = (uint8_t)('0' + v % 10); v /= 10; }
-        } else {
-            const uint8_t *src = cig + k * (uint64_t)cig_stride + (cig_stride - cl);
-            for (uint32_t x = 0; x < cl; x++) h_cig[co + x] = src[x];
+        h_rec[ho] = hr;
+        if (!(clf & CIG_DIAG)) {
+            HitExtra x; x.hit = (uint32_t)ho; x.win_len = wl; x.cig_off = (uint32_t)co; x.cig_len = clf;
+            x_rec[xo++] = x;
+            const uint8_t *src = cig + k * (uint64_t)cig_stride + (cig_stride - clf);
+            for (uint32_t i = 0; i < clf; i++) x_cig[co + i] = src[i];
+            co += clf;
         }
-        ho++; co += cl;
+        ho++;
+    }
+}
+
+// ---- expansion of the compact table into the per-hit arrays of bwt_align_batch (on demand)
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; }
+__global__ __launch_bounds__(256) void k_hits_xidx(const HitExtra *__restrict__ x_rec, uint64_t nx, uint32_t *__restrict__ h_xidx) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nx; k += (uint64_t)gridDim.x * blockDim.x)
+        h_xidx[x_rec[k].hit] = (uint32_t)k;
+}
+__global__ __launch_bounds__(256) void k_hits_len(uint64_t nh, const HitRec *__restrict__ h_rec, const uint32_t *__restrict__ h_xidx,
+                                                   const HitExtra *__restrict__ x_rec, const uint64_t *__restrict__ off, uint32_t ulen,
+                                                   uint32_t *__restrict__ h_len) {
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t xi = h_xidx[h];
+        if (xi != 0xffffffffu) { h_len[h] = x_rec[xi].cig_len; continue; }
+        const uint32_t r = h_rec[h].read;
+        const uint32_t lq = ulen ? ulen : (uint32_t)(off[r + 1] - off[r]);
+        h_len[h] = dec_digits(lq) + 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_hits_expand(uint64_t nh, int32_t shift, const HitRec *__restrict__ h_rec,
+                                                      const uint32_t *__restrict__ h_xidx, const HitExtra *__restrict__ x_rec,
+                                                      const uint8_t *__restrict__ x_cig, const uint64_t *__restrict__ off, uint32_t ulen,
+                                                      const uint64_t *__restrict__ h_cigoff, int64_t *__restrict__ h_woff,
+                                                      int32_t *__restrict__ h_wlen, uint8_t *__restrict__ h_cig) {
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += (uint64_t)gridDim.x * blockDim.x) {
+        const HitRec hr = h_rec[h];
+        const uint32_t xi = h_xidx[h];
+        const uint64_t co = h_cigoff[h];
+        h_woff[h] = hr.pos - shift + BWT_REF_EXT;                  // Start = S - Ref_len + 200, Pos = S - Ref_len + Shift
+        if (xi != 0xffffffffu) {
+            const HitExtra x = x_rec[xi];
+            h_wlen[h] = (int32_t)x.win_len;
+            for (uint32_t i = 0; i < x.cig_len; i++) h_cig[co + i] = x_cig[x.cig_off + i];
+        } else {
+            const uint32_t lq = ulen ? ulen : (uint32_t)(off[hr.read + 1] - off[hr.read]);
+            h_wlen[h] = (int32_t)lq;
+            const uint32_t cl = dec_digits(lq) + 1;                 // "<Lq>M"
+            h_cig[co + cl - 1] = (uint8_t)'M';
+            uint32_t v = lq;
+            for (uint32_t x = cl - 1; x-- > 0;) { h_cig[co + x] = (uint8_t)('0' + v % 10); v /= 10; }
+        }
+    }
+}
+
+// ---- packed reads (include/bwt_gpu.h): 2-bit codes + exceptions -> the bit-planes (and, on request, the ASCII bytes)
+// lane = one 32-base word: 8 bytes of codes in, 16 bytes of planes (+ 32 bytes of ASCII) out
+__device__ __forceinline__ uint32_t up_spread4(uint32_t x4) { return (x4 * 0x00204081u) & 0x01010101u; }   // bit i -> bit 8i
+__global__ __launch_bounds__(256) void k_unpack_reads(const uint2 *__restrict__ codes, uint64_t nwords, uint64_t total,
+                                                       uint32_t *__restrict__ planes, uint8_t *__restrict__ ascii) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint2 c = codes[w];
+        if (w == nwords - 1 && (total & 31)) { const uint32_t m = (1u << (total & 31)) - 1u; c.x &= m; c.y &= m; }   // nothing behind the last base
+        if (planes) ((uint4 *)planes)[w] = make_uint4(c.x, c.y, 0u, 0u);
+        if (ascii) {
+            uint32_t o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t L = up_spread4((c.x >> (4 * k)) & 15u), H = up_spread4((c.y >> (4 * k)) & 15u);
+                o[k] = 0x41414141u + 2u * L + 6u * H + 0x0Bu * (L & H);        // A 41, C 43, G 47, T 54
+            }
+            uint4 *dst = (uint4 *)(ascii + w * 32);
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+// the exceptions: is-N / is-other plane bits, code bits cleared, the byte itself into the ASCII stream.  err: bit 0 = a position
+// past the end, bit 1 = a byte that is one of ACGT (not an exception)
+__global__ __launch_bounds__(256) void k_unpack_exc(const uint64_t *__restrict__ exc, uint64_t n_exc, uint64_t total,
+                                                     uint32_t *__restrict__ planes, uint8_t *__restrict__ ascii, unsigned int *__restrict__ err) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_exc; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = exc[k], pos = e & 0x00ffffffffffffffull;
+        const uint32_t c = (uint32_t)(e >> 56);
+        if (pos >= total) { atomicOr(err, 1u); continue; }
+        if (c == 'A' || c == 'C' || c == 'G' || c == 'T') { atomicOr(err, 2u); continue; }
+        const uint64_t w = pos >> 5;
+        const uint32_t bit = 1u << (pos & 31);
+        atomicAnd(&planes[4 * w + RP_LO], ~bit); atomicAnd(&planes[4 * w + RP_HI], ~bit);
+        atomicOr(&planes[4 * w + (c == 'N' ? RP_N : RP_O)], bit);
+        ascii[pos] = (uint8_t)c;
+    }
+}
+__global__ __launch_bounds__(256) void k_off_uniform(uint64_t *__restrict__ off, uint32_t n, uint32_t len) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) off[i] = i * len;
+}
+// ASCII bytes of single reads out of the planes (packed batches keep no ASCII copy of reads that never reach a byte-reading
+// kernel): wave per listed candidate's read, 'other' positions keep the byte k_unpack_exc stored
+__global__ __launch_bounds__(256) void k_ascii_reads(const uint32_t *__restrict__ queue, const unsigned int *__restrict__ count,
+                                                      const uint64_t *__restrict__ c_qoff, const uint32_t *__restrict__ c_qlen,
+                                                      const uint32_t *__restrict__ planes, uint8_t *__restrict__ ascii) {
+    const uint32_t nq = *count, lane = threadIdx.x & 63;
+    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nq; q += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t c = queue[q];
+        const uint64_t qo = c_qoff[c];
+        const uint32_t lq = c_qlen[c];
+        for (uint32_t i = lane; i < lq; i += 64) {
+            const uint64_t pos = qo + i, w = pos >> 5;
+            const uint32_t sh = (uint32_t)pos & 31u;
+            const uint4 v = ((const uint4 *)planes)[w];
+            if ((v.w >> sh) & 1u) continue;
+            const uint32_t code = ((v.x >> sh) & 1u) | (((v.y >> sh) & 1u) << 1);
+            ascii[pos] = ((v.z >> sh) & 1u) ? (uint8_t)'N' : (uint8_t)("ACGT"[code]);
+        }
     }
 }

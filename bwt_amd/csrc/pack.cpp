@@ -1,0 +1,81 @@
+// libbwtgpu: bwt_pack_reads -- ASCII bases -> the packed wire format of the host boundary (include/bwt_gpu.h): two bits per
+// base as a low and a high bit-plane word per 32 bases, plus an exception list for everything outside ACGT.  Host only.
+//
+// Eight bases at a time: with x the 8 ASCII bytes, bit 1 and bit 2 of every byte give the code (A 41 -> 00, C 43 -> 01,
+// G 47 -> 10, T 54 -> 11: hi = bit 2, lo = bit 1 ^ bit 2); the byte the code stands for is rebuilt arithmetically
+// (41 + 2 lo + 6 hi + 0B (lo & hi)) and compared with x -- equal for all eight bytes is the common case; otherwise the
+// group is redone byte by byte and its exceptions listed.  The eight flag bits of a group are gathered by one multiply.
+#include "../../include/bwt_gpu.h"
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+int bwt_fail(int code, const std::string &msg);
+
+namespace {
+constexpr uint64_t ONES = 0x0101010101010101ull;
+inline uint32_t gather8(uint64_t v) { return (uint32_t)((v * 0x0102040810204080ull) >> 56); }   // bit 0 of byte i -> bit i
+
+// bases [a, e) of the stream, a a multiple of 32: the code words of that range; exceptions appended to ex
+void pack_range(const uint8_t *bases, uint64_t a, uint64_t e, uint32_t *codes, std::vector<uint64_t> &ex) {
+    for (uint64_t w = a / 32; w * 32 < e; w++) {
+        uint32_t lo = 0, hi = 0;
+        const uint64_t p0 = w * 32;
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint64_t p = p0 + 8 * g;
+            if (p >= e) break;
+            uint64_t x;
+            if (p + 8 <= e) memcpy(&x, bases + p, 8);
+            else {                                            // the stream's tail: 'A' behind the last base (code 0, no exception)
+                x = 0x4141414141414141ull;
+                memcpy(&x, bases + p, (size_t)(e - p));
+            }
+            const uint64_t b1 = (x >> 1) & ONES, b2 = (x >> 2) & ONES;
+            uint64_t l = b1 ^ b2, h = b2;
+            const uint64_t expect = 0x41 * ONES + 2 * l + 6 * h + 0x0B * (l & h);
+            if (x != expect) {
+                // some byte of the group is not one of ACGT: it gets code 0 and an exception record
+                const uint64_t d = x ^ expect;
+                for (uint32_t i = 0; i < 8; i++)
+                    if ((d >> (8 * i)) & 0xff) {
+                        l &= ~(1ull << (8 * i)); h &= ~(1ull << (8 * i));
+                        ex.push_back((p + i) | ((x >> (8 * i)) & 0xff) << 56);
+                    }
+            }
+            lo |= gather8(l) << (8 * g); hi |= gather8(h) << (8 * g);
+        }
+        codes[2 * w] = lo; codes[2 * w + 1] = hi;
+    }
+}
+}  // namespace
+
+extern "C" int bwt_pack_reads(const uint8_t *bases, uint64_t total, uint32_t *codes, uint64_t *exc, uint64_t exc_cap,
+                              uint64_t *n_exc, uint32_t threads) {
+    if ((!bases && total) || !codes || (!exc && exc_cap)) return bwt_fail(BWT_EINVAL, "bwt_pack_reads: null argument");
+    if (total >> 56) return bwt_fail(BWT_EINVAL, "bwt_pack_reads: too many bases");
+    const uint64_t nwords = (total + 31) / 32;
+    unsigned T = threads ? threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, nwords / 32768 + 1));        // a thread is worth >= 1 MB of bases
+    std::vector<std::vector<uint64_t>> ex(T);
+    const uint64_t per = ((nwords + T - 1) / T) * 32;
+    if (T == 1) pack_range(bases, 0, total, codes, ex[0]);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                const uint64_t a = std::min<uint64_t>(total, t * per), e = std::min<uint64_t>(total, a + per);
+                if (a < e) pack_range(bases, a, e, codes, ex[t]);
+            });
+        for (auto &x : th) x.join();
+    }
+    codes[2 * nwords] = 0; codes[2 * nwords + 1] = 0;         // (bwt_packed_words leaves room for one empty word behind the last)
+    uint64_t k = 0;
+    for (auto &v : ex) k += v.size();
+    if (n_exc) *n_exc = k;
+    if (k > exc_cap) return bwt_fail(BWT_ENOSPC, "bwt_pack_reads: exception capacity too small");
+    uint64_t o = 0;
+    for (auto &v : ex) { if (!v.empty()) memcpy(exc + o, v.data(), v.size() * 8); o += v.size(); }
+    return 0;
+}

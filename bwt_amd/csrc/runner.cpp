@@ -5,8 +5,9 @@
 //   threshold) -- with the casts in the order the reference sends them: workloads in file order, inside a workload the lists
 //   newest first (produce_workload prepends), inside a list the reads in file order (read_seqs prepends, the worker's fold
 //   prepends again).
-// FASTQ records are parsed by the threaded reader straight into a pipe slot's pinned buffers (bwt_pipe: upload, kernels and download
-// of consecutive batches overlap), picked and printed on the host.  Transport (navel) and the gen_server shell stay out of scope.
+// FASTQ records are parsed by the threaded reader into a pipe slot's staging buffer, packed to two bits per base by the slot's own
+// thread (bwt_pipe_submit_ascii) and uploaded; the compact hit tables that come back (bwt_pipe: upload, kernels and download
+// of consecutive batches overlap) are picked and printed on the host.  Transport (navel) and the gen_server shell stay out of scope.
 #include "common.h"
 #include "otp_sort.h"
 
@@ -17,7 +18,7 @@
 #include <vector>
 
 namespace {
-struct SlotHost { std::vector<char> names; std::vector<uint64_t> name_off; uint32_t n = 0; int state = 0; };
+struct SlotHost { std::vector<char> names; std::vector<uint64_t> name_off; const uint64_t *off = nullptr; uint32_t n = 0; int state = 0; };
 
 inline char *put_int(char *p, long long v) {
     char tmp[24];
@@ -57,6 +58,8 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
     if (out_path && !(out = fopen(out_path, "wb"))) return fail(BWT_EIO, std::string("cannot create ") + out_path);
     struct OG { FILE *f; ~OG() { if (f) fclose(f); } } og{out};
     const uint32_t depth = 3;
+    uint32_t meta[5];
+    if ((rc = bwt_index_meta(ix, meta))) return rc;
     bwt_pipe *pipe = nullptr;
     if ((rc = bwt_pipe_create(ix, depth, &pipe))) return rc;
     struct PG { bwt_pipe *p; ~PG() { bwt_pipe_destroy(p); } } pg{pipe};
@@ -69,6 +72,8 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
     std::vector<uint32_t> sel;            // per read of the batch: the picked hit, or ~0u
     std::vector<int64_t> gwoff; std::vector<int32_t> gwlen; std::vector<uint64_t> goff; std::vector<uint8_t> gwin;
     std::vector<int32_t> sc;
+    std::vector<uint64_t> hoff;           // per read of the batch: where its hits start in the compact table
+    std::vector<uint32_t> xof;            // per printed hit: its extra record, or ~0u (plain: "<Lq>M" on a window of Lq bases)
 
     double t_parse = 0, t_wait = 0, t_pick = 0, t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -86,12 +91,18 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
         // the pick (worker_bwt.erl:99-106) per read; array index i is file-order record n-1-i of the batch
         sel.assign(n, ~0u);
         uint64_t nsel = 0;
+        // the compact table is ascending by read: one pass gives every read's slice
+        hoff.assign((size_t)n + 1, r.n_hits);
+        {
+            uint64_t rn = 0;
+            for (uint64_t k = 0; k < r.n_hits; k++) while (rn <= r.hits[k].read) hoff[(size_t)rn++] = k;
+        }
         for (uint32_t i = 0; i < n; i++) {
             const int32_t rs = r.read_status[i];
             if (rs == 1) continue;                                          // sga returned []: nothing is cast (:77)
             if (rs < 0) { st.crashes++; continue; }
             st.with_clusters++;
-            const uint64_t a = r.hit_off[i], b = r.hit_off[i + 1];
+            const uint64_t a = hoff[i], b = hoff[(size_t)i + 1];
             if (a == b) { st.no_cigar++; continue; }
             uint32_t pick = (uint32_t)a;
             if (b - a > 1) {
@@ -107,7 +118,20 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
             gwoff.resize((size_t)nsel); gwlen.resize((size_t)nsel); goff.resize((size_t)nsel + 1);
             std::vector<uint32_t> gidx(n, 0);
             uint64_t k = 0, wbytes = 0;
-            for (uint32_t i = 0; i < n; i++) if (sel[i] != ~0u) { gidx[i] = (uint32_t)k; gwoff[(size_t)k] = r.win_off[sel[i]]; gwlen[(size_t)k] = r.win_len[sel[i]]; wbytes += (uint64_t)r.win_len[sel[i]]; k++; }
+            // window and CIGAR of a picked hit: from its extra record if it has one (the extras are ascending by hit, and so are
+            // the picked hits in array order), else the plain form
+            xof.assign((size_t)nsel, ~0u);
+            uint64_t xi = 0;
+            const int32_t shift = (int32_t)meta[4];
+            for (uint32_t i = 0; i < n; i++) if (sel[i] != ~0u) {
+                const uint32_t hsel = sel[i];
+                while (xi < r.n_extra && r.extra[xi].hit < hsel) xi++;
+                const bool ex = xi < r.n_extra && r.extra[xi].hit == hsel;
+                const uint32_t lq = r.read_len ? r.read_len : (uint32_t)(h.off[i + 1] - h.off[i]);
+                const int32_t wl = (int32_t)(ex ? r.extra[xi].win_len : lq);
+                if (ex) xof[(size_t)k] = (uint32_t)xi;
+                gidx[i] = (uint32_t)k; gwoff[(size_t)k] = r.hits[hsel].pos - shift + 200; gwlen[(size_t)k] = wl; wbytes += (uint64_t)wl; k++;
+            }
             gwin.resize((size_t)wbytes + 16);
             uint64_t need = 0;
             if ((rc2 = bwt_ref1_gather(ix, gwoff.data(), gwlen.data(), nsel, gwin.data(), wbytes, goff.data(), &need))) return rc2;
@@ -122,8 +146,12 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
                         const uint32_t i = n - 1 - f;
                         if (sel[i] == ~0u) continue;
                         const uint32_t hsel = sel[i];
-                        const uint64_t nl = h.name_off[i + 1] - h.name_off[i], cl = r.cig_off[hsel + 1] - r.cig_off[hsel];
                         const uint64_t g = gidx[i], wl = goff[(size_t)g + 1] - goff[(size_t)g];
+                        char plain[16];
+                        const char *ctext; uint64_t cl;
+                        if (xof[(size_t)g] != ~0u) { ctext = r.cigar + r.extra[xof[(size_t)g]].cig_off; cl = r.extra[xof[(size_t)g]].cig_len; }
+                        else { char *e = put_int(plain, (long long)wl); *e++ = 'M'; ctext = plain; cl = (uint64_t)(e - plain); }
+                        const uint64_t nl = h.name_off[i + 1] - h.name_off[i];
                         const size_t at = text.size();
                         text.resize(at + nl + clen + cl + wl + 96);
                         char *p = text.data() + at;
@@ -131,7 +159,7 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
                         memcpy(p, h.names.data() + h.name_off[i], nl); p += nl;
                         memcpy(p, "      ", 6); p += 6; memcpy(p, chromosome, clen); p += clen;
                         memcpy(p, "      ", 6); p += 6; p = put_int(p, r.hits[hsel].pos);
-                        memcpy(p, "      ", 6); p += 6; memcpy(p, r.cigar + r.cig_off[hsel], cl); p += cl;
+                        memcpy(p, "      ", 6); p += 6; memcpy(p, ctext, cl); p += cl;
                         memcpy(p, "      ", 6); p += 6; p = put_int(p, r.hits[hsel].score);
                         memcpy(p, "      ", 6); p += 6; memcpy(p, gwin.data() + goff[(size_t)g], wl); p += wl;
                         *p++ = '\n';
@@ -150,9 +178,11 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
     while (!eof || inflight) {
         if (!eof && inflight < depth) {
             uint8_t *pb; uint64_t *po; uint32_t slot;
-            rc = bwt_pipe_acquire(pipe, bases_cap, batch_reads, &pb, &po, &slot);
+            bwt_pipe_input in;
+            rc = bwt_pipe_acquire_packed(pipe, bases_cap, batch_reads, batch_reads / 8 + 4096, &in, &slot);
             if (rc == BWT_ENOSPC) { if ((rc = consume())) return rc; continue; }
             if (rc) return rc;
+            pb = in.ascii; po = in.off;
             SlotHost &h = host[slot];
             h.names.resize((size_t)batch_reads * 48 + 4096);
             h.name_off.resize((size_t)batch_reads + 1);
@@ -164,7 +194,8 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
                 bases_cap = std::max<uint64_t>(bases_cap, need[0] + 4096);
                 h.names.resize((size_t)need[1] + 4096);
                 (void)bwt_pipe_release(pipe, slot);
-                if ((rc = bwt_pipe_acquire(pipe, bases_cap, batch_reads, &pb, &po, &slot))) return rc;
+                if ((rc = bwt_pipe_acquire_packed(pipe, bases_cap, batch_reads, batch_reads / 8 + 4096, &in, &slot))) return rc;
+                pb = in.ascii; po = in.off;
                 SlotHost &h2 = host[slot];
                 h2.names.resize((size_t)need[1] + 4096); h2.name_off.resize((size_t)batch_reads + 1);
                 rc = bwt_fastq_read_seqs(fq, batch_reads, pb, bases_cap, po, h2.names.data(), h2.names.size(), h2.name_off.data(), &k, &state, need);
@@ -172,9 +203,9 @@ extern "C" int bwt_run_fastq(bwt_index *ix, const char *fastq_path, const char *
             if (rc) { (void)bwt_pipe_release(pipe, slot); return rc; }
             if (state != 0) eof = true;                                     // eof, with or without a last partial batch
             if (k == 0) { (void)bwt_pipe_release(pipe, slot); continue; }
-            host[slot].n = k;
+            host[slot].n = k; host[slot].off = po;
             st.reads += k;
-            if ((rc = bwt_pipe_submit(pipe, slot, k))) return rc;
+            if ((rc = bwt_pipe_submit_ascii(pipe, slot, k, 0))) return rc;
             inflight++;
         } else if ((rc = consume()))
             return rc;

@@ -22,6 +22,9 @@ EXPORTS = [
     "bwt_pipe_release", "bwt_reverse_complement_batch", "bwt_batch_hits_to_device_global",
     "bwt_index_save_native", "bwt_index_open_native", "bwt_native_check", "bwt_fastq_set_threads",
     "bwt_run_fastq", "bwt_otp_pick", "bwt_batch_set_reads_both_strands", "bwt_batch_pair_hits",
+    "bwt_options_init", "bwt_index_set_options", "bwt_batch_set_options", "bwt_index_set_ktable_ex", "bwt_packed_words", "bwt_pack_reads",
+    "bwt_batch_set_reads_packed", "bwt_batch_fetch_hits_compact", "bwt_hits_expand", "bwt_pipe_set_options", "bwt_pipe_profile",
+    "bwt_pipe_kernel_times", "bwt_pipe_acquire_packed", "bwt_pipe_submit_packed", "bwt_pipe_submit_ascii", "bwt_pipe_batch",
 ]
 
 
@@ -50,17 +53,55 @@ class RunStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("reads", "with_clusters", "no_cigar", "cigars", "lines", "crashes")] + [("seconds", C.c_double)]
 
 
+OPTION_FIELDS = ("seed_fuse", "seed_fast", "seed_big", "search_ilp", "sw_prefilter", "sw_fuse_cand", "sw_wave", "sw_band", "sw_band_min",
+                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug")
+
+
+class Options(C.Structure):
+    """bwt_options: which of the library's equivalent kernels run (-1 = its own choice); never read from the environment by the library."""
+    _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in OPTION_FIELDS]
+
+
+def make_options(**kw):
+    o = Options()
+    load().bwt_options_init(C.byref(o))
+    for k, v in kw.items():
+        if k not in OPTION_FIELDS:
+            raise KeyError("no such option: %s" % k)
+        setattr(o, k, int(v))
+    return o
+
+
+def options_from_env(env=None):
+    """BWT_SEED_FAST=0 etc. -> keyword arguments for set_options (bench.py / scripts / tests: experiments are switched from outside
+    the library, which itself never looks at the environment)."""
+    env = os.environ if env is None else env
+    out = {}
+    for k in OPTION_FIELDS:
+        v = env.get("BWT_" + k.upper())
+        if v not in (None, ""):
+            out[k] = int(v)
+    return out
+
+
 HIT_REC = np.dtype([("read", np.uint32), ("score", np.int32), ("pos", np.int64)])
 PAIR_REC = np.dtype([("hit1", np.uint32), ("hit2", np.uint32), ("insert", np.int32), ("score", np.int32), ("n_proper", np.uint32),
                      ("flags", np.uint32)])
 NO_HIT = 0xFFFFFFFF
 
 
+HIT_EXTRA = np.dtype([("hit", np.uint32), ("win_len", np.uint32), ("cig_off", np.uint32), ("cig_len", np.uint32)])
+
+
+class PipeInput(C.Structure):
+    _fields_ = [("codes", C.c_void_p), ("exc", C.c_void_p), ("off", C.c_void_p), ("ascii", C.c_void_p), ("bases_cap", C.c_uint64),
+                ("exc_cap", C.c_uint64), ("reads_cap", C.c_uint32)]
+
+
 class PipeResult(C.Structure):
-    _fields_ = [("slot", C.c_uint32), ("n_reads", C.c_uint32), ("status", C.c_int32), ("n_hits", C.c_uint64),
-                ("cigar_bytes", C.c_uint64), ("read_status", C.c_void_p), ("hit_off", C.c_void_p), ("hits", C.c_void_p),
-                ("win_off", C.c_void_p), ("win_len", C.c_void_p), ("cig_off", C.c_void_p), ("cigar", C.c_void_p),
-                ("counts", BatchCounts)]
+    _fields_ = [("slot", C.c_uint32), ("n_reads", C.c_uint32), ("status", C.c_int32), ("read_len", C.c_uint32), ("n_hits", C.c_uint64),
+                ("n_extra", C.c_uint64), ("cigar_bytes", C.c_uint64), ("read_status", C.c_void_p), ("hits", C.c_void_p),
+                ("extra", C.c_void_p), ("cigar", C.c_void_p), ("counts", BatchCounts)]
 
 
 _lib = None
@@ -83,6 +124,9 @@ def load():
     lib.bwt_batch_destroy.restype = None
     lib.bwt_pipe_destroy.restype = None
     lib.bwt_constants.restype = None
+    lib.bwt_options_init.restype = None
+    lib.bwt_packed_words.restype = C.c_uint64
+    lib.bwt_pipe_batch.restype = C.c_void_p
     _lib = lib
     return lib
 
@@ -119,6 +163,41 @@ def native_check(path):
 
 def fm_rewrite(in_path, out_path):
     _chk(load().bwt_fm_rewrite(os.fsencode(in_path), os.fsencode(out_path)))
+
+
+def pack_2bit(bases, threads=0):
+    """bwt_pack_reads: ASCII stream -> (codes u32[bwt_packed_words], exceptions u64[]) -- the packed wire format."""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    total = len(bases)
+    codes = np.zeros(int(load().bwt_packed_words(C.c_uint64(total))), np.uint32)
+    n_exc = C.c_uint64(0)
+    exc = np.zeros(max(16, total // 64), np.uint64)
+    rc = load().bwt_pack_reads(_p(bases), C.c_uint64(total), _p(codes), _p(exc), C.c_uint64(len(exc)), C.byref(n_exc), C.c_uint32(threads))
+    if rc == ENOSPC:
+        exc = np.zeros(n_exc.value, np.uint64)
+        rc = load().bwt_pack_reads(_p(bases), C.c_uint64(total), _p(codes), _p(exc), C.c_uint64(len(exc)), C.byref(n_exc), C.c_uint32(threads))
+    _chk(rc)
+    return codes, exc[:n_exc.value].copy()
+
+
+def hits_expand(n, read_len, off, shift, hits, extra, xcigar):
+    """bwt_hits_expand: a compact hit table (HIT_REC array, HIT_EXTRA array, text bytes) -> the per-hit arrays of align_batch."""
+    hits = np.ascontiguousarray(hits, HIT_REC); extra = np.ascontiguousarray(extra, HIT_EXTRA)
+    nh = len(hits)
+    xc = np.frombuffer(bytes(xcigar), np.uint8) if not isinstance(xcigar, np.ndarray) else np.ascontiguousarray(xcigar, np.uint8)
+    off64 = None if off is None else np.ascontiguousarray(off, np.uint64)
+    hoff = np.empty(n + 1, np.uint64); score = np.empty(nh, np.int32); pos = np.empty(nh, np.int64); woff = np.empty(nh, np.int64)
+    wlen = np.empty(nh, np.int32); coff = np.empty(nh + 1, np.uint64)
+    need = C.c_uint64(0)
+
+    def call(cig, cap):
+        return load().bwt_hits_expand(C.c_uint32(n), C.c_uint32(read_len), _p(off64), C.c_int32(shift), _p(hits), C.c_uint64(nh), _p(extra),
+                                      C.c_uint64(len(extra)), _p(xc), _p(hoff), _p(score), _p(pos), _p(woff), _p(wlen), _p(coff), _p(cig),
+                                      C.c_uint64(cap), C.byref(need))
+    _chk(call(None, 0))
+    cig = np.empty(need.value, np.uint8)
+    _chk(call(cig, len(cig)))
+    return dict(hit_off=hoff, score=score, pos=pos, win_off=woff, win_len=wlen, cig_off=coff, cigar=cig.tobytes())
 
 
 def pack_reads(reads):
@@ -209,10 +288,15 @@ class Index:
         _chk(load().bwt_index_device_bytes(self.h, out))
         return dict(rank_blocks=int(out[0]), sa=int(out[1]), ref1=int(out[2]), ktable=int(out[3]))
 
-    def set_ktable(self, k, wide=-1):
-        """Suffix-interval table: depth k (0 = none, 8..15, negative = the library's default for this index) and
-        whether its top level carries SA values (1 / 0 / negative = default)."""
-        _chk(load().bwt_index_set_ktable(self.h, int(k), int(wide)))
+    def set_ktable(self, k, wide=-1, summary=1):
+        """Suffix-interval table: depth k (0 = none, 8..15, negative = the library's default for this index), whether its
+        top level carries SA values (1 / 0 / negative = default) and the summary bitmap (0 none, 1 where it pays, 2 everywhere)."""
+        _chk(load().bwt_index_set_ktable_ex(self.h, int(k), int(wide), int(summary)))
+
+    def set_options(self, **kw):
+        """bwt_index_set_options: defaults of the batches made on this index from now on (no arguments = the library's own choices)."""
+        o = make_options(**kw)
+        _chk(load().bwt_index_set_options(self.h, C.byref(o)))
 
     @property
     def ktable(self):
@@ -393,11 +477,36 @@ class Batch:
         except Exception:
             pass
 
+    def set_options(self, **kw):
+        o = make_options(**kw)
+        _chk(load().bwt_batch_set_options(self.h, C.byref(o)))
+
     def set_reads(self, bases, off):
         bases = np.ascontiguousarray(bases, np.uint8)
         off = np.ascontiguousarray(off, np.uint64)
         self.n = len(off) - 1
         _chk(load().bwt_batch_set_reads(self.h, _p(bases), _p(off), C.c_uint32(self.n)))
+
+    def set_reads_packed(self, codes, exc, n, read_len=0, off=None, total=None):
+        """bwt_batch_set_reads_packed: 2-bit codes + exceptions (pack_2bit); read_len > 0 for a uniform batch, else off[n+1]."""
+        codes = np.ascontiguousarray(codes, np.uint32); exc = np.ascontiguousarray(exc, np.uint64)
+        off64 = None if off is None else np.ascontiguousarray(off, np.uint64)
+        if total is None:
+            total = n * read_len if read_len else int(off64[n])
+        self.n = n
+        _chk(load().bwt_batch_set_reads_packed(self.h, _p(codes), C.c_uint64(total), C.c_uint32(n), C.c_uint32(read_len), _p(off64),
+                                               _p(exc), C.c_uint64(len(exc))))
+
+    def fetch_hits_compact(self):
+        """The compact hit table as it sits in HBM -> dict(read_status i8[n], hits HIT_REC[], extra HIT_EXTRA[], cigar bytes)."""
+        need = (C.c_uint64 * 3)()
+        rc = load().bwt_batch_fetch_hits_compact(self.h, None, None, None, None, C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), need)
+        if rc not in (0, ENOSPC):
+            _chk(rc)
+        nh, nx, cb = int(need[0]), int(need[1]), int(need[2])
+        rs = np.empty(self.n, np.int8); hits = np.empty(nh, HIT_REC); extra = np.empty(nx, HIT_EXTRA); cig = np.empty(cb, np.uint8)
+        _chk(load().bwt_batch_fetch_hits_compact(self.h, _p(rs), _p(hits), _p(extra), _p(cig), C.c_uint64(nh), C.c_uint64(nx), C.c_uint64(cb), need))
+        return dict(read_status=rs, hits=hits, extra=extra, cigar=cig.tobytes())
 
     def set_reads_both_strands(self, bases, off):
         """SURVEY 8f-4 (not in the reference): the batch then holds 2n reads, read n + i = reverse complement of read i."""
@@ -483,7 +592,8 @@ def _view(ptr, count, dtype):
 
 
 class Pipe:
-    """bwt_pipe: `depth` slots with pinned host buffers; H2D, kernels and D2H of consecutive batches overlap."""
+    """bwt_pipe: `depth` slots with pinned host buffers; H2D, kernels and D2H of consecutive batches overlap.  Reads go up packed
+    (2 bits per base + exceptions) or as ASCII; the compact hit table comes back."""
 
     def __init__(self, index, depth=3):
         self.index = index
@@ -501,8 +611,22 @@ class Pipe:
         except Exception:
             pass
 
+    def set_options(self, **kw):
+        o = make_options(**kw)
+        _chk(load().bwt_pipe_set_options(self.h, C.byref(o)))
+
+    def profile(self, enable=True):
+        _chk(load().bwt_pipe_profile(self.h, 1 if enable else 0))
+
+    def kernel_times(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * 64)(); ln = (C.c_uint64 * 64)()
+        k = _chk(load().bwt_pipe_kernel_times(self.h, names, 4096, ms, ln, 64))
+        parts = names.raw.split(b"\0")[:k]
+        return {parts[i].decode(): dict(ms=float(ms[i]), launches=int(ln[i])) for i in range(k)}
+
     def acquire(self, bases_cap, reads_cap):
-        """-> (slot, bases u8 view, off u64 view) of a free slot's pinned input buffers, or None when all are busy."""
+        """ASCII form -> (slot, bases u8 view, off u64 view) of a free slot's pinned input buffers, or None when all are busy."""
         pb = C.c_void_p(); po = C.c_void_p(); slot = C.c_uint32(0)
         rc = load().bwt_pipe_acquire(self.h, C.c_uint64(bases_cap), C.c_uint32(reads_cap), C.byref(pb), C.byref(po), C.byref(slot))
         if rc == ENOSPC:
@@ -513,17 +637,43 @@ class Pipe:
     def submit(self, slot, n_reads):
         _chk(load().bwt_pipe_submit(self.h, C.c_uint32(slot), C.c_uint32(n_reads)))
 
+    def acquire_packed(self, bases_cap, reads_cap, exc_cap=0):
+        """Packed form -> (slot, dict of views: codes u32, exc u64, off u64, ascii u8 staging), or None when all slots are busy."""
+        pin = PipeInput(); slot = C.c_uint32(0)
+        rc = load().bwt_pipe_acquire_packed(self.h, C.c_uint64(bases_cap), C.c_uint32(reads_cap), C.c_uint64(exc_cap), C.byref(pin), C.byref(slot))
+        if rc == ENOSPC:
+            return None
+        _chk(rc)
+        words = int(load().bwt_packed_words(C.c_uint64(bases_cap)))
+        return slot.value, dict(codes=_view(pin.codes, words, np.uint32), exc=_view(pin.exc, int(pin.exc_cap), np.uint64),
+                                off=_view(pin.off, reads_cap + 1, np.uint64), ascii=_view(pin.ascii, bases_cap, np.uint8))
+
+    def submit_packed(self, slot, n_reads, read_len, total_bases, n_exc):
+        _chk(load().bwt_pipe_submit_packed(self.h, C.c_uint32(slot), C.c_uint32(n_reads), C.c_uint32(read_len), C.c_uint64(total_bases),
+                                           C.c_uint64(n_exc)))
+
+    def submit_ascii(self, slot, n_reads, read_len=0):
+        _chk(load().bwt_pipe_submit_ascii(self.h, C.c_uint32(slot), C.c_uint32(n_reads), C.c_uint32(read_len)))
+
     def wait(self):
-        """The oldest submitted batch -> dict of views into the slot's pinned result buffers (valid until release(slot))."""
+        """The oldest submitted batch -> dict of views into the slot's pinned result buffers (valid until release(slot)): the
+        compact hit table (read_status i8, hits, extra, cigar); expand() gives the per-hit arrays of align_batch."""
         r = PipeResult()
         _chk(load().bwt_pipe_wait(self.h, C.byref(r)))
-        n, nh = r.n_reads, int(r.n_hits)
-        hits = _view(r.hits, nh, HIT_REC)
-        return dict(slot=r.slot, n_reads=n, read_status=_view(r.read_status, n, np.int32), hit_off=_view(r.hit_off, n + 1, np.uint64),
-                    hits=hits, score=hits["score"] if nh else np.zeros(0, np.int32), pos=hits["pos"] if nh else np.zeros(0, np.int64),
-                    win_off=_view(r.win_off, nh, np.int64), win_len=_view(r.win_len, nh, np.int32),
-                    cig_off=_view(r.cig_off, nh + 1, np.uint64), cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8).tobytes(),
-                    counts=r.counts.as_dict())
+        n, nh, nx = r.n_reads, int(r.n_hits), int(r.n_extra)
+        return dict(slot=r.slot, n_reads=n, read_len=int(r.read_len), read_status=_view(r.read_status, n, np.int8),
+                    hits=_view(r.hits, nh, HIT_REC), extra=_view(r.extra, nx, HIT_EXTRA),
+                    cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8).tobytes(), counts=r.counts.as_dict())
+
+    def expand(self, res, off=None):
+        """per-hit arrays of a wait() result (host-side bwt_hits_expand); off = the batch's read offsets when the lengths differ"""
+        out = hits_expand(res["n_reads"], res["read_len"], off, self.index.meta()[1], res["hits"], res["extra"], res["cigar"])
+        out["read_status"] = res["read_status"].astype(np.int32)
+        return out
+
+    def batch_handle(self, slot):
+        """the slot's resident batch (hit tables still in HBM until release): for the RCCL gather"""
+        return C.c_void_p(load().bwt_pipe_batch(self.h, C.c_uint32(slot)))
 
     def release(self, slot):
         _chk(load().bwt_pipe_release(self.h, C.c_uint32(slot)))

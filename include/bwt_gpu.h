@@ -49,6 +49,32 @@ void bwt_constants(bwt_constants_t *out);
 
 const char *bwt_last_error(void);
 
+/* ------------------------------------------------------------------ execution options
+ * Which of the library's equivalent kernels run is decided by this struct, never by the process environment (a library
+ * loaded into a BEAM VM must not change behaviour with ambient variables).  Every field: -1 = the library's own choice;
+ * results are bit-identical for every setting (tests/test_gpu_modes.py drives each one against the oracle).
+ * bwt_options_init fills in -1 everywhere.  bwt_index_set_options: the defaults of every batch / pipe created on the index
+ * afterwards and of the private batches of the host-buffer entry points (bwt_align_batch, ...); bwt_batch_set_options: one
+ * batch.  Only bench.py, scripts/ and the tests translate environment variables into this struct. */
+typedef struct {
+    uint32_t struct_size;       /* sizeof(bwt_options): set by bwt_options_init */
+    int32_t seed_fuse;          /* 0: the seed kernel does not cluster reads itself */
+    int32_t seed_fast;          /* 0: general seed kernel only (no k_seed_fast) */
+    int32_t seed_big;           /* 0 / 1: force the one- / two-register variant of k_seed_fast */
+    int32_t search_ilp;         /* 2: two tasks per quad in k_search (table-less search) */
+    int32_t sw_prefilter;       /* 0: every candidate goes to the DP kernels */
+    int32_t sw_fuse_cand;       /* 0: separate k_candidates pass in front of the prefilter */
+    int32_t sw_wave;            /* 0: no wave-per-alignment kernel for short DP queues */
+    int32_t sw_band;            /* 0: no banded DP tier (full rectangles only) */
+    int32_t sw_band_min;        /* DP queues up to this many candidates skip the banded tier (default 16384) */
+    int32_t sw_lds;             /* 0: boundary rows in HBM slabs instead of LDS */
+    int32_t sw_pk;              /* 0: no packed-i16 DP kernels */
+    int32_t sw_trace_all;       /* 0: score-only DP pass first, traceback for what needs it */
+    int32_t pf_blocks_per_cu, sw_blocks_per_cu, sw_waves_per_cu;   /* occupancy caps (experiments) */
+    int32_t debug;              /* 1: diagnostic lines on stderr (hand-back reasons of k_seed_fast) */
+} bwt_options;
+void bwt_options_init(bwt_options *o);
+
 /* ------------------------------------------------------------------ index (a-11, worker init)
  * Replaces fm_index:get_index/2 (src/fm_index.erl:154-156) + the .ref load and 200-N halo of
  * src/worker_bwt.erl:48-55.  Parses the ETF .fm, keeps only L and SA (F and I are redundant,
@@ -71,15 +97,19 @@ int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[4]);
  * bwa:find_seeds/5 (src/bwa.erl:31-45) reach -- computed once with the same LF step when the index is
  * opened, so that a task costs one table read instead of up to 14 dependent steps (K = 15 answers every
  * task; smaller K leaves 15-K steps).  Results are identical with or without it.
- * K: 0 = none (every task searched step by step), 8..15, <0 = default (env BWT_KTAB, else by index size).
+ * K: 0 = none (every task searched step by step), 8..15, <0 = default (by index size).
  * wide: 1 = the top level as 64-byte entries that also hold the first 14 SA values of the range, so that
  *   a task ending there needs no SA read and the seed kernel can cluster the read itself (64 * 4^K bytes:
- *   68.7 GB at K = 15); 0 = 8-byte entries throughout; <0 = default (env BWT_KTAB_WIDE, else on when
- *   K = 15 and it leaves >= 32 GB of HBM free).
+ *   68.7 GB at K = 15); 0 = 8-byte entries throughout; <0 = default (on when K = 15 and it leaves
+ *   >= 32 GB of HBM free).
  * Not to be called while a batch on this index is running. */
 int bwt_index_set_ktable(bwt_index *idx, int K, int wide);
 /* current K (0 = none), + 16 when the top level is wide */
 int bwt_index_ktable(const bwt_index *idx);
+/* the same with the summary bitmap of the 8-byte levels chosen explicitly: summary 0 = none, 1 = where it pays (the
+ * default), 2 = on every level (tests) */
+int bwt_index_set_ktable_ex(bwt_index *idx, int K, int wide, int summary);
+int bwt_index_set_options(bwt_index *idx, const bwt_options *opt);
 
 /* ------------------------------------------------------------------ a-13 / 8f-1: index construction
  * Replaces fm_index:make_index/4 (src/fm_index.erl:127-141) = IUPAC map + random:uniform(4) for N
@@ -223,7 +253,29 @@ typedef struct {
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);
 void bwt_batch_destroy(bwt_batch *b);
+int bwt_batch_set_options(bwt_batch *b, const bwt_options *opt);
 int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n);
+
+/* ------------------------------------------------------------------ packed reads (the host boundary's wire format)
+ * The reference hands a worker its reads as Erlang strings (src/master.erl:162-178 -> src/worker_bwt.erl:62-69); what has to
+ * cross PCIe is two bits per base.  A packed batch is the concatenated base stream (read i = bases [off[i], off[i+1]), or
+ * [i*read_len, (i+1)*read_len) when every read has the same length) as
+ *   codes  two u32 per 32 bases: codes[2w] = bit i is the LOW bit of the 2-bit code (A C G T = 0 1 2 3) of base 32w+i,
+ *          codes[2w+1] = the HIGH bits; a base outside ACGT has code 0.  bwt_packed_words(total) words, zero behind the
+ *          last base.
+ *   exc    one u64 per base outside ACGT, ascending by position: position | (uint64_t)byte << 56 (N, IUPAC codes,
+ *          anything else -- the byte is kept because sw:sigma/2 compares read bytes, src/sw.erl:164-202).
+ * 0.25 bytes per base up instead of 1 (+ 8 per read for offsets): 25 instead of 108 bytes for a 100 bp read.
+ * bwt_pack_reads (host only, no GPU) packs an ASCII stream with `threads` host threads (0 = automatic); BWT_ENOSPC +
+ * *n_exc = the count when exc_cap is too small (the codes are complete either way).
+ * bwt_batch_set_reads_packed uploads a packed batch and expands it on the device into the bit-planes every kernel reads --
+ * the same planes, bit for bit, that bwt_batch_set_reads derives from ASCII, so every result is identical.
+ * read_len > 0: uniform batch (off may be NULL); read_len == 0: off[0..n] as in bwt_batch_set_reads (off[0] = 0). */
+uint64_t bwt_packed_words(uint64_t total_bases);
+int bwt_pack_reads(const uint8_t *bases, uint64_t total_bases, uint32_t *codes, uint64_t *exc, uint64_t exc_cap,
+                   uint64_t *n_exc, uint32_t threads);
+int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, uint64_t total_bases, uint32_t n, uint32_t read_len,
+                               const uint64_t *off, const uint64_t *exc, uint64_t n_exc);
 /* runs the requested stages (a later stage implies the earlier ones) and waits for them */
 int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts);
 /* per-kernel device time of the runs since the last reset, from hipEvents recorded on the
@@ -268,38 +320,75 @@ int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint64_t *hit_o
                              int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t hit_cap, uint64_t cig_cap,
                              uint64_t needed[2]);
 
+/* The compact hit table -- the device's own format, and what crosses PCIe and xGMI.  hits[] as above, ascending by read
+ * (a read's hits adjacent, in the reference's list order); read_status one signed byte per read (values of bwt_align_batch).
+ * Most hits are "plain": square window (RefSeq = Lq bases) and CIGAR "<Lq>M" -- for those nothing else is stored:
+ *     win_len = Lq,  win_off = pos - Shift + 200 (src/worker_bwt.erl:86-94),  cigar = "<Lq>M".
+ * Every other hit has a record in extra[] (ascending by hit): its window length and its CIGAR text
+ * cigar[cig_off .. cig_off + cig_len).  needed = {hits, extras, cigar bytes}.  Any output pointer may be NULL. */
+typedef struct { uint32_t hit, win_len, cig_off, cig_len; } bwt_hit_extra;
+int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, bwt_hit_rec *hits, bwt_hit_extra *extra, char *cigar,
+                                 uint64_t hit_cap, uint64_t extra_cap, uint64_t cig_cap, uint64_t needed[3]);
+/* Host-side expansion of a compact table into the arrays of bwt_align_batch (no GPU): read_len > 0 for a uniform batch,
+ * else off[0..n] gives the read lengths.  hit_off n+1, score/pos/win_off/win_len n_hits, cig_off n_hits+1; cigar
+ * capacity cig_cap (BWT_ENOSPC + *cig_needed otherwise). */
+int bwt_hits_expand(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const bwt_hit_rec *hits, uint64_t n_hits,
+                    const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t *hit_off, int32_t *score,
+                    int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t cig_cap,
+                    uint64_t *cig_needed);
+
 /* ------------------------------------------------------------------ host-buffer pipeline
  * The worker's `running` clause as a pipeline over host buffers: `depth` slots, each with a resident batch (own HIP
  * stream), PINNED host buffers for the reads and the hit tables, and a host thread running
- *     H2D of the reads -> seed search + clustering + extension -> D2H of the hit tables,
- * so that the upload of batch k+1, the kernels of batch k and the download of batch k-1 overlap.
- *   bwt_pipe_acquire  a free slot's pinned input buffers, sized for bases_cap bytes / reads_cap reads: the caller writes the
- *                     concatenated reads and the n+1 offsets (off[0] = 0) straight into them; BWT_ENOSPC when every slot is
- *                     busy (take a result first).
- *   bwt_pipe_submit   starts the slot (asynchronous).
+ *     H2D of the packed reads -> seed search + clustering + extension -> D2H of the compact hit table,
+ * so that the upload of batch k+1, the kernels of batch k and the download of batch k-1 overlap (one upload, one batch's
+ * kernels and one download at a time).  Per 100 bp read 25 bytes go up and ~17 come back.
+ *   bwt_pipe_acquire_packed  a free slot's pinned input buffers for up to bases_cap bases / reads_cap reads / exc_cap
+ *                     exceptions: the caller writes the packed batch (format above) straight into them -- or ASCII into
+ *                     `ascii` (pageable staging of bases_cap bytes) and lets bwt_pipe_submit_ascii pack it; BWT_ENOSPC
+ *                     when every slot is busy (take a result first).
+ *   bwt_pipe_submit_packed   starts the slot (asynchronous); read_len / off as bwt_batch_set_reads_packed.
+ *   bwt_pipe_submit_ascii    packs in->ascii[0 .. off[n]) with host threads into the slot's pinned buffers, then the same.
+ *   bwt_pipe_acquire / bwt_pipe_submit   the ASCII form: pinned concatenated reads + n+1 offsets (off[0] = 0), uploaded
+ *                     as they are (108 bytes per 100 bp read on the link).
  *   bwt_pipe_wait     blocks for the OLDEST submitted batch; the pointers in *res (pinned memory) stay valid until
- *                     bwt_pipe_release(slot), which makes the slot free again.
+ *                     bwt_pipe_release(slot), which makes the slot free again.  Until then bwt_pipe_batch(slot) is the
+ *                     slot's resident batch, hit tables still in HBM (the RCCL gather copies them from there).
  * One caller thread per pipe (the handle is not re-entrant); several pipes may share an index. */
 typedef struct bwt_pipe bwt_pipe;
 typedef struct {
+    uint32_t *codes;                 /* bwt_packed_words(bases_cap) u32 */
+    uint64_t *exc;                   /* exc_cap */
+    uint64_t *off;                   /* reads_cap + 1 (only read when read_len == 0) */
+    uint8_t *ascii;                  /* bases_cap bytes of pageable staging for bwt_pipe_submit_ascii */
+    uint64_t bases_cap, exc_cap;
+    uint32_t reads_cap;
+} bwt_pipe_input;
+typedef struct {
     uint32_t slot, n_reads;
     int32_t status;                  /* 0 or the BWT_E* code of the batch */
-    uint64_t n_hits, cigar_bytes;
-    const int32_t *read_status;      /* n_reads   (as bwt_align_batch) */
-    const uint64_t *hit_off;         /* n_reads+1 */
-    const bwt_hit_rec *hits;         /* n_hits    */
-    const int64_t *win_off;          /* n_hits    */
-    const int32_t *win_len;          /* n_hits    */
-    const uint64_t *cig_off;         /* n_hits+1  */
-    const char *cigar;               /* cigar_bytes */
+    uint32_t read_len;               /* > 0: every read of the batch has this length */
+    uint64_t n_hits, n_extra, cigar_bytes;
+    const int8_t *read_status;       /* n_reads   (values as bwt_align_batch) */
+    const bwt_hit_rec *hits;         /* n_hits, ascending by read */
+    const bwt_hit_extra *extra;      /* n_extra, ascending by hit */
+    const char *cigar;               /* cigar_bytes: the text of the extras */
     bwt_batch_counts counts;
 } bwt_pipe_result;
 int bwt_pipe_create(bwt_index *idx, uint32_t depth /* 1..8 */, bwt_pipe **out);
 void bwt_pipe_destroy(bwt_pipe *p);
+int bwt_pipe_set_options(bwt_pipe *p, const bwt_options *opt);
+/* per-kernel device time of the slots' batches (bwt_batch_profile / bwt_batch_kernel_times summed over the slots) */
+int bwt_pipe_profile(bwt_pipe *p, int enable);
+int bwt_pipe_kernel_times(bwt_pipe *p, char *names, uint32_t names_cap, double *ms, uint64_t *launches, uint32_t cap);
+int bwt_pipe_acquire_packed(bwt_pipe *p, uint64_t bases_cap, uint32_t reads_cap, uint64_t exc_cap, bwt_pipe_input *in, uint32_t *slot);
+int bwt_pipe_submit_packed(bwt_pipe *p, uint32_t slot, uint32_t n_reads, uint32_t read_len, uint64_t total_bases, uint64_t n_exc);
+int bwt_pipe_submit_ascii(bwt_pipe *p, uint32_t slot, uint32_t n_reads, uint32_t read_len);
 int bwt_pipe_acquire(bwt_pipe *p, uint64_t bases_cap, uint32_t reads_cap, uint8_t **bases, uint64_t **off, uint32_t *slot);
 int bwt_pipe_submit(bwt_pipe *p, uint32_t slot, uint32_t n_reads);
 int bwt_pipe_wait(bwt_pipe *p, bwt_pipe_result *res);
 int bwt_pipe_release(bwt_pipe *p, uint32_t slot);
+bwt_batch *bwt_pipe_batch(bwt_pipe *p, uint32_t slot);
 
 /* ------------------------------------------------------------------ the whole job for one FASTQ file
  * What the reference's master and one worker do (src/master.erl:162-178 workload production, src/worker_bwt.erl:73-112 the

@@ -111,3 +111,86 @@ def test_native_check_refuses_what_is_not_an_index(tmp_path):
     with pytest.raises(lib.BwtError) as e:
         lib.native_check(str(tmp_path / "missing.bwtgpu"))
     assert e.value.code == -5
+
+
+def test_library_never_reads_the_environment():
+    """Which kernels run is decided by bwt_options (include/bwt_gpu.h), not by ambient variables: the only getenv calls left in
+    the product's sources are debug prints (BWT_*_DEBUG), none of them in the translation unit that launches kernels."""
+    src_dir = os.path.join(ROOT, "bwt_amd", "csrc")
+    for fn in os.listdir(src_dir):
+        if not fn.endswith((".hip", ".cpp", ".h")):
+            continue
+        text = open(os.path.join(src_dir, fn), errors="replace").read()
+        for m in re.finditer(r'getenv\("([A-Z_0-9]+)"\)', text):
+            assert m.group(1).endswith("_DEBUG"), (fn, m.group(1))
+        if fn in ("bwt_gpu.hip", "kernels.hip.h", "pipe.cpp", "pack.cpp", "index_build.hip", "fs_seeds.hip"):
+            assert "getenv" not in text, fn
+
+
+def test_options_struct_round_trip():
+    from bwt_amd import lib
+    o = lib.make_options()
+    assert o.struct_size == 4 * (1 + len(lib.OPTION_FIELDS)) and all(getattr(o, k) == -1 for k in lib.OPTION_FIELDS)
+    o = lib.make_options(sw_band=0, sw_band_min=7)
+    assert (o.sw_band, o.sw_band_min, o.seed_fast) == (0, 7, -1)
+    assert lib.options_from_env({"BWT_SW_WAVE": "0", "BWT_SEED_BIG": "1", "BWT_KTAB": "9", "HOME": "/"}) == {"sw_wave": 0, "seed_big": 1}
+    with pytest.raises(KeyError):
+        lib.make_options(no_such_switch=1)
+
+
+def _pack_reference(bases):
+    """numpy restatement of the packed wire format (include/bwt_gpu.h)"""
+    import numpy as np
+    code = np.full(256, 255, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+    c = code[bases]
+    bad = np.nonzero(c == 255)[0]
+    c = np.where(c == 255, 0, c).astype(np.uint8)
+    nw = (len(bases) + 31) // 32
+    pad = np.zeros(nw * 32, np.uint8); pad[:len(c)] = c
+    lo = np.packbits((pad & 1).reshape(nw, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
+    hi = np.packbits((pad >> 1).reshape(nw, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
+    codes = np.empty(2 * nw, np.uint32); codes[0::2] = lo; codes[1::2] = hi
+    exc = bad.astype(np.uint64) | (bases[bad].astype(np.uint64) << np.uint64(56))
+    return codes, exc
+
+
+@pytest.mark.parametrize("total", [0, 1, 7, 31, 32, 33, 100, 4097, 3_000_001])
+def test_pack_reads_matches_the_format(total):
+    """bwt_pack_reads (host only): code words and exception list of random streams with N, IUPAC and arbitrary bytes, at lengths
+    around the word and group boundaries, single- and multi-threaded."""
+    import numpy as np
+    from bwt_amd import lib
+    rng = np.random.default_rng(total + 5)
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, total, dtype=np.uint8)].copy()
+    if total:
+        k = max(1, total // 50)
+        bases[rng.integers(0, total, k)] = np.frombuffer(b"NNNNRYKMSWBDVHacgtn\x00\xff@", np.uint8)[rng.integers(0, 22, k)]
+    want_c, want_e = _pack_reference(bases)
+    for threads in (1, 0, 5):
+        codes, exc = lib.pack_2bit(bases, threads)
+        assert len(codes) == len(want_c) + 2 and np.array_equal(codes[:len(want_c)], want_c) and not codes[len(want_c):].any()
+        assert np.array_equal(exc, want_e)
+
+
+def test_hits_expand_on_the_host():
+    """bwt_hits_expand: plain hits get "<Lq>M" on a window of Lq bases at pos - Shift + 200, extras their own text and window."""
+    import numpy as np
+    from bwt_amd import lib
+    hits = np.array([(0, 200, 1000), (2, 190, 50), (2, 188, 5000), (5, 140, -3)], lib.HIT_REC)
+    extra = np.array([(1, 103, 0, 7), (3, 73, 7, 8)], lib.HIT_EXTRA)
+    text = b"50M3D50" + b"30M2I41M"
+    off = np.array([0, 100, 200, 300, 400, 500, 573], np.uint64)
+    out = lib.hits_expand(6, 0, off, 7, hits, extra, text)
+    assert out["hit_off"].tolist() == [0, 1, 1, 3, 3, 3, 4]
+    assert out["score"].tolist() == [200, 190, 188, 140] and out["pos"].tolist() == [1000, 50, 5000, -3]
+    assert out["win_off"].tolist() == [1193, 243, 5193, 190] and out["win_len"].tolist() == [100, 103, 100, 73]
+    cig = [out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])] for h in range(4)]
+    assert cig == [b"100M", b"50M3D50", b"100M", b"30M2I41M"]
+    same = lib.hits_expand(6, 100, None, 7, hits[:3], extra[:1], text)
+    assert same["win_len"].tolist() == [100, 103, 100] and same["hit_off"].tolist() == [0, 1, 1, 3, 3, 3, 3]
+    with pytest.raises(lib.BwtError):                          # an extra that names no hit
+        lib.hits_expand(6, 100, None, 7, hits[:1], extra[:1], text)
+    with pytest.raises(lib.BwtError):                          # hits out of order
+        lib.hits_expand(6, 100, None, 7, hits[::-1].copy(), extra[:0], text)

@@ -34,20 +34,24 @@ def check_against_oracle(out, reads, orc_fm, ref1):
     return nh
 
 
-MODES = [{"BWT_SEED_BIG": "1"}, {"BWT_KTAB_SUMMARY": "2"}, {"BWT_KTAB_SUMMARY": "0"}, {"BWT_SW_BAND": "0"}, {"BWT_SW_BAND_MIN": "0"}, {"BWT_SW_BAND_MIN": "0", "BWT_SW_WAVE": "0"}, {"BWT_SEED_FUSE": "0"}, {"BWT_SW_PREFILTER": "0"}, {"BWT_SW_PK": "0"}, {"BWT_SW_LDS": "0"},
-         {"BWT_SW_TRACE_ALL": "0", "BWT_SW_WAVE": "0"}, {"BWT_SW_WAVE": "0", "BWT_SW_PREFILTER": "0"},
-         {"BWT_SEARCH_ILP": "2"}]
+# every execution option of bwt_options (include/bwt_gpu.h) that selects between equivalent kernels, and the table's summary bitmap
+MODES = [{"seed_big": 1}, {"ktab_summary": 2}, {"ktab_summary": 0}, {"sw_band": 0}, {"sw_band_min": 0}, {"sw_band_min": 0, "sw_wave": 0},
+         {"seed_fuse": 0}, {"sw_prefilter": 0}, {"sw_pk": 0}, {"sw_lds": 0}, {"sw_trace_all": 0, "sw_wave": 0},
+         {"sw_wave": 0, "sw_prefilter": 0}, {"search_ilp": 2}, {"seed_fast": 0}, {"sw_fuse_cand": 0}]
 
 
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: ",".join("%s=%s" % kv for kv in m.items()))
 @pytest.mark.parametrize("K", ["15w", 0])
-def test_experiment_switches_keep_parity(gpu_index, orc_fm, ref_bytes, monkeypatch, mode, K):
+def test_experiment_switches_keep_parity(gpu_index, orc_fm, ref_bytes, mode, K):
+    """The options go in through bwt_index_set_options (the batches of the host-buffer entry points take the index's) -- the
+    library itself never reads the environment (tests/test_abi.py checks that)."""
     from bwt_amd import lib
     from oracle import erl_literal as E
-    for k, v in mode.items():
-        monkeypatch.setenv(k, v)
+    mode = dict(mode)
+    summary = mode.pop("ktab_summary", 1)
     wide = isinstance(K, str)
-    gpu_index.set_ktable(15 if wide else K, 1 if wide else 0)
+    gpu_index.set_ktable(15 if wide else K, 1 if wide else 0, summary)
+    gpu_index.set_options(**mode)
     try:
         ref1 = E.make_ref1(ref_bytes)
         reads = (synth_reads(ref_bytes, 500, 100, 301, max_subs=3) + synth_reads(ref_bytes, 250, 100, 302, indel_frac=1.0) +
@@ -56,6 +60,7 @@ def test_experiment_switches_keep_parity(gpu_index, orc_fm, ref_bytes, monkeypat
         out = gpu_index.align_batch(bases, off)
         assert check_against_oracle(out, reads, orc_fm, ref1) > 300
     finally:
+        gpu_index.set_options()
         gpu_index.set_ktable(-1)
 
 
@@ -126,7 +131,7 @@ def test_set_ktable_waits_for_running_batches(gpu_index, orc_fm, ref_bytes):
 
 
 @pytest.mark.parametrize("length", [103, 100])
-def test_fast_seed_kernel_against_general_and_oracle(monkeypatch, length):
+def test_fast_seed_kernel_against_general_and_oracle(length):
     """k_seed_fast (uniform read length, K = 15 wide table) with reads that make it hand groups back (N, IUPAC, repeats
     with many seeds / clusters): same hit tables as the general kernel alone, and the oracle's answers.  103-bp reads:
     every sub-read has >= 15 bases (all tasks end in the table's top level); 100-bp reads on this small genome: the
@@ -154,8 +159,8 @@ def test_fast_seed_kernel_against_general_and_oracle(monkeypatch, length):
         packed = lib.pack_reads(reads)
         outs = {}
         for fast in ("1", "0"):
-            monkeypatch.setenv("BWT_SEED_FAST", fast)
             b = lib.Batch(ix)
+            b.set_options(seed_fast=int(fast))
             b.set_reads(*packed)
             c = b.run(lib.STAGE_EXTEND)
             outs[fast] = (b.fetch_hits(), c)
@@ -174,31 +179,54 @@ def test_fast_seed_kernel_against_general_and_oracle(monkeypatch, length):
         ix.close()
 
 
-def test_pipe_overlapped_batches_equal_align_batch(gpu_index, ref_bytes):
-    """bwt_pipe: six batches of different sizes through a pipe of depth 3 (pinned buffers, a host thread and a HIP stream per
-    slot): results come back in submission order and equal bwt_align_batch's, empty batch included."""
+@pytest.mark.parametrize("form", ["packed", "ascii_staging", "ascii_pinned"])
+def test_pipe_overlapped_batches_equal_align_batch(gpu_index, ref_bytes, form):
+    """bwt_pipe: seven batches of different sizes through a pipe of depth 3 (pinned buffers, a host thread and a HIP stream per
+    slot), the reads going up in each of the three input forms -- packed by the caller (2 bits per base + exceptions), ASCII left in
+    the slot's staging buffer and packed by the pipe, ASCII uploaded as it is; the compact hit tables that come back, expanded on
+    the host, equal bwt_align_batch's arrays, in submission order, empty and ragged batches included."""
     from bwt_amd import lib
-    sets = [synth_reads(ref_bytes, n, 100, 700 + i, indel_frac=0.2, n_frac=0.05) for i, n in enumerate((900, 1, 0, 1500, 300, 700))]
+    sets = [synth_reads(ref_bytes, n, 100, 700 + i, indel_frac=0.2, n_frac=0.05, iupac_frac=0.03) for i, n in enumerate((900, 1, 0, 1500, 300, 700))]
+    sets.append(synth_reads(ref_bytes, 200, 100, 790, indel_frac=0.3) + synth_reads(ref_bytes, 150, 73, 791, n_frac=0.2) + synth_reads(ref_bytes, 50, 151, 792))
     packed = [lib.pack_reads(s) for s in sets]
     want = [gpu_index.align_batch(*p) for p in packed]
     pipe = lib.Pipe(gpu_index, depth=3)
-    got, nxt, inflight = [], 0, 0
+    got, nxt = [], 0
     try:
         while len(got) < len(sets):
             slot = None
             if nxt < len(sets):
-                slot = pipe.acquire(len(packed[nxt][0]), len(sets[nxt]))
+                bases, off = packed[nxt]
+                n, total = len(sets[nxt]), len(bases)
+                uniform = 100 if nxt < 6 else 0
+                if form == "ascii_pinned":
+                    slot = pipe.acquire(total, n)
+                    if slot is not None:
+                        s, pb, po = slot
+                        pb[:total] = bases
+                        po[:] = off
+                        pipe.submit(s, n)
+                else:
+                    codes, exc = lib.pack_2bit(bases)
+                    slot = pipe.acquire_packed(total, n, len(exc))
+                    if slot is not None:
+                        s, v = slot
+                        v["off"][:] = off
+                        if form == "packed":
+                            v["codes"][:len(codes)] = codes
+                            v["exc"][:len(exc)] = exc
+                            pipe.submit_packed(s, n, uniform, total, len(exc))
+                        else:
+                            v["ascii"][:total] = bases
+                            pipe.submit_ascii(s, n, uniform)
             if slot is not None:
-                s, pb, po = slot
-                pb[:len(packed[nxt][0])] = packed[nxt][0]
-                po[:] = packed[nxt][1]
-                pipe.submit(s, len(sets[nxt]))
-                nxt += 1; inflight += 1
+                nxt += 1
                 continue
             r = pipe.wait()                                    # every slot busy (or nothing left to submit): take the oldest result
-            got.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()})
+            g = pipe.expand(r, packed[len(got)][1])
+            g["counts"] = r["counts"]; g["n_extra"] = len(r["extra"])
+            got.append(g)
             pipe.release(r["slot"])
-            inflight -= 1
         assert pipe.acquire(16, 1) is not None                 # all slots free again
     finally:
         pipe.close()
@@ -207,6 +235,8 @@ def test_pipe_overlapped_batches_equal_align_batch(gpu_index, ref_bytes):
             assert np.array_equal(g[k], w[k]), k
         assert g["cigar"] == w["cigar"]
         assert g["counts"]["n_hits"] == len(w["score"])
+    # most hits of the big batches are plain (no extra record), the reads with indels are not
+    assert 0 < got[3]["n_extra"] < got[3]["counts"]["n_hits"]
 
 
 @pytest.fixture(scope="module")
@@ -229,7 +259,7 @@ def repeat_index():
 
 
 @pytest.mark.parametrize("length", [64, 71, 72, 89, 96, 111, 112, 120, 128, 150, 168, 175])
-def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
+def test_fast_seed_kernel_read_lengths(repeat_index, length):
     """Every number of sub-reads per read the fast seed kernel takes (8..21: 8..3 reads per wave pass), in both variants
     (one / two registers per read), against the oracle -- with reads from a repeat (many seeds, several clusters), indels, N."""
     from bwt_amd import lib
@@ -240,8 +270,8 @@ def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
     packed = lib.pack_reads(reads)
     kept = []
     for big in ("0", "1"):
-        monkeypatch.setenv("BWT_SEED_BIG", big)
         b = lib.Batch(ix)
+        b.set_options(seed_big=int(big))
         b.set_reads(*packed)
         c = b.run(lib.STAGE_EXTEND)
         out = b.fetch_hits()
@@ -255,18 +285,18 @@ def test_fast_seed_kernel_read_lengths(repeat_index, monkeypatch, length):
 
 
 @pytest.mark.parametrize("length", [48, 64, 100, 150, 175, 400])
-def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_bytes, length, monkeypatch):
+def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_bytes, length):
     """k_sw_band runs the DP on 20 (then 32) diagonals around the cluster and keeps its result only when the best score proves that
     nothing outside the band can matter (kernels.hip.h); everything else goes on to the full-rectangle kernels.
     Reads with one indel and up to 4 substitutions (most are settled by the band), reads with up to 14 substitutions (few are):
     every answer must be the oracle's, and both routes must have been taken."""
     from bwt_amd import lib
     from oracle import erl_literal as E
-    monkeypatch.setenv("BWT_SW_BAND_MIN", "0")                  # (queues this short are k_sw_wave's otherwise)
     ref1 = E.make_ref1(ref_bytes)
     reads = (synth_reads(ref_bytes, 500, length, 900 + length, max_subs=4, indel_frac=1.0) +
              synth_reads(ref_bytes, 300, length, 901 + length, max_subs=14, indel_frac=0.5))
     b = lib.Batch(gpu_index)
+    b.set_options(sw_band_min=0)                                # (queues this short are k_sw_wave's otherwise)
     try:
         b.set_reads(*lib.pack_reads(reads))
         c = b.run(lib.STAGE_EXTEND)
@@ -274,7 +304,7 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
         assert check_against_oracle(out, reads, orc_fm, ref1) > 200
         assert c["n_banded"] > 100 and c["n_dp"] > c["n_banded"], c
         # the same batch without the band: the same tables
-        monkeypatch.setenv("BWT_SW_BAND", "0")
+        b.set_options(sw_band_min=0, sw_band=0)
         c0 = b.run(lib.STAGE_EXTEND)
         out0 = b.fetch_hits()
         assert c0["n_banded"] == 0 and c0["n_dp"] == c["n_dp"]
@@ -314,7 +344,7 @@ def tandem_index():
 
 
 @pytest.mark.parametrize("length", [100, 150])
-def test_banded_dp_in_tandem_repeats(tandem_index, monkeypatch, length):
+def test_banded_dp_in_tandem_repeats(tandem_index, length):
     from bwt_amd import lib
     ix, ref, regions, ofm, ref1 = tandem_index
     rng = np.random.default_rng(99 + length)
@@ -336,15 +366,15 @@ def test_banded_dp_in_tandem_repeats(tandem_index, monkeypatch, length):
             for _ in range(int(rng.integers(0, 3))):
                 q[int(rng.integers(0, length))] = int(rng.choice(list(b"ACGT")))
             reads.append(bytes(q))
-    monkeypatch.setenv("BWT_SW_BAND_MIN", "0")
     b = lib.Batch(ix)
+    b.set_options(sw_band_min=0)
     try:
         b.set_reads(*lib.pack_reads(reads))
         c = b.run(lib.STAGE_EXTEND)
         out = b.fetch_hits()
         assert check_against_oracle(out, reads, ofm, ref1) > 200
         assert c["n_banded"] > 100, c
-        monkeypatch.setenv("BWT_SW_BAND", "0")
+        b.set_options(sw_band_min=0, sw_band=0)
         b.run(lib.STAGE_EXTEND)
         out0 = b.fetch_hits()
         for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):

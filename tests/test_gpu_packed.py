@@ -1,0 +1,164 @@
+"""GPU tests of the host boundary's wire formats (include/bwt_gpu.h): reads uploaded PACKED (2 bits per base + exception list,
+expanded to the bit-planes on the device) and hits fetched COMPACT (16-byte records + extras) give, bit for bit, what the ASCII
+upload and the per-hit tables give -- and what the oracle says (the worker loop of src/worker_bwt.erl:73-106)."""
+import numpy as np
+import pytest
+
+from conftest import synth_reads
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off")
+
+
+def oracle_check(out, reads, ofm, ref1):
+    from oracle import orc
+    nh = 0
+    for i, q in enumerate(reads):
+        a, b = int(out["hit_off"][i]), int(out["hit_off"][i + 1])
+        try:
+            exp = orc.align_read(ofm, ref1, q)
+        except RuntimeError:               # the reference crashes on this read (a sub-read ending outside ACGTN; a window outside Ref1)
+            assert out["read_status"][i] < 0 and a == b
+            continue
+        if exp is None:
+            assert out["read_status"][i] == 1 and a == b
+            continue
+        got = [(int(out["score"][h]), out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode(), int(out["pos"][h]),
+                int(out["win_off"][h]), int(out["win_len"][h])) for h in range(a, b)]
+        assert got == exp, (i, q)
+        nh += len(exp)
+    return nh
+
+
+def mixed(ref, length, seed, n=1200):
+    return (synth_reads(ref, n, length, seed, max_subs=3) + synth_reads(ref, n // 3, length, seed + 1, indel_frac=1.0) +
+            synth_reads(ref, n // 6, length, seed + 2, n_frac=1.0) + synth_reads(ref, n // 6, length, seed + 3, iupac_frac=1.0) +
+            [b"N" * length, b"ACGT" * (length // 4) + b"A" * (length % 4), ref[:length], ref[-length:]])
+
+
+@pytest.mark.parametrize("opts", [{}, {"sw_prefilter": 0}, {"sw_wave": 0, "sw_band": 0}, {"seed_fast": 0}], ids=str)
+@pytest.mark.parametrize("length", [100, 150, 67])
+def test_packed_upload_equals_ascii_upload_and_oracle(gpu_index, orc_fm, ref_bytes, length, opts):
+    """One batch of one read length, uploaded both ways: identical tables, the oracle's answers.  Reads with N and IUPAC codes
+    (exceptions), indels (DP kernels that read the read's BYTES: made from the planes for queued candidates only, or for the
+    whole batch when no prefilter runs), reads that are all N."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = mixed(ref_bytes, length, 1300 + length)
+    bases, off = lib.pack_reads(reads)
+    codes, exc = lib.pack_2bit(bases)
+    assert len(exc) > 100
+    a = lib.Batch(gpu_index); a.set_options(**opts)
+    a.set_reads(bases, off)
+    ca = a.run(lib.STAGE_EXTEND)
+    want = a.fetch_hits()
+    p = lib.Batch(gpu_index); p.set_options(**opts)
+    p.set_reads_packed(codes, exc, len(reads), read_len=length)
+    cp = p.run(lib.STAGE_EXTEND)
+    got = p.fetch_hits()
+    for k in KEYS:
+        assert np.array_equal(got[k], want[k]), k
+    assert got["cigar"] == want["cigar"]
+    for k in ("n_tasks", "n_clusters", "n_hits", "cigar_bytes", "sw_cells", "n_float", "n_dp"):
+        assert ca[k] == cp[k], k
+    assert oracle_check(got, reads, orc_fm, ref1) > 500
+    # the compact table of the same run, expanded on the host, is the same again
+    c = p.fetch_hits_compact()
+    ex = lib.hits_expand(len(reads), length, None, gpu_index.meta()[1], c["hits"], c["extra"], c["cigar"])
+    for k in KEYS[1:]:
+        assert np.array_equal(ex[k], want[k]), k
+    assert ex["cigar"] == want["cigar"] and np.array_equal(c["read_status"].astype(np.int32), want["read_status"])
+    # substitutions only: plain; indels / N: extras (only the prefilter settles hits as plain)
+    assert 0 < len(c["extra"]) <= len(c["hits"]) and (len(c["extra"]) < len(c["hits"]) or opts.get("sw_prefilter") == 0)
+    a.destroy(); p.destroy()
+
+
+def test_packed_upload_ragged_batch_and_reuse(gpu_index, orc_fm, ref_bytes):
+    """Reads of different lengths (offsets go up with the codes), an empty batch, and a batch object reused for ASCII after packed."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = (synth_reads(ref_bytes, 300, 100, 41, indel_frac=0.3, n_frac=0.1) + synth_reads(ref_bytes, 200, 48, 42) +
+             synth_reads(ref_bytes, 100, 333, 43, max_subs=6, iupac_frac=0.2) + [b"ACGTACG", b"", b"N"])
+    rng = np.random.default_rng(5)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    bases, off = lib.pack_reads(reads)
+    codes, exc = lib.pack_2bit(bases)
+    b = lib.Batch(gpu_index)
+    b.set_reads_packed(codes, exc, len(reads), off=off)
+    b.run(lib.STAGE_EXTEND)
+    got = b.fetch_hits()
+    assert oracle_check(got, reads, orc_fm, ref1) > 300
+    c = b.fetch_hits_compact()
+    ex = lib.hits_expand(len(reads), 0, off, gpu_index.meta()[1], c["hits"], c["extra"], c["cigar"])
+    for k in KEYS[1:]:
+        assert np.array_equal(ex[k], got[k]), k
+    assert ex["cigar"] == got["cigar"]
+    # empty packed batch
+    b.set_reads_packed(np.zeros(2, np.uint32), np.zeros(0, np.uint64), 0, read_len=100)
+    assert b.run(lib.STAGE_EXTEND)["n_hits"] == 0
+    e = b.fetch_hits_compact()
+    assert len(e["hits"]) == 0 and len(e["extra"]) == 0 and len(e["read_status"]) == 0
+    # ... and the same object with an ASCII batch again
+    b.set_reads(bases, off)
+    b.run(lib.STAGE_EXTEND)
+    again = b.fetch_hits()
+    for k in KEYS:
+        assert np.array_equal(again[k], got[k]), k
+    b.destroy()
+
+
+def test_packed_upload_rejects_bad_input(gpu_index):
+    from bwt_amd import lib
+    bases, off = lib.pack_reads([b"ACGTACGTAC" * 10] * 4)
+    codes, exc = lib.pack_2bit(bases)
+    b = lib.Batch(gpu_index)
+    with pytest.raises(lib.BwtError) as e:                            # an exception that is no exception
+        b.set_reads_packed(codes, np.array([5 | (ord("A") << 56)], np.uint64), 4, read_len=100)
+    assert e.value.code == -22
+    with pytest.raises(lib.BwtError) as e:                            # ... behind the last base
+        b.set_reads_packed(codes, np.array([400 | (ord("N") << 56)], np.uint64), 4, read_len=100)
+    assert e.value.code == -22
+    with pytest.raises(lib.BwtError):                                 # n * read_len != total
+        b.set_reads_packed(codes, exc, 4, read_len=99, total=400)
+    with pytest.raises(lib.BwtError):                                 # ragged without offsets
+        b.set_reads_packed(codes, exc, 4, read_len=0, total=400)
+    bad = off.copy(); bad[2] = 50                                     # decreasing offsets
+    with pytest.raises(lib.BwtError):
+        b.set_reads_packed(codes, exc, 4, off=bad)
+    b.set_reads_packed(codes, exc, 4, read_len=100)                   # the batch is still usable
+    assert b.run(lib.STAGE_EXTEND)["n_reads"] == 4
+    b.destroy()
+
+
+def test_compact_table_on_a_repeat_genome():
+    """Reads with many hits each (a 300-bp segment in 40 copies): the compact table keeps the reference's list order inside a read,
+    extras stay ascending by hit, and expansion equals the per-hit fetch."""
+    from bwt_amd import lib
+    rng = np.random.default_rng(77)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 1_500_000, dtype=np.uint8)].tobytes())
+    seg = bytes(g[5000:5300])
+    for k in range(1, 40):
+        g[30_000 * k:30_000 * k + 300] = seg
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=1)
+    try:
+        reads = [bytes(seg[i:i + 100]) for i in range(0, 200, 3)] + synth_reads(ref, 400, 100, 9, indel_frac=0.5)
+        bases, off = lib.pack_reads(reads)
+        codes, exc = lib.pack_2bit(bases)
+        b = lib.Batch(ix)
+        b.set_reads_packed(codes, exc, len(reads), read_len=100)
+        c = b.run(lib.STAGE_EXTEND)
+        full = b.fetch_hits()
+        comp = b.fetch_hits_compact()
+        assert c["n_hits"] == len(comp["hits"]) > 40 * 60
+        assert np.all(np.diff(comp["hits"]["read"].astype(np.int64)) >= 0) and np.all(np.diff(comp["extra"]["hit"].astype(np.int64)) > 0)
+        ex = lib.hits_expand(len(reads), 100, None, 1, comp["hits"], comp["extra"], comp["cigar"])
+        for k in KEYS[1:]:
+            assert np.array_equal(ex[k], full[k]), k
+        assert ex["cigar"] == full["cigar"]
+        b.destroy()
+    finally:
+        ix.close()

@@ -258,19 +258,19 @@ def test_bench_gather_path_single_rank():
 
 @pytest.mark.parametrize("wave_dp", ["1", "0"])          # short DP queues: wave-per-alignment kernel / packed kernels
 @pytest.mark.parametrize("length", [100, 150])
-def test_align_uniform_length_fast_path(gpu_index, orc_fm, ref_bytes, length, wave_dp, monkeypatch):
+def test_align_uniform_length_fast_path(gpu_index, orc_fm, ref_bytes, length, wave_dp):
     """Batches of one read length take the packed-i16 extend kernels (k_sw_pk<100|150>) or, for a short DP queue,
     the wave-per-alignment kernel (k_sw_wave): substitutions are settled by the prefilter, indels run the traced DP,
     N goes to the fp64 pass."""
     from bwt_amd import lib
     from oracle import orc, erl_literal as E
-    monkeypatch.setenv("BWT_SW_WAVE", wave_dp)
     ref1 = E.make_ref1(ref_bytes)
     reads = (synth_reads(ref_bytes, 1500, length, 61 + length, max_subs=3) +
              synth_reads(ref_bytes, 700, length, 62 + length, indel_frac=1.0) +
              synth_reads(ref_bytes, 200, length, 63 + length, n_frac=1.0))
     bases, off = lib.pack_reads(reads)
     b = lib.Batch(gpu_index)
+    b.set_options(sw_wave=int(wave_dp))
     b.set_reads(bases, off)
     counts = b.run(lib.STAGE_EXTEND)
     out = b.fetch_hits()
