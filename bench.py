@@ -4,9 +4,15 @@
     python bench.py --gpus N --steps K --warmup W [--workload grch38|chr1|config2|config2-align]
 
 One process per GPU (torch.distributed / RCCL for N > 1; the driver launches the ranks).  A "step"
-is one pass of the hot path over one batch of synthetic reads that is already resident in HBM.
+is one batch of synthetic reads through the hot path AT THE HOST BOUNDARY ("reads submitted /
+wall time from the first H2D copy to the last gathered hit"; the reference's own boundary is host strings
+in, casts out: src/master.erl:162-178 -> src/worker_bwt.erl:62-69): the packed reads of the batch sit in
+pinned host memory, go up over PCIe, run seed search + clustering + extension, and the compact hit table
+comes back into pinned host memory (bwt_pipe: depth 3, upload / kernels / download of consecutive batches
+overlapped).  `value` is that rate; the rate with the reads already resident in HBM (what rounds 1-2
+reported as `value`) is measured beside it and reported as `resident`.  The index is resident throughout.
 Rank 0 prints ONE JSON line.  Weak scaling: every GPU gets its own slab of reads, the index is
-replicated, and the only collective is the per-step gather of the 16-byte hit records to rank 0.
+replicated, and the only collective is the per-step gather of the compact hit tables to rank 0.
 
 Workloads (BASELINE.json configs):
   grch38 (default)  configs[3] at N GPUs: whole-GRCh38-SCALE FM index (3.1e9 rows) resident in HBM,
@@ -82,10 +88,10 @@ def synth_reads(ref, n, length, seed, max_subs, indel_p=0.0):
     return out, off
 
 
-def parity_sample(batch, ofm, ref1, bases, off, length, n=2000):
-    """Hits of the LAST timed step for the first n reads, compared one by one with the CPU oracle."""
+def parity_sample(out, ofm, ref1, bases, off, length, n=2000):
+    """Hits of the LAST timed step (the table that came back over the host boundary) for the first n reads, compared one by one
+    with the CPU oracle."""
     from oracle import orc
-    out = batch.fetch_hits()
     bad = 0
     for i in range(min(n, len(off) - 1)):
         q = bases[i * length:(i + 1) * length].tobytes()
@@ -101,7 +107,7 @@ def parity_sample(batch, ofm, ref1, bases, off, length, n=2000):
     return {"reads": min(n, len(off) - 1), "mismatching_reads": bad}
 
 
-def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
+def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, hits=None):
     """The oracle's C restatement (literal linear-scan se_down/se_up over the L and I columns,
     full-rectangle SW with the per-row abort) timed on this host's cores on a bounded sample of the
     same reads.  kind = "port": the reference is Erlang and cannot run here.  The index COLUMNS (L, SA)
@@ -128,11 +134,10 @@ def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
            "sample": "first %d reads of the bench batch (%d passes, %d reads in all), %s, %d threads, %.1f s" %
                      (n, reps, done, "sga (search+cluster)" if mode == 0 else "search+cluster+SW", cores, dt),
            "checksum": int(res[3])}
-    if batch is not None and mode == 1:
-        out["parity_sample"] = parity_sample(batch, ofm, ref1, bases, off, length)
+    if hits is not None and mode == 1:
+        out["parity_sample"] = parity_sample(hits, ofm, ref1, bases, off, length)
         # at-scale parity: the oracle's aggregate over the whole CPU sample (reads with a hit, hits kept,
         # sum of 31*pos + score) against the same aggregate of the GPU's hit table for those reads
-        hits = batch.fetch_hits()
         a, b = int(hits["hit_off"][0]), int(hits["hit_off"][n])
         gpu = [int((np.diff(hits["hit_off"][: n + 1].astype(np.int64)) > 0).sum()), b - a,
                int((hits["pos"][a:b].astype(np.int64) * 31 + hits["score"][a:b].astype(np.int64)).sum())]
@@ -141,44 +146,75 @@ def cpu_baseline(ix, ref, bases, off, length, mode, budget_s=12.0, batch=None):
     return out
 
 
-def host_pipeline(ix, read_sets, n_reads, depth=3, rounds=12):
-    """The host-buffer boundary as a pipeline (bwt_pipe): reads in PINNED host memory in, hit tables in pinned host memory
-    out, H2D + kernels + D2H of consecutive batches overlapped on `depth` slots.  Each slot's input buffers are filled once
-    (a FASTQ parser would write there); every submit uploads them again.  Never `value`."""
-    from bwt_amd import lib
-    pipe = lib.Pipe(ix, depth=depth)
-    nb = len(read_sets[0][0])
-    filled = set()
+class HostPipeline:
+    """The host boundary as the bench drives it: bwt_pipe with `depth` slots.  A slot's pinned input buffers are filled ONCE with
+    the packed form of one of the read sets (where a FASTQ reader / the NIF would pack every batch; profiles/r3 holds the packer's
+    own rate) and every submit uploads them again; every result is the compact hit table in pinned host memory."""
 
-    def submit_next():
-        s, pb, po = pipe.acquire(nb, n_reads)
-        if s not in filled:
-            bases, off = read_sets[s % len(read_sets)]
-            pb[:nb] = bases
-            po[:] = off
-            filled.add(s)
-        pipe.submit(s, n_reads)
+    def __init__(self, ix, packed_sets, n_reads, length, depth=3, options=None, on_result=None):
+        from bwt_amd import lib
+        self.lib, self.pipe, self.sets, self.n, self.length, self.depth = lib, lib.Pipe(ix, depth=depth), packed_sets, n_reads, length, depth
+        if options:
+            self.pipe.set_options(**options)
+        self.filled = {}
+        self.on_result = on_result
+        self.last = None                    # (read set, expanded per-hit arrays) of the last batch taken when keep_last is set
+        self.keep_last = False
+        self.held = None
+        self.done_at = []
+        self.stage_ms, self.stage_n = {}, 0
 
-    def run(k):
+    def submit_next(self):
+        total = self.n * self.length
+        codes, exc = self.sets[0]
+        got = self.pipe.acquire_packed(total, self.n, max(len(e) for _, e in self.sets))
+        if got is None:
+            return False
+        s, v = got
+        if s not in self.filled:
+            k = s % len(self.sets)
+            codes, exc = self.sets[k]
+            v["codes"][:len(codes)] = codes
+            v["exc"][:len(exc)] = exc
+            self.filled[s] = k
+        k = self.filled[s]
+        self.pipe.submit_packed(s, self.n, self.length, total, len(self.sets[k][1]))
+        return True
+
+    def run(self, k):
         submitted = done = hits = 0
+        counts = None
         while done < k:
-            while submitted < k and submitted - done < depth:
-                submit_next(); submitted += 1
-            r = pipe.wait()
-            hits += int(r["counts"]["n_hits"])
-            pipe.release(r["slot"])
+            while submitted < k and submitted - done < self.depth and self.submit_next():
+                submitted += 1
+            r = self.pipe.wait()
+            counts = r["counts"]
+            hits += int(counts["n_hits"])
+            self.last_sizes = (len(r["hits"]), len(r["extra"]), len(r["cigar"]))
+            for kk, vv in r["stage_ms"].items():
+                self.stage_ms[kk] = self.stage_ms.get(kk, 0.0) + vv
+            self.stage_n += 1
+            if self.on_result is not None:
+                self.on_result(self.pipe, r)
+            self.done_at.append(time.perf_counter())
             done += 1
-        return hits
-    try:
-        run(depth)                                         # warm-up: device and pinned buffers sized, inputs in place
-        t0 = time.perf_counter()
-        hits = run(rounds)
-        dt = time.perf_counter() - t0
-        return {"reads_per_s": rounds * n_reads / dt, "ms_per_batch": dt / rounds * 1e3, "depth": depth, "batches": rounds,
-                "hits_per_batch": hits // rounds,
-                "what": "pinned host reads in -> pinned host hit tables + CIGAR text out, H2D / kernels / D2H overlapped (bwt_pipe)"}
-    finally:
-        pipe.close()
+            if self.keep_last and done == k:
+                self.held = r                       # the last batch's tables stay in the slot's pinned buffers: looked at after the clock stops
+            else:
+                self.pipe.release(r["slot"])
+        return counts, hits
+
+    def take_last(self):
+        """the last batch's compact table expanded into per-hit arrays (after the timed region), its slot released"""
+        r = self.held
+        self.held = None
+        out = self.pipe.expand(r)
+        self.last = (self.filled[r["slot"]], {kk: (vv.copy() if isinstance(vv, np.ndarray) else vv) for kk, vv in out.items()})
+        self.pipe.release(r["slot"])
+        return self.last
+
+    def close(self):
+        self.pipe.close()
 
 
 def load_traffic(workload):
@@ -202,8 +238,6 @@ def main():
     ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-batch", action="store_true", help="one resident batch instead of two alternating ones")
-    ap.add_argument("--no-pipeline", action="store_true", help="skip the host-buffer pipeline measurement")
-    ap.add_argument("--overlap", action="store_true", help="also measure the two resident batches in flight at once (experiment)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -271,46 +305,42 @@ def main():
                    " and one indel of 1-5 bp with p=0.2 (2x150 bp mates aligned independently, as the reference does)"
                    if wl == "paired150" else ""))
 
-    # two distinct read batches, both resident in HBM before the timed region; the steps alternate between them
-    batch = lib.Batch(ix)
-    batch.set_reads(bases, off)
-    batches = [batch]
-    if not args.single_batch:
-        if wl.startswith("config2"):
-            bases2, off2 = synth_reads(ref, n_reads, length, seed=1002 + rank, max_subs=0)
-        else:
-            bases2, off2 = synth_reads(ref, n_reads, length, seed={"grch38": 5, "chr1": 4, "paired150": 6}[wl] * 1000 + 500 + rank,
-                                       max_subs=2, indel_p=0.2 if wl == "paired150" else 0.0)
-        b2 = lib.Batch(ix)
-        b2.set_reads(bases2, off2)
-        batches.append(b2)
-    step_no = [0]
+    # two distinct read sets, packed on the host (bwt_pack_reads) before anything is timed
+    if wl.startswith("config2"):
+        bases2, off2 = synth_reads(ref, n_reads, length, seed=1002 + rank, max_subs=0)
+    else:
+        bases2, off2 = synth_reads(ref, n_reads, length, seed={"grch38": 5, "chr1": 4, "paired150": 6}[wl] * 1000 + 500 + rank,
+                                   max_subs=2, indel_p=0.2 if wl == "paired150" else 0.0)
+    read_sets = [(bases, off), (bases2, off2)]
+    t0 = time.perf_counter()
+    packed_sets = [lib.pack_2bit(b_) for b_, _ in read_sets]
+    t_pack = time.perf_counter() - t0
+    log("rank %d: %d reads packed to 2 bits per base on the host in %.2f s (%.0f M reads/s, %d exceptions)"
+        % (rank, 2 * n_reads, t_pack, 2 * n_reads / t_pack / 1e6, sum(len(e) for _, e in packed_sets)))
+    opts = lib.options_from_env()              # experiments: BWT_SW_BAND=0 etc. are translated here, the library never reads the environment
     gather = (world > 1 or force_gather) and stages == lib.STAGE_EXTEND
     lo, _ = shard.slab(n_reads * world, world, rank)
-    gatherer = shard.HitGatherer(dist, rank, world, torch.device("cuda", local_rank)) if gather else None
-    gathered = [0]
+    cpu_group = dist.new_group(backend="gloo") if gather else None       # the counts of the exchange travel between hosts, not GPUs
+    gatherer = shard.TableGatherer(dist, rank, world, torch.device("cuda", local_rank), cpu_group=cpu_group) if gather else None
+    gathered = [0, 0]
 
-    def step():
-        batch = batches[step_no[0] % len(batches)]
-        step_no[0] += 1
-        c = batch.run(stages)
-        if gather:
-            # RCCL hit gather (the path's one exchange step): 16-byte records to rank 0, double-buffered so that the gather of
-            # this step overlaps the next step's kernels; the library writes the records (global read ids) straight into the
-            # gatherer's send buffer
-            nh = c["n_hits"]
-            parts, buf = gatherer.begin(nh)
-            batch.hits_to_device_global(buf.data_ptr(), buf.shape[0], lo)
-            gatherer.commit()
-            if rank == 0 and parts is not None:
-                gathered[0] = int(sum(p.shape[0] for p in parts))
-        return c
+    def note(parts):
+        if rank == 0 and parts is not None:
+            gathered[0] = int(sum(p[0].shape[0] for p in parts)); gathered[1] = int(sum(p[1].shape[0] for p in parts))
+
+    def exchange(pipe, r):
+        # RCCL hit gather (the path's one exchange step): the batch's compact table, device to device into the send buffer (read
+        # ids made global on the way), then one asynchronous gather to rank 0 that overlaps the next batches' work
+        c = r["counts"]
+        prev, (h, x, t) = gatherer.begin(len(r["hits"]), len(r["extra"]), len(r["cigar"]))
+        note(prev)
+        slot_batch = lib.Batch(ix, handle=pipe.batch_handle(r["slot"]))
+        slot_batch.compact_to_device(h.data_ptr(), h.shape[0], x.data_ptr(), x.shape[0], t.data_ptr(), t.shape[0], lo)
+        gatherer.commit()
 
     def drain():
         if gather:
-            parts = gatherer.wait()
-            if rank == 0 and parts is not None:
-                gathered[0] = int(sum(p.shape[0] for p in parts))
+            note(gatherer.wait())
 
     def sync():
         torch.cuda.synchronize()
@@ -318,34 +348,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed set-up: every resident batch runs once so that its device buffers exist at their final sizes (hipMalloc, the
-    # CIGAR-slot retry) before anything is timed -- the W warm-up steps alone would leave the second batch cold
-    for b_ in batches:
-        b_.run(stages)
-    for _ in range(args.warmup):
-        step()
-    drain()
-    for b_ in batches:
-        b_.profile(True)                                # hipEvents around every kernel, on the library's own streams
-    step_no[0] = 0
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = step()
-    drain()                                             # the last gather is inside the timed region
-    sync()
-    dt = time.perf_counter() - t0
-    if gather and rank == 0:
-        counts["gathered_hits"] = gathered[0]
     kt = {}
-    for b_ in batches:
-        for k, v in b_.kernel_times().items():
+
+    def add_times(times):
+        for k, v in times.items():
             a = kt.setdefault(k, {"ms": 0.0, "launches": 0})
             a["ms"] += v["ms"]; a["launches"] += v["launches"]
+
+    batches = []
+    if stages == lib.STAGE_EXTEND:
+        # ---- the timed region: K batches over the host boundary
+        hp = HostPipeline(ix, packed_sets, n_reads, length, depth=3, options=opts, on_result=exchange if gather else None)
+        hp.run(3)                                           # untimed set-up: every slot's device and pinned buffers at their final sizes
+        hp.run(args.warmup)
+        drain()
+        hp.pipe.profile(True)                               # hipEvents around every kernel, on the slots' own streams
+        hp.keep_last = True
+        hp.done_at = []
+        hp.stage_ms, hp.stage_n = {}, 0
+        sync()
+        t0 = time.perf_counter()
+        counts, _ = hp.run(args.steps)
+        drain()                                             # the last gather is inside the timed region
+        sync()
+        dt = time.perf_counter() - t0
+        steady = (hp.done_at[-1] - hp.done_at[0]) / max(1, len(hp.done_at) - 1) if len(hp.done_at) > 1 else dt
+        add_times(hp.pipe.kernel_times())
+        last_set, last_hits = hp.take_last()
+        hp.pipe.profile(False)
+        if gather and rank == 0:
+            counts["gathered_hits"], counts["gathered_extras"] = gathered
+    else:
+        hp = None
+        steady = None
+    # ---- the same steps with the reads resident in HBM (packed upload done once, hits left on the device)
+    for codes, exc in packed_sets if not args.single_batch else packed_sets[:1]:
+        b_ = lib.Batch(ix)
+        if opts:
+            b_.set_options(**opts)
+        b_.set_reads_packed(codes, exc, n_reads, read_len=length)
+        batches.append(b_)
+    batch = batches[0]
+    for b_ in batches:
+        b_.run(stages)
+    for i_ in range(args.warmup):
+        batches[i_ % len(batches)].run(stages)
+    kt_res = {}
+    for b_ in batches:
+        b_.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    for i_ in range(args.steps):
+        rcounts = batches[i_ % len(batches)].run(stages)
+    sync()
+    dt_res = time.perf_counter() - t0
+    for b_ in batches:
+        for k, v in b_.kernel_times().items():
+            a = kt_res.setdefault(k, {"ms": 0.0, "launches": 0})
+            a["ms"] += v["ms"]; a["launches"] += v["launches"]
+        b_.profile(False)
+    if hp is None:                                          # search-only workload: the resident steps are the measurement
+        dt, counts, kt = dt_res, rcounts, kt_res
+        last_set, last_hits = 0, None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_res], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_res = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         value = n_reads * world * args.steps / dt
@@ -423,6 +491,9 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "value_is": ("host boundary (SURVEY 8d): packed reads in pinned host memory -> PCIe -> kernels -> compact hit tables in pinned "
+                         "host memory, %d batches through bwt_pipe (depth 3) incl. pipeline fill and drain" % args.steps) if hp is not None
+                        else "search stage only, reads resident in HBM (BASELINE configs[1] times the kernel alone)",
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
                        "suffix_interval_table": {"K": ix.ktable[0], "top_level_carries_sa": ix.ktable[1]},
@@ -433,6 +504,18 @@ def main():
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(kt.items())},
             "counts_per_step": counts,
         }
+        if hp is not None:
+            up = sum(len(c_) * 4 + len(e_) * 8 for c_, e_ in packed_sets) / len(packed_sets)
+            down = hp.last_sizes[0] * 16 + hp.last_sizes[1] * 16 + hp.last_sizes[2] + n_reads
+            line["host_boundary"] = {"bytes_up_per_read": up / n_reads, "bytes_down_per_read": down / n_reads,
+                                     "steady_state_ms_per_batch": steady * 1e3, "steady_state_reads_per_s": n_reads * world / steady,
+                                     "host_pack_reads_per_s": 2 * n_reads / t_pack,
+                                     "extras_per_batch": hp.last_sizes[1],
+                                     "slot_thread_ms_per_batch": {kk: vv / max(1, hp.stage_n) for kk, vv in hp.stage_ms.items()},
+                                     "what": "2-bit codes + exception list up, 16-byte hit records + 1 status byte per read + extras down"}
+            line["resident"] = {"reads_per_s": n_reads * world * args.steps / dt_res, "ms_per_step": dt_res / args.steps * 1e3,
+                                "what": "the same steps with the reads already in HBM and the hit tables left there (rounds 1-2 `value`)",
+                                "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(kt_res.items())}}
         if "sw_extend" in per or "sw_wave" in per:
             banded = counts.get("n_banded", 0) > 0
             left = counts["n_dp"] - counts.get("n_banded", 0)
@@ -446,43 +529,17 @@ def main():
                               # cells of the reference's full rectangles for these candidates, per second of DP kernels (the banded
                               # kernel fills 24 diagonals of them)
                               "dp_cells_per_s": counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1) / t_dp if t_dp else None}
-        # PCIe-inclusive rate (never `value`): host buffers in, host hit tables out, one untimed-extra pass
-        t0 = time.perf_counter()
-        batch.set_reads(bases, off)
-        batch.run(stages)
-        if stages == lib.STAGE_EXTEND:
-            batch.fetch_hits()
-        line["pcie_inclusive_reads_per_s"] = n_reads / (time.perf_counter() - t0)
-        if len(batches) > 1 and args.overlap:
-            # experiment (never `value`): the two resident batches in flight at once, each on its own stream and host thread
-            import threading
-            for b_ in batches:
-                b_.profile(False)
-            def runner(b_, k):
-                for _ in range(k):
-                    b_.run(stages)
-            k_each = max(1, args.steps // 2)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            th = [threading.Thread(target=runner, args=(b_, k_each)) for b_ in batches]
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t0
-            line["two_batches_in_flight"] = {"reads_per_s": n_reads * k_each * len(batches) / dt2, "ms_per_step": dt2 / (k_each * len(batches)) * 1e3,
-                                             "what": "both resident batches run concurrently (own stream + host thread each)"}
-        if stages == lib.STAGE_EXTEND and not args.no_pipeline:
-            line["host_pipeline"] = host_pipeline(ix, [(bases, off)] + ([(bases2, off2)] if len(batches) > 1 else []), n_reads)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(ix, ref, bases, off, length, 0 if stages == lib.STAGE_SEARCH else 1,
-                                                batch=batch)
+            cb_bases, cb_off = read_sets[last_set]
+            line["cpu_baseline"] = cpu_baseline(ix, ref, cb_bases, cb_off, length, 0 if stages == lib.STAGE_SEARCH else 1, hits=last_hits)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
-    batch.destroy()
+    if hp is not None:
+        hp.close()
+    for b_ in batches:
+        b_.destroy()
     ix.close()
     if dist is not None:
         dist.barrier()

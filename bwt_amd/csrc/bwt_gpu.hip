@@ -1245,7 +1245,7 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
         return 0;
     }
     HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->cig_total, 0, 8, b->stream));     // (a retry with wider CIGAR slots counts again)
-    KLAUNCH(b, "hits_count", k_hits_count, cdiv(n, 256), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
+    KLAUNCH(b, "hits_count", k_hits_count, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
             b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_nx.as<uint32_t>(), b->r_xcb.as<uint32_t>(),
             b->r_status.as<int8_t>(), b->ctr.as<Counters>());
     if ((rc = dev_scan3(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), b->r_nx.as<uint32_t>(), b->x_off.as<uint64_t>(),
@@ -1549,6 +1549,24 @@ extern "C" int bwt_batch_hits_to_device_global(bwt_batch *b, void *dev_dst, uint
     if (b->n_hits)
         hipLaunchKernelGGL(k_hits_global, dim3((uint32_t)std::min<uint64_t>(cdiv(b->n_hits, 256), 4096)), dim3(256), 0, b->stream,
                            b->h_rec.as<HitRec>(), b->n_hits, read_base, (HitRec *)dev_dst);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the whole compact table, device to device, into caller-owned device memory (the send buffer of the RCCL gather): hit records
+// with global read ids, extras and their text as they are (their hit / text offsets stay slab-local: the receiver adds the bases)
+extern "C" int bwt_batch_compact_to_device(bwt_batch *b, void *dst_hits, uint64_t cap_hits, void *dst_extra, uint64_t cap_extra,
+                                           void *dst_cigar, uint64_t cap_cigar, uint32_t read_base) {
+    if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_compact_to_device: extend stage not run");
+    if ((!dst_hits && b->n_hits) || (!dst_extra && b->n_extra) || (!dst_cigar && b->xcig_bytes)) return fail(BWT_EINVAL, "bwt_batch_compact_to_device: null destination");
+    HIPCHK(hipSetDevice(b->device));
+    if (b->n_hits > cap_hits || b->n_extra > cap_extra || b->xcig_bytes > cap_cigar) return fail(BWT_ENOSPC, "bwt_batch_compact_to_device: capacity too small");
+    if (b->n_hits)
+        hipLaunchKernelGGL(k_hits_global, dim3((uint32_t)std::min<uint64_t>(cdiv(b->n_hits, 256), 4096)), dim3(256), 0, b->stream,
+                           b->h_rec.as<HitRec>(), b->n_hits, read_base, (HitRec *)dst_hits);
+    if (b->n_extra) HIPCHK(hipMemcpyAsync(dst_extra, b->x_rec.p, b->n_extra * 16, hipMemcpyDeviceToDevice, b->stream));
+    if (b->xcig_bytes) HIPCHK(hipMemcpyAsync(dst_cigar, b->x_cig.p, b->xcig_bytes, hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipGetLastError());
     return 0;

@@ -3181,10 +3181,12 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
                                                      const uint32_t *__restrict__ r_qty,
                                                      uint32_t *__restrict__ r_nhit, uint32_t *__restrict__ r_nx,
                                                      uint32_t *__restrict__ r_xcb, int8_t *__restrict__ r_status, Counters *ctr) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride over a capped grid: one atomic per wave for the whole launch (same-address atomics are rated at ~88 per us:
+    // one per wave of a 12.5 M-read batch would be 2 ms of them)
     unsigned long long cb = 0;                        // bytes of all CIGAR texts (plain ones included): bwt_batch_counts.cigar_bytes
-    if (r < n) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         uint32_t nh = 0, nx = 0, xcb = 0;
+        unsigned long long cbr = 0;
         int32_t st = 1;                                   // sga returned []
         if (r_qty[r] >> 31) st = -1;
         const uint64_t a = clus_off[r], b = clus_off[r + 1];
@@ -3193,12 +3195,13 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
             const int32_t cs = c_status[k];
             if (cs == CS_OK) {
                 const uint32_t clf = c_ciglen[k];
-                nh++; cb += clf & ~CIG_DIAG;
+                nh++; cbr += clf & ~CIG_DIAG;
                 if (!(clf & CIG_DIAG)) { nx++; xcb += clf; }
             } else if (cs == CS_WINDOW_OOR) st = -2;
             else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
         }
-        if (st == -2) { nh = 0; nx = 0; xcb = 0; cb = 0; }
+        if (st == -2) { nh = 0; nx = 0; xcb = 0; cbr = 0; }
+        cb += cbr;
         r_nhit[r] = nh; r_nx[r] = nx; r_xcb[r] = xcb; r_status[r] = (int8_t)st;
     }
     cb = wave_sum_u64(cb);

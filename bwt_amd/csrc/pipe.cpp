@@ -12,9 +12,12 @@
 // until the slot is released.
 #include "common.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -55,6 +58,7 @@ struct Slot {
     std::string err;
     bwt_batch_counts counts{};
     uint64_t n_hits = 0, n_extra = 0, cig_bytes = 0;
+    double ms[4] = {0, 0, 0, 0};                   // upload, kernels, download, waiting for a turn
     std::thread th;
 };
 }  // namespace
@@ -71,6 +75,11 @@ struct bwt_pipe {
     // pipeline.  The kernels of a batch fill the chip by themselves (persistent grids): two batches' kernels side by side gain
     // nothing, and taking turns keeps the per-kernel event times those of undisturbed launches.
     std::mutex h2d_turn, gpu_turn, d2h_turn;
+    bool debug = false;                  // BWT_PIPE_DEBUG: a timeline line per event on stderr
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void trace(uint32_t slot, const char *what) const {
+        if (debug) fprintf(stderr, "[pipe %9.3f ms] slot %u %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), slot, what);
+    }
 };
 
 static void slot_worker(bwt_pipe *p, uint32_t si) {
@@ -94,15 +103,30 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
                 rc = BWT_ENOSPC;
             }
         }
+        p->trace(si, "picked up");
+        using clk = std::chrono::steady_clock;
+        auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+        s.ms[0] = s.ms[1] = s.ms[2] = s.ms[3] = 0;
         if (!rc) {
+            const auto tw = clk::now();
             std::lock_guard<std::mutex> turn(p->h2d_turn);
+            s.ms[3] += ms_since(tw);
+            p->trace(si, "upload begins");
+            const auto t0 = clk::now();
+            struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[0], t0};
             if (s.mode == M_ASCII) rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
             else rc = bwt_batch_set_reads_packed(s.batch, (const uint32_t *)s.codes.p, s.total, s.n, s.read_len,
                                                  s.read_len ? nullptr : (const uint64_t *)s.off.p, (const uint64_t *)s.exc.p, s.n_exc);
         }
         if (!rc) {
+            const auto tw = clk::now();
             std::lock_guard<std::mutex> turn(p->gpu_turn);
+            s.ms[3] += ms_since(tw);
+            p->trace(si, "kernels begin");
+            const auto t0 = clk::now();
             rc = bwt_batch_run(s.batch, BWT_STAGE_EXTEND, &s.counts);
+            s.ms[1] = ms_since(t0);
+            p->trace(si, "kernels done");
         }
         uint64_t need[3] = {0, 0, 0};
         if (!rc) {
@@ -113,7 +137,12 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
                 if ((rc = s.rstat.ensure((size_t)s.n + 16)) || (rc = s.rec.ensure(((size_t)need[0] + 1) * 16)) ||
                     (rc = s.extra.ensure(((size_t)need[1] + 1) * 16)) || (rc = s.cig.ensure((size_t)need[2] + 16))) {
                 } else {
+                    const auto tw = clk::now();
                     std::lock_guard<std::mutex> turn(p->d2h_turn);
+                    s.ms[3] += ms_since(tw);
+                    p->trace(si, "download begins");
+                    const auto t0 = clk::now();
+                    struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[2], t0};
                     rc = bwt_batch_fetch_hits_compact(s.batch, (int8_t *)s.rstat.p, (bwt_hit_rec *)s.rec.p, (bwt_hit_extra *)s.extra.p,
                                                       (char *)s.cig.p, need[0], need[1], need[2], need);
                 }
@@ -126,6 +155,7 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
             s.n_hits = need[0]; s.n_extra = need[1]; s.cig_bytes = need[2];
             s.state = DONE;
         }
+        p->trace(si, "done");
         p->cv.notify_all();
     }
 }
@@ -136,6 +166,7 @@ extern "C" int bwt_pipe_create(bwt_index *ix, uint32_t depth, bwt_pipe **out) {
     HIPCHK(hipSetDevice(ix->device));
     bwt_pipe *p = new bwt_pipe();
     p->ix = ix;
+    p->debug = getenv("BWT_PIPE_DEBUG") != nullptr;
     p->slots.resize(depth);
     for (uint32_t i = 0; i < depth; i++) {
         int rc = bwt_batch_create(ix, &p->slots[i].batch);
@@ -268,6 +299,7 @@ extern "C" int bwt_pipe_acquire_packed(bwt_pipe *p, uint64_t bases_cap, uint32_t
 }
 
 static int queue_slot(bwt_pipe *p, uint32_t slot) {
+    p->trace(slot, "submitted");
     {
         std::lock_guard<std::mutex> lk(p->mu);
         p->slots[slot].state = QUEUED;
@@ -321,11 +353,13 @@ extern "C" int bwt_pipe_wait(bwt_pipe *p, bwt_pipe_result *res) {
     p->cv.wait(lk, [&] { return s.state == DONE; });
     p->order.pop_front();
     s.state = TAKEN;
+    p->trace(si, "taken");
     res->slot = si; res->n_reads = s.n; res->status = s.rc; res->read_len = s.read_len;
     res->n_hits = s.n_hits; res->n_extra = s.n_extra; res->cigar_bytes = s.cig_bytes;
     res->read_status = (const int8_t *)s.rstat.p; res->hits = (const bwt_hit_rec *)s.rec.p;
     res->extra = (const bwt_hit_extra *)s.extra.p; res->cigar = (const char *)s.cig.p;
     res->counts = s.counts;
+    res->ms_upload = s.ms[0]; res->ms_kernels = s.ms[1]; res->ms_download = s.ms[2]; res->ms_waiting = s.ms[3];
     if (s.rc) return fail(s.rc, "bwt_pipe: batch failed: " + s.err);
     return 0;
 }

@@ -25,6 +25,7 @@ EXPORTS = [
     "bwt_options_init", "bwt_index_set_options", "bwt_batch_set_options", "bwt_index_set_ktable_ex", "bwt_packed_words", "bwt_pack_reads",
     "bwt_batch_set_reads_packed", "bwt_batch_fetch_hits_compact", "bwt_hits_expand", "bwt_pipe_set_options", "bwt_pipe_profile",
     "bwt_pipe_kernel_times", "bwt_pipe_acquire_packed", "bwt_pipe_submit_packed", "bwt_pipe_submit_ascii", "bwt_pipe_batch",
+    "bwt_batch_compact_to_device",
 ]
 
 
@@ -101,7 +102,8 @@ class PipeInput(C.Structure):
 class PipeResult(C.Structure):
     _fields_ = [("slot", C.c_uint32), ("n_reads", C.c_uint32), ("status", C.c_int32), ("read_len", C.c_uint32), ("n_hits", C.c_uint64),
                 ("n_extra", C.c_uint64), ("cigar_bytes", C.c_uint64), ("read_status", C.c_void_p), ("hits", C.c_void_p),
-                ("extra", C.c_void_p), ("cigar", C.c_void_p), ("counts", BatchCounts)]
+                ("extra", C.c_void_p), ("cigar", C.c_void_p), ("counts", BatchCounts), ("ms_upload", C.c_double), ("ms_kernels", C.c_double),
+                ("ms_download", C.c_double), ("ms_waiting", C.c_double)]
 
 
 _lib = None
@@ -460,16 +462,18 @@ def sw_batch(q, qoff, r, roff, device=0):
 class Batch:
     """Resident batch: reads, intermediates and hits stay in HBM between calls."""
 
-    def __init__(self, index):
+    def __init__(self, index, handle=None):
         self.index = index
-        self.h = C.c_void_p()
-        _chk(load().bwt_batch_create(index.h, C.byref(self.h)))
+        self.owned = handle is None
+        self.h = C.c_void_p() if handle is None else handle       # handle: a batch owned by someone else (a pipe slot's)
+        if self.owned:
+            _chk(load().bwt_batch_create(index.h, C.byref(self.h)))
         self.n = 0
 
     def destroy(self):
-        if self.h:
+        if self.h and self.owned:
             load().bwt_batch_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -540,6 +544,11 @@ class Batch:
 
     def hits_to_device(self, dev_ptr, cap_hits):
         _chk(load().bwt_batch_hits_to_device(self.h, C.c_void_p(dev_ptr), C.c_uint64(cap_hits)))
+
+    def compact_to_device(self, hits_ptr, cap_hits, extra_ptr, cap_extra, cigar_ptr, cap_cigar, read_base):
+        """bwt_batch_compact_to_device: the compact table into device memory (RCCL send buffer), read ids made global"""
+        _chk(load().bwt_batch_compact_to_device(self.h, C.c_void_p(hits_ptr), C.c_uint64(cap_hits), C.c_void_p(extra_ptr), C.c_uint64(cap_extra),
+                                                C.c_void_p(cigar_ptr), C.c_uint64(cap_cigar), C.c_uint32(read_base)))
 
     def hits_to_device_global(self, dev_ptr, cap_hits, read_base):
         _chk(load().bwt_batch_hits_to_device_global(self.h, C.c_void_p(dev_ptr), C.c_uint64(cap_hits), C.c_uint32(read_base)))
@@ -663,7 +672,8 @@ class Pipe:
         n, nh, nx = r.n_reads, int(r.n_hits), int(r.n_extra)
         return dict(slot=r.slot, n_reads=n, read_len=int(r.read_len), read_status=_view(r.read_status, n, np.int8),
                     hits=_view(r.hits, nh, HIT_REC), extra=_view(r.extra, nx, HIT_EXTRA),
-                    cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8).tobytes(), counts=r.counts.as_dict())
+                    cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8).tobytes(), counts=r.counts.as_dict(),
+                    stage_ms=dict(upload=r.ms_upload, kernels=r.ms_kernels, download=r.ms_download, waiting=r.ms_waiting))
 
     def expand(self, res, off=None):
         """per-hit arrays of a wait() result (host-side bwt_hits_expand); off = the batch's read offsets when the lengths differ"""

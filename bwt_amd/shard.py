@@ -1,6 +1,7 @@
 """Multi-GPU sharding of the read stream: reads are independent units, the index is
 replicated on every GPU, each rank aligns one contiguous slab, and the only exchange is the
-gather of the fixed-size hit records {read:u32, score:i32, pos:i64} (16 B) to rank 0.
+gather of the compact hit tables -- fixed-size hit records {read:u32, score:i32, pos:i64} (16 B) plus, for the hits that are
+not plain, window length and CIGAR text -- to rank 0 (TableGatherer; HitGatherer / gather_hits carry the records alone).
 
 The reference shards the same way -- every worker_bwt holds the whole index and pulls batches of
 reads from the master (/root/reference/src/master.erl:123,140-147, src/worker_bwt.erl:46-48).
@@ -54,6 +55,114 @@ def gather_hits(dist, rec, rank, world, dst=0):
     return [out[r][: counts[r]] for r in range(world)]
 
 
+def _round16(x):
+    return (int(x) + 15) // 16 * 16
+
+
+class TableGatherer:
+    """Asynchronous, double-buffered gather of COMPACT HIT TABLES (include/bwt_gpu.h) to rank `dst`: everything the worker's cast
+    {cigar, Name, {Score, Cigar}, Pos, RefSeq} needs (src/worker_bwt.erl:100-105) -- 16-byte hit records with global read ids,
+    and for the hits that are not plain their window length and CIGAR text (extras).  A plain hit's CIGAR is "<Lq>M" on a window
+    of Lq bases; RefSeq is Ref1[pos - Shift + 200, win_len) on any replica of the index.
+
+    Per batch and rank ONE collective on the device: a gather of one byte buffer [hits | extras | text], the three sections at
+    capacities every rank computes alike.  The counts that size them are exchanged on the HOST (a gloo group next to RCCL:
+    the counts are host integers as soon as a batch's kernels are done, so no rank waits for its GPU to learn them -- round 2's
+    all_gather on the device followed by .tolist() was a stream synchronisation per step).  `begin(counts)` hands out the send
+    buffer's three sections for the producer to fill (bwt_batch_compact_to_device: device to device, on the batch's stream);
+    `commit()` starts the gather; results come one batch late (`begin` returns the previous batch's, `wait()` the last one's):
+    on dst a list of per-rank (hits [k,2] int64, extras [x,4] int32, text uint8) views in rank order, None elsewhere.
+    Buffers are allocated with torch.empty -- nothing is ever launched on them by torch (round 2 zero-filled them on torch's
+    stream, unordered with the library's stream: ADVICE r2)."""
+
+    def __init__(self, dist, rank, world, device, cpu_group=None, dst=0):
+        self.dist, self.rank, self.world, self.device, self.dst = dist, rank, world, device, dst
+        self.cpu_group = cpu_group
+        self.caps = [0, 0, 0]          # hits, extras (records), text (bytes, multiple of 16)
+        self.send = [None, None]
+        self.recv = [None, None]
+        self.pending = None            # (slot, work handle, counts per rank)
+        self.cur = None
+        self.k = 0
+
+    def _nbytes(self):
+        return 16 * self.caps[0] + 16 * self.caps[1] + self.caps[2]
+
+    def _alloc(self):
+        nb = max(self._nbytes(), 16)
+        for s in (0, 1):
+            self.send[s] = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            if self.rank == self.dst:
+                self.recv[s] = [torch.empty(nb, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+
+    def _sections(self, buf, counts=None):
+        ch, cx, cc = self.caps
+        nh, nx, nc = (ch, cx, cc) if counts is None else counts
+        hits = buf[: 16 * ch].view(torch.int64).view(-1, 2)[:nh]
+        extra = buf[16 * ch: 16 * (ch + cx)].view(torch.int32).view(-1, 4)[:nx]
+        text = buf[16 * (ch + cx): 16 * (ch + cx) + cc][:nc]
+        return hits, extra, text
+
+    def begin(self, n_hits, n_extra, cig_bytes):
+        """-> (result of the previous batch, (hits, extras, text) sections of this batch's send buffer, at full capacity)."""
+        prev = self.wait()                                   # (also: both slots are idle, so they may be reallocated)
+        mine = torch.tensor([int(n_hits), int(n_extra), int(cig_bytes)], dtype=torch.int64)
+        allc = [torch.zeros(3, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(allc, mine, group=self.cpu_group)                 # host integers over the host group: no device sync
+        counts = [tuple(int(v) for v in c.tolist()) for c in allc]
+        need = [max(c[j] for c in counts) for j in range(3)]
+        if any(need[j] > self.caps[j] for j in range(3)) or self.send[0] is None:
+            # the same decision on every rank; 1/16 head-room because the padding travels too
+            self.caps = [max(self.caps[0], need[0] * 17 // 16 + 1024), max(self.caps[1], need[1] * 17 // 16 + 1024),
+                         max(self.caps[2], _round16(need[2] * 17 // 16 + 1024))]
+            self._alloc()
+        s = self.k & 1
+        self.k += 1
+        self.cur = (s, counts)
+        return prev, self._sections(self.send[s])
+
+    def commit(self):
+        s, counts = self.cur
+        self.cur = None
+        w = self.dist.gather(self.send[s], self.recv[s] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        self.pending = (s, w, counts)
+
+    def submit(self, hits, extra, text):
+        """Tables that already sit in tensors ([k,2] int64 with global read ids, [x,4] int32, uint8).  Returns the PREVIOUS result."""
+        prev, (h, x, t) = self.begin(hits.shape[0], extra.shape[0], text.shape[0])
+        h[: hits.shape[0]] = hits
+        x[: extra.shape[0]] = extra
+        t[: text.shape[0]] = text
+        self.commit()
+        return prev
+
+    def wait(self):
+        """Finish the outstanding gather, if any, and return its result."""
+        if self.pending is None:
+            return None
+        s, work, counts = self.pending
+        self.pending = None
+        work.wait()
+        if self.rank != self.dst:
+            return None
+        return [self._sections(self.recv[s][r], counts[r]) for r in range(self.world)]
+
+
+def merge_tables(parts):
+    """The per-rank sections of a gathered batch as ONE compact table in global read order: hit records concatenated (their
+    read ids are global already), extras with the sender's hit base and text base added.  -> (hits [k,2], extras [x,4], text)."""
+    hits = torch.cat([p[0] for p in parts])
+    text = torch.cat([p[2] for p in parts])
+    ex, hb, tb = [], 0, 0
+    for h, x, t in parts:
+        x = x.clone()
+        x[:, 0] += hb
+        x[:, 2] += tb
+        ex.append(x)
+        hb += h.shape[0]; tb += t.shape[0]
+    return hits, torch.cat(ex), text
+
+
 class HitGatherer:
     """Asynchronous, double-buffered form of gather_hits for a steady stream of batches: the gather of batch b runs on the
     collective's own stream while batch b+1 is being computed.
@@ -80,7 +189,7 @@ class HitGatherer:
     def _grow(self, need):
         self.cap = max(need * 17 // 16 + 1024, 1)
         for s in (0, 1):
-            self.send[s] = torch.zeros((self.cap, 2), dtype=torch.int64, device=self.device)
+            self.send[s] = torch.empty((self.cap, 2), dtype=torch.int64, device=self.device)   # (not zeros: nothing of torch's may run on it later than the library's writes)
             if self.rank == self.dst:
                 self.recv[s] = [torch.empty((self.cap, 2), dtype=torch.int64, device=self.device) for _ in range(self.world)]
 

@@ -329,6 +329,11 @@ int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint64_t *hit_o
 typedef struct { uint32_t hit, win_len, cig_off, cig_len; } bwt_hit_extra;
 int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, bwt_hit_rec *hits, bwt_hit_extra *extra, char *cigar,
                                  uint64_t hit_cap, uint64_t extra_cap, uint64_t cig_cap, uint64_t needed[3]);
+/* the same table device to device into caller-owned device memory (the send buffer of the RCCL hit gather): records with
+ * `read_base` added to the read ids, extras and text as they are (hit indices and text offsets stay local to this batch: the
+ * receiver adds the sender's bases).  Capacities in records / records / bytes. */
+int bwt_batch_compact_to_device(bwt_batch *b, void *dst_hits, uint64_t cap_hits, void *dst_extra, uint64_t cap_extra,
+                                void *dst_cigar, uint64_t cap_cigar, uint32_t read_base);
 /* Host-side expansion of a compact table into the arrays of bwt_align_batch (no GPU): read_len > 0 for a uniform batch,
  * else off[0..n] gives the read lengths.  hit_off n+1, score/pos/win_off/win_len n_hits, cig_off n_hits+1; cigar
  * capacity cig_cap (BWT_ENOSPC + *cig_needed otherwise). */
@@ -374,6 +379,8 @@ typedef struct {
     const bwt_hit_extra *extra;      /* n_extra, ascending by hit */
     const char *cigar;               /* cigar_bytes: the text of the extras */
     bwt_batch_counts counts;
+    /* wall time of the slot's thread in its three stages (host packing excluded), and the time it waited for its turn */
+    double ms_upload, ms_kernels, ms_download, ms_waiting;
 } bwt_pipe_result;
 int bwt_pipe_create(bwt_index *idx, uint32_t depth /* 1..8 */, bwt_pipe **out);
 void bwt_pipe_destroy(bwt_pipe *p);

@@ -108,3 +108,69 @@ def test_async_double_buffered_gather_world2():
             n = [5, 3, 6, 40][step] + rank
             exp += [[i + 1000 * rank + 100000 * step, step] for i in range(n)]
         assert res == exp
+
+
+def _fake_table(rank, step):
+    """a rank's compact table of one step: k hits (global read ids), every third one with an extra record and text"""
+    k = [5, 0, 9, 70][step] + 2 * rank
+    hits = torch.stack([(torch.arange(k, dtype=torch.int64) // 2 + 1000 * rank) | ((150 + torch.arange(k, dtype=torch.int64)) << 32),
+                        torch.arange(k, dtype=torch.int64) * 31 + step], dim=1)
+    xs, text = [], b""
+    for h in range(0, k, 3):
+        t = ("%dM1D%dM" % (h + 1, 99 - h)).encode()
+        xs.append([h, 101, len(text), len(t)])
+        text += t
+    extra = torch.tensor(xs, dtype=torch.int32).reshape(-1, 4)
+    return hits, extra, torch.frombuffer(bytearray(text), dtype=torch.uint8) if text else torch.zeros(0, dtype=torch.uint8)
+
+
+def _worker_tables(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = shard.TableGatherer(dist, rank, world, torch.device("cpu"))
+    results = []
+
+    def keep(parts):
+        h, x, t = shard.merge_tables(parts)
+        results.append((h.tolist(), x.tolist(), bytes(t.tolist())))
+    for step in range(4):                      # sizes change from step to step; step 3 outgrows every agreed capacity
+        prev = g.submit(*_fake_table(rank, step))
+        if prev is not None and rank == 0:
+            keep(prev)
+    last = g.wait()
+    if rank == 0:
+        keep(last)
+        q.put(results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_table_gather_world2():
+    """TableGatherer: rank 0 reassembles, step by step, the compact table a single rank would have produced for the whole batch --
+    records, extras (hit indices and text offsets rebased) and the CIGAR bytes -- with capacities that grow on the way."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tables, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == 4
+    for step, (h, x, t) in enumerate(got):
+        eh, ex, et, hb = [], [], b"", 0
+        for rank in range(world):
+            fh, fx, ft = _fake_table(rank, step)
+            eh += fh.tolist()
+            for (hit, wl, co, cl) in fx.tolist():
+                ex.append([hit + hb, wl, co + len(et), cl])
+            et += bytes(ft.tolist())
+            hb += fh.shape[0]
+        assert h == eh and x == ex and t == et
+        # every extra's text is where it says
+        for (hit, wl, co, cl) in x:
+            assert t[co:co + cl].endswith(b"M") and wl == 101
