@@ -715,6 +715,8 @@ __global__ __launch_bounds__(256) static void k_strand_copy(uint8_t *__restrict_
 extern "C" int bwt_batch_set_reads_both_strands(bwt_batch *b, const uint8_t *bases, const uint64_t *off, uint32_t n) {
     if (!b || !off) return fail(BWT_EINVAL, "bwt_batch_set_reads_both_strands: null argument");
     if (n > 0x7fffffffu) return fail(BWT_EINVAL, "bwt_batch_set_reads_both_strands: too many reads");
+    if (!bases && n) return fail(BWT_EINVAL, "bwt_batch_set_reads_both_strands: null argument");
+    if (n && off[n] < off[0]) return fail(BWT_EINVAL, "bwt_batch_set_reads_both_strands: offsets must be non-decreasing");   // (before the sizes below are computed from them)
     HIPCHK(hipSetDevice(b->device));
     const uint64_t total = n ? off[n] - off[0] : 0;
     int rc;
@@ -747,10 +749,15 @@ __device__ static int64_t cigar_ref_span(const uint8_t *cig, uint64_t a, uint64_
     }
     return span;
 }
+// reference bases each hit's CIGAR consumes (M + D), once per hit: the pairing loop below is quadratic in a read's hits
+__global__ __launch_bounds__(256) static void k_hit_spans(uint64_t nh, const uint64_t *__restrict__ cigoff, const uint8_t *__restrict__ cig,
+                                                           uint32_t *__restrict__ span) {
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += (uint64_t)gridDim.x * blockDim.x)
+        span[h] = (uint32_t)cigar_ref_span(cig, cigoff[h], cigoff[h + 1]);
+}
 __global__ __launch_bounds__(256) static void k_pair_hits(uint32_t n_pairs, uint32_t n_fwd, const uint64_t *__restrict__ hit_off,
-                                                           const HitRec *__restrict__ rec, const uint64_t *__restrict__ cigoff,
-                                                           const uint8_t *__restrict__ cig, int32_t min_ins, int32_t max_ins,
-                                                           PairRec *__restrict__ out) {
+                                                           const HitRec *__restrict__ rec, const uint32_t *__restrict__ span,
+                                                           int32_t min_ins, int32_t max_ins, PairRec *__restrict__ out) {
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
         PairRec best{0xffffffffu, 0xffffffffu, 0, 0, 0, 0};
         for (uint32_t o = 0; o < 2; o++) {                        // o = 0: mate 1 forward, mate 2 reverse; o = 1: the other way round
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(256) static void k_pair_hits(uint32_t n_pairs, uint
                 for (uint64_t hr = hit_off[rr]; hr < hit_off[rr + 1]; hr++) {
                     const HitRec r = rec[hr];
                     if (r.pos < f.pos) continue;
-                    const int64_t ins = r.pos + cigar_ref_span(cig, cigoff[hr], cigoff[hr + 1]) - f.pos;
+                    const int64_t ins = r.pos + (int64_t)span[hr] - f.pos;
                     if (ins < min_ins || ins > max_ins) continue;
                     best.n_proper++;
                     const int32_t sc = f.score + r.score;
@@ -786,8 +793,12 @@ extern "C" int bwt_batch_pair_hits(bwt_batch *b, uint32_t n_pairs, int32_t min_i
     HIPCHK(hipSetDevice(b->device));
     int rc;
     if ((rc = ensure_expanded(b)) || (rc = b->pairs.ensure((size_t)n_pairs * sizeof(PairRec)))) return rc;
+    if ((rc = b->h_len.ensure((b->n_hits + 1) * 4))) return rc;              // (h_len is free again once the expansion is done: the spans go there)
+    if (b->n_hits)
+        hipLaunchKernelGGL(k_hit_spans, dim3((uint32_t)std::min<uint64_t>(cdiv(b->n_hits, 256), 4096)), dim3(256), 0, b->stream, b->n_hits,
+                           (const uint64_t *)b->h_cigoff.as<uint64_t>(), (const uint8_t *)b->h_cig.as<uint8_t>(), b->h_len.as<uint32_t>());
     hipLaunchKernelGGL(k_pair_hits, dim3(std::min<uint32_t>(cdiv(n_pairs, 256), 4096)), dim3(256), 0, b->stream, n_pairs, b->n / 2,
-                       b->hit_off.as<uint64_t>(), b->h_rec.as<HitRec>(), b->h_cigoff.as<uint64_t>(), b->h_cig.as<uint8_t>(), min_insert,
+                       b->hit_off.as<uint64_t>(), b->h_rec.as<HitRec>(), (const uint32_t *)b->h_len.as<uint32_t>(), min_insert,
                        max_insert, b->pairs.as<PairRec>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(pairs, b->pairs.p, (size_t)n_pairs * sizeof(PairRec), hipMemcpyDeviceToHost, b->stream));

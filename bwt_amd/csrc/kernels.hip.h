@@ -2915,10 +2915,13 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     if (sh == 0) {
-                        const uint4 qv = planes4(io.qplanes, qo[h] + b);
+                        // a half whose candidate has no row b (the shorter of the lane's two, a half that does not run) stays on
+                        // words that exist: the rows of a 1500-base partner would walk it far past its own read and window
+                        const uint32_t bb = b < lq[h] ? b : 0u;
+                        const uint4 qv = planes4(io.qplanes, qo[h] + bb);
                         qlw[h] = qv.x; qhw[h] = qv.y;
                         rl0[h] = rl1[h]; rh0[h] = rh1[h];
-                        const uint4 v = planes4(io.wplanes, P0[h] + b + 32);
+                        const uint4 v = planes4(io.wplanes, P0[h] + bb + 32);
                         rl1[h] = v.x; rh1[h] = v.y;
                     }
                     const uint32_t QL = 0u - ((qlw[h] >> sh) & 1u), QH = 0u - ((qhw[h] >> sh) & 1u);

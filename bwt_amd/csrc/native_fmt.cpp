@@ -52,7 +52,8 @@ int header_ok(const Header &h, uint64_t file_size, std::string &err) {
     if (memcmp(h.magic, MAGIC, 8) != 0) { err = "not a native index file (magic)"; return BWT_EFORMAT; }
     if (h.version != 1) { err = "native index: unknown version " + std::to_string(h.version); return BWT_EFORMAT; }
     if (h.rows < 8 || h.Last != h.rows || h.ref_len + 1 != h.rows || h.nblk != h.rows / BWT_BLOCK_ROWS + 1 || h.dollar < 1 || h.dollar > h.rows ||
-        !(1 < h.Pc && h.Pc < h.Pg && h.Pg < h.Pt && h.Pt <= h.Last)) { err = "native index: inconsistent header"; return BWT_EFORMAT; }
+        !(1 < h.Pc && h.Pc < h.Pg && h.Pg < h.Pt && h.Pt <= h.Last) ||
+        (uint64_t)h.rows + 70000ull >= 0xffffffffull) { err = "native index: inconsistent header"; return BWT_EFORMAT; }   // (the invariants of index_build)
     const uint64_t want = sizeof(Header) + (uint64_t)h.nblk * 64 + (uint64_t)h.rows * 4 + h.ref_len;
     if (file_size != want) { err = "native index: file is " + std::to_string(file_size) + " bytes, header says " + std::to_string(want); return BWT_EFORMAT; }
     return 0;
@@ -91,6 +92,34 @@ int load_section(FILE *f, uint8_t *dev, uint64_t bytes, uint8_t *pin[2], hipStre
 }
 }  // namespace
 
+// What the checksums cannot say (they are not keyed: a crafted or stale file can carry consistent ones): the CONTENTS obey the
+// invariants the kernels rely on -- every SA value is a row's suffix offset (< rows: it becomes a window offset into Ref1), every
+// rank block's counts are the previous block's plus that block's rows, and the totals are the header's pointers.
+__global__ __launch_bounds__(256) static void k_native_verify(const uint32_t *__restrict__ blocks, uint32_t nblk, const uint32_t *__restrict__ sa,
+                                                               uint32_t rows, uint32_t dollar, uint32_t Pc, uint32_t Pg, uint32_t Pt,
+                                                               unsigned int *__restrict__ err) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x, t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int bad = 0;
+    for (uint64_t r = t0; r < rows; r += nthreads) if (sa[r] >= rows) bad |= 1u;
+    for (uint64_t b = t0; b < nblk; b += nthreads) {
+        const uint32_t *w = blocks + b * 16;
+        uint32_t c[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < BWT_BLOCK_ROWS; i++) {
+            const uint64_t row0 = b * BWT_BLOCK_ROWS + i;
+            if (row0 >= rows) { if (blk_get_code(w, i)) bad |= 2u; continue; }       // nothing behind the last row
+            if (row0 + 1 == dollar) { if (blk_get_code(w, i)) bad |= 2u; continue; } // the $ row is stored as code 0 and not counted
+            c[blk_get_code(w, i)]++;
+        }
+        for (int q = 0; q < 4; q++) {
+            const uint32_t have = w[4 * q];
+            if (b == 0 && have != 0) bad |= 4u;
+            const uint32_t next = b + 1 < nblk ? w[16 + 4 * q] : (q == 0 ? Pc - 2 : q == 1 ? Pg - Pc : q == 2 ? Pt - Pg : rows + 1 - Pt);
+            if (have + c[q] != next) bad |= 4u;
+        }
+    }
+    if (bad) atomicOr(err, bad);
+}
+
 extern "C" int bwt_index_save_native(const bwt_index *ix, const char *path) {
     if (!ix || !path) return fail(BWT_EINVAL, "bwt_index_save_native: null argument");
     HIPCHK(hipSetDevice(ix->device));
@@ -99,9 +128,11 @@ extern "C" int bwt_index_save_native(const bwt_index *ix, const char *path) {
     memcpy(h.magic, MAGIC, 8);
     h.version = 1; h.rows = ix->Last; h.Pc = ix->Pc; h.Pg = ix->Pg; h.Pt = ix->Pt; h.Last = ix->Last; h.shift = ix->shift;
     h.dollar = ix->d.dollar; h.nblk = ix->d.nblk; h.ref_len = ix->ref1_len - 2 * BWT_REF_EXT;
-    FILE *f = fopen(path, "wb");
-    if (!f) return fail(BWT_EIO, std::string("cannot create ") + path);
-    struct FG { FILE *f; ~FG() { if (f) fclose(f); } } fg{f};
+    // written next to its final name and renamed when complete: a crash leaves no half-written index under `path`
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(BWT_EIO, std::string("cannot create ") + tmp);
+    struct FG { FILE *f; std::string t; ~FG() { if (f) { fclose(f); remove(t.c_str()); } } } fg{f, tmp};
     uint8_t *pin = nullptr;
     if (hipHostMalloc((void **)&pin, CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(BWT_ENOMEM, "native index: no pinned buffer"); }
     struct PG { uint8_t *p; ~PG() { (void)hipHostFree(p); } } pg{pin};
@@ -113,7 +144,8 @@ extern "C" int bwt_index_save_native(const bwt_index *ix, const char *path) {
         return rc;
     if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&h, 1, sizeof h, f) != sizeof h) return fail(BWT_EIO, "native index: cannot finish the header");
     fg.f = nullptr;
-    if (fclose(f) != 0) return fail(BWT_EIO, "native index: close failed");
+    if (fclose(f) != 0) { remove(tmp.c_str()); return fail(BWT_EIO, "native index: close failed"); }
+    if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(BWT_EIO, std::string("native index: cannot rename to ") + path); }
     return 0;
 }
 
@@ -182,6 +214,22 @@ extern "C" int bwt_index_open_native(const char *path, int device, bwt_index **o
     if ((rc = load_section(f, (uint8_t *)ix->blocks.p, (uint64_t)h.nblk * 64, pin, ix->stream, h.h_blocks, "rank blocks")) ||
         (rc = load_section(f, (uint8_t *)ix->sa.p, (uint64_t)h.rows * 4, pin, ix->stream, h.h_sa, "SA")) ||
         (rc = load_section(f, ix->ref1.as<uint8_t>() + BWT_REF_EXT, h.ref_len, pin, ix->stream, h.h_ref, ".ref"))) { bwt_index_close(ix); return rc; }
+    {
+        unsigned int *derr = nullptr, herr = 0;
+        if (hipMalloc((void **)&derr, 4) != hipSuccess) { (void)hipGetLastError(); bwt_index_close(ix); return fail(BWT_ENOMEM, "native index: no memory"); }
+        (void)hipMemsetAsync(derr, 0, 4, ix->stream);
+        hipLaunchKernelGGL(k_native_verify, dim3(2048), dim3(256), 0, ix->stream, (const uint32_t *)ix->blocks.as<uint32_t>(), h.nblk,
+                           (const uint32_t *)ix->sa.as<uint32_t>(), h.rows, h.dollar, h.Pc, h.Pg, h.Pt, derr);
+        e = hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        (void)hipFree(derr);
+        if (e != hipSuccess) { bwt_index_close(ix); return fail(BWT_EHIP, std::string("native index: verification failed to run: ") + hipGetErrorString(e)); }
+        if (herr) {
+            bwt_index_close(ix);
+            return fail(BWT_EFORMAT, std::string("native index: contents break the index invariants (") + ((herr & 1) ? "SA value >= rows; " : "") +
+                                         ((herr & 2) ? "code bits outside the rows; " : "") + ((herr & 4) ? "rank-block counts disagree with the rows / pointers" : "") + ")");
+        }
+    }
     ix->d.blocks = ix->blocks.as<uint4>(); ix->d.sa = ix->sa.as<uint32_t>(); ix->d.ref1 = ix->ref1.as<uint8_t>();
     ix->d.ref1_len = ix->ref1_len;
     ix->d.Pc = h.Pc; ix->d.Pg = h.Pg; ix->d.Pt = h.Pt; ix->d.Last = h.Last; ix->d.dollar = h.dollar; ix->d.nblk = h.nblk;

@@ -137,3 +137,58 @@ def test_native_index_round_trip(tmp_path, ref_bytes, orc_fm):
     open(bad, "wb").write(bytes(raw[:-5]))
     with pytest.raises(lib.BwtError):
         lib.native_check(bad)
+
+
+def _fnv1a_words(data):
+    """the section checksum of the native format (csrc/native_fmt.cpp): FNV-1a over 8-byte words, the tail byte-wise"""
+    h, mask = 0xcbf29ce484222325, (1 << 64) - 1
+    n8 = len(data) // 8 * 8
+    for (w,) in __import__("struct").iter_unpack("<Q", data[:n8]):
+        h = ((h ^ w) * 0x100000001b3) & mask
+    for c in data[n8:]:
+        h = ((h ^ c) * 0x100000001b3) & mask
+    return h
+
+
+@pytest.mark.gpu
+def test_native_index_contents_are_verified(tmp_path):
+    """A file whose checksums are CONSISTENT but whose contents break the index invariants (the checksum is not keyed: ADVICE r2)
+    passes the host-only check and is refused when opened: an SA value >= rows, a rank block whose counts do not continue the
+    previous block's.  Nothing is left behind under the final name by a save that fails half-way (tmp + rename)."""
+    import struct
+    from bwt_amd import lib
+    from conftest import FM_PATH, REF_PATH
+    ix = lib.Index.open(FM_PATH, REF_PATH, 0)
+    path = str(tmp_path / "ok.bwtgpu")
+    ix.save_native(path)
+    ix.close()
+    assert not os.path.exists(path + ".tmp")
+    raw = bytearray(open(path, "rb").read())
+    rows, = struct.unpack_from("<I", raw, 16)
+    nblk, = struct.unpack_from("<I", raw, 44)
+    o_blocks, o_sa = 128, 128 + nblk * 64
+    o_ref = o_sa + rows * 4
+    assert _fnv1a_words(bytes(raw[o_sa:o_ref])) == struct.unpack_from("<Q", raw, 64)[0]     # the restated checksum is the file's
+    # 1. one SA value far outside the rows, checksum brought in line
+    bad = bytearray(raw)
+    struct.pack_into("<I", bad, o_sa + 4 * 1234, 0xFFFFFF00)
+    struct.pack_into("<Q", bad, 64, _fnv1a_words(bytes(bad[o_sa:o_ref])))
+    p1 = str(tmp_path / "bad_sa.bwtgpu")
+    open(p1, "wb").write(bytes(bad))
+    lib.native_check(p1)                                                       # consistent as a file
+    with pytest.raises(lib.BwtError) as e:
+        lib.Index.open_native(p1, 0)
+    assert e.value.code == -74 and "SA value" in str(e.value)
+    # 2. a rank block's count word off by one
+    bad = bytearray(raw)
+    w, = struct.unpack_from("<I", bad, o_blocks + 64 * 7)
+    struct.pack_into("<I", bad, o_blocks + 64 * 7, w + 1)
+    struct.pack_into("<Q", bad, 56, _fnv1a_words(bytes(bad[o_blocks:o_sa])))
+    p2 = str(tmp_path / "bad_blocks.bwtgpu")
+    open(p2, "wb").write(bytes(bad))
+    lib.native_check(p2)
+    with pytest.raises(lib.BwtError) as e:
+        lib.Index.open_native(p2, 0)
+    assert e.value.code == -74 and "counts" in str(e.value)
+    # the untouched file still opens
+    lib.Index.open_native(path, 0).close()

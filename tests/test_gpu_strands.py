@@ -120,3 +120,61 @@ def test_pairing_of_simulated_fragments(gpu_index, ref_bytes):
             b.pair_hits(500, 100)
     finally:
         b.destroy()
+
+
+def test_pairing_ties_and_many_hits_against_array_form():
+    """Pairs drawn from a genome with a 400-bp segment in 12 exact copies: every mate has ~12 equally good hits, so score sums tie
+    and the rule's tie-break (first in enumeration order: mate 1 forward before mate 2 forward, forward hit outer, reverse hit
+    inner) decides.  Checked against an ARRAY formulation -- all combinations of a pair at once, np.argmax takes the first
+    maximum in C order -- instead of the loop restatement above; the reference span comes from the CIGAR text (k_hit_spans
+    computes it once per hit now)."""
+    from bwt_amd import lib
+    rng = np.random.default_rng(5)
+    g = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600_000, dtype=np.uint8)].tobytes())
+    seg = bytes(g[10_000:10_400])
+    for k in range(1, 12):
+        g[40_000 * k + 10_000:40_000 * k + 10_400] = seg
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=1)
+    mates = []
+    for p in range(60):
+        a = int(rng.integers(0, 60)); frag = int(rng.integers(280, 400 - a))
+        f = bytearray(seg[a:a + frag])
+        if p % 3 == 0:                                           # one indel in the reverse mate: its CIGAR consumes Lq +- k reference bases
+            del f[frag - 50:frag - 50 + 1 + p % 3]
+        m1, m2 = bytes(f[:100]), rc(bytes(f[-100:]))
+        mates += [m2, m1] if p % 2 else [m1, m2]
+    b = lib.Batch(ix)
+    try:
+        b.set_reads_both_strands(*lib.pack_reads(mates))
+        b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        lo, hi = 200, 450
+        pairs = b.pair_hits(lo, hi)
+        n_fwd = len(mates)
+        span = np.array([ref_span(out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])].decode()) for h in range(len(out["score"]))], np.int64)
+        pos, score, hoff = out["pos"].astype(np.int64), out["score"].astype(np.int64), out["hit_off"].astype(np.int64)
+        tied = many = 0
+        for p in range(60):
+            cands = []
+            for o in (0, 1):
+                rf, rr = 2 * p + o, n_fwd + 2 * p + (1 - o)
+                hf = np.arange(hoff[rf], hoff[rf + 1]); hr = np.arange(hoff[rr], hoff[rr + 1])
+                F, R = np.meshgrid(hf, hr, indexing="ij")
+                ins = pos[R] + span[R] - pos[F]
+                ok = (pos[R] >= pos[F]) & (ins >= lo) & (ins <= hi)
+                cands.append((F[ok], R[ok], ins[ok], (score[F] + score[R])[ok], np.full(int(ok.sum()), o)))
+            F, R, ins, sc, oo = (np.concatenate([c[i] for c in cands]) for i in range(5))
+            rec = pairs[p]
+            assert int(rec["n_proper"]) == len(sc), p
+            if not len(sc):
+                assert int(rec["hit1"]) == lib.NO_HIT
+                continue
+            k = int(np.argmax(sc))                                # the first maximum in enumeration order
+            tied += int((sc == sc[k]).sum() > 1); many += len(sc) >= 3
+            h1, h2 = (F[k], R[k]) if oo[k] == 0 else (R[k], F[k])
+            assert (int(rec["hit1"]), int(rec["hit2"]), int(rec["insert"]), int(rec["score"]), int(rec["flags"]) & 1) == \
+                (int(h1), int(h2), int(ins[k]), int(sc[k]), int(oo[k])), p
+        assert tied > 20 and many > 20
+    finally:
+        b.destroy(); ix.close()
