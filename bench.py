@@ -48,6 +48,75 @@ def synth_genome(n, seed):
     return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)]
 
 
+def synth_genome_repeats(n, seed):
+    """An i.i.d. contig with a stated repeat spectrum planted into it (real genomes are ~50 % repeats; the i.i.d.
+    contig is the best case for every shortcut of the path).  Fractions are of the genome, sizes scale with n / 3.1e9:
+      SINE-like   one 300-bp consensus, 1e6 copies at 10-15 % divergence from it                       ~ 9.7 %
+      LINE-like   one 6-kb consensus, 1e5 copies at 10-15 %                                             ~ 19 %
+      families    5000 families of 500-5000 bp in 4..64 copies at 0.5-4 % (the copy numbers at which a 15-mer's suffix
+                  interval stays under MAX_RANGE = 45: these reads bring many seeds and several clusters)   ~ 8 %
+      tandem      2e5 tracts of 60-600 bp, period 1-60, 2 % substitutions                               ~ 2 %
+      low compl.  1e5 tracts of 100-300 bp: poly-A / poly-T / 90 % AT                                   ~ 0.6 %
+      seg. dups   300 segments of 100 kb copied once at 1 %                                              ~ 2 %
+    Later plantings overwrite earlier ones where they meet.  -> (ref u8 array, composition dict)."""
+    rng = np.random.default_rng(seed + 77)
+    ref = synth_genome(n, seed).copy()
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    code = np.zeros(256, np.uint8)
+    code[ord("C")] = 1; code[ord("G")] = 2; code[ord("T")] = 3
+    scale = n / 3.1e9
+    planted = {}
+
+    def mutate(blk, div):
+        # substitutions at a rate `div` per base (per row): their number per row is drawn (Poisson), then their places
+        m, L = blk.shape
+        cnt = rng.poisson(np.broadcast_to(np.asarray(div, np.float64), (m,)) * L)
+        k = int(cnt.sum())
+        if k:
+            rows = np.repeat(np.arange(m), cnt); cols = rng.integers(0, L, k)
+            blk[rows, cols] = alpha[(code[blk[rows, cols]] + rng.integers(1, 4, k, dtype=np.uint8)) & 3]
+        return blk
+
+    def plant(name, cons, copies, dlo, dhi, chunk):
+        L = len(cons)
+        for lo in range(0, copies, chunk):
+            m = min(chunk, copies - lo)
+            pos = rng.integers(0, n - L, m)
+            blk = mutate(np.broadcast_to(cons, (m, L)).copy(), rng.uniform(dlo, dhi, m))
+            for i_, p_ in enumerate(pos.tolist()):                  # (slice copies: faster than one fancy-indexed scatter of m x L positions)
+                ref[p_:p_ + L] = blk[i_]
+        planted[name] = planted.get(name, 0) + copies * L
+
+    plant("sine_like_300bp", alpha[rng.integers(0, 4, 300)], max(1, int(1e6 * scale)), 0.10, 0.15, 100_000)
+    plant("line_like_6kb", alpha[rng.integers(0, 4, 6000)], max(1, int(1e5 * scale)), 0.10, 0.15, 5_000)
+    for _ in range(max(1, int(5000 * scale))):
+        L = int(rng.integers(500, 5001))
+        copies = int(min(64, 4 + rng.geometric(0.08)))
+        plant("families_4_to_64_copies", alpha[rng.integers(0, 4, L)], copies, 0.005, 0.04, 64)
+    nt = max(1, int(2e5 * scale))
+    for _ in range(nt):
+        per = int(rng.integers(1, 61)); L = int(rng.integers(60, 601))
+        tract = np.tile(alpha[rng.integers(0, 4, per)], L // per + 1)[:L].copy()
+        st = int(rng.integers(0, n - L))
+        ref[st:st + L] = mutate(tract[None, :], 0.02)[0]
+        planted["tandem"] = planted.get("tandem", 0) + L
+    for _ in range(max(1, int(1e5 * scale))):
+        L = int(rng.integers(100, 301)); kind = int(rng.integers(0, 3))
+        tract = np.full(L, ord("A") if kind == 0 else ord("T"), np.uint8) if kind < 2 else \
+            np.where(rng.random(L) < 0.9, np.where(rng.random(L) < 0.5, ord("A"), ord("T")), alpha[rng.integers(0, 4, L)]).astype(np.uint8)
+        st = int(rng.integers(0, n - L))
+        ref[st:st + L] = tract
+        planted["low_complexity"] = planted.get("low_complexity", 0) + L
+    for _ in range(max(1, int(300 * scale))):
+        L = min(100_000, n // 8)
+        a, b_ = int(rng.integers(0, n - L)), int(rng.integers(0, n - L))
+        ref[b_:b_ + L] = mutate(ref[a:a + L].copy()[None, :], 0.01)[0]
+        planted["segmental_duplications"] = planted.get("segmental_duplications", 0) + 2 * L
+    comp = {k: v / n for k, v in planted.items()}
+    comp["total_planted_fraction"] = sum(planted.values()) / n
+    return ref, comp
+
+
 def synth_reads(ref, n, length, seed, max_subs, indel_p=0.0):
     """uniform start, exactly k substitutions with k uniform in 0..max_subs (a substituted
     base always differs from the original); with probability indel_p one insertion or deletion of 1-5 bp.
@@ -233,7 +302,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="grch38", choices=["grch38", "chr1", "paired150", "config2", "config2-align"])
+    ap.add_argument("--workload", default="grch38", choices=["grch38", "grch38-repeats", "chr1", "paired150", "config2", "config2-align"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the workload's own)")
     ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -271,6 +340,7 @@ def main():
 
     from bwt_amd import lib, shard
     length = 100
+    composition = None
     wl = args.workload
     if wl.startswith("config2"):
         g = os.path.join(ROOT, "tests", "golden", "fm_indices", "GL000193.1_p1")
@@ -287,20 +357,24 @@ def main():
         glen = args.genome_len or (230_000_000 if wl == "chr1" else 3_100_000_000)
         n_reads = args.reads or (10_000_000 if wl == "chr1" else 12_500_000)
         t0 = time.perf_counter()
-        ref = synth_genome(glen, seed=3 if wl == "chr1" else 5)
-        log("rank %d: synthetic genome of %d bp in %.1f s" % (rank, glen, time.perf_counter() - t0))
+        if wl == "grch38-repeats":
+            ref, composition = synth_genome_repeats(glen, seed=5)
+        else:
+            ref = synth_genome(glen, seed=3 if wl == "chr1" else 5)
+        log("rank %d: synthetic genome of %d bp in %.1f s%s" % (rank, glen, time.perf_counter() - t0, "" if composition is None else " " + json.dumps(composition)))
         t0 = time.perf_counter()
         ix = lib.Index.build(ref, shift=1, device=local_rank)
         log("rank %d: FM index built on the GPU in %.1f s (%s)" % (rank, time.perf_counter() - t0, ix.device_bytes()))
         t0 = time.perf_counter()
-        bases, off = synth_reads(ref, n_reads, length, seed={"grch38": 5, "chr1": 4, "paired150": 6}[wl] * 1000 + rank,
+        bases, off = synth_reads(ref, n_reads, length, seed={"grch38": 5, "grch38-repeats": 7, "chr1": 4, "paired150": 6}[wl] * 1000 + rank,
                                  max_subs=2, indel_p=0.2 if wl == "paired150" else 0.0)
         log("rank %d: %d reads in %.1f s" % (rank, n_reads, time.perf_counter() - t0))
         stages = lib.STAGE_EXTEND
         desc = ("BASELINE configs[%d]: %s synthetic i.i.d. ACGT genome of %d bp (no GRCh38 FASTA offline), FM index "
                 "(%d rows) built on the GPU and resident in HBM, %d reads of %d bp per GPU per step with 0/1/2 "
                 "substitutions (p=1/3 each)%s, seed search + clustering + SW extension + CIGAR"
-                % ({"grch38": 3, "chr1": 2, "paired150": 4}[wl], "chr1-scale" if wl == "chr1" else "whole-GRCh38-scale",
+                % ({"grch38": 3, "grch38-repeats": 3, "chr1": 2, "paired150": 4}[wl],
+                   "chr1-scale" if wl == "chr1" else "whole-GRCh38-scale REPEAT-RICH (planted repeat spectrum, see config.repeat_spectrum)" if composition else "whole-GRCh38-scale",
                    glen, glen + 1, n_reads, length,
                    " and one indel of 1-5 bp with p=0.2 (2x150 bp mates aligned independently, as the reference does)"
                    if wl == "paired150" else ""))
@@ -309,7 +383,7 @@ def main():
     if wl.startswith("config2"):
         bases2, off2 = synth_reads(ref, n_reads, length, seed=1002 + rank, max_subs=0)
     else:
-        bases2, off2 = synth_reads(ref, n_reads, length, seed={"grch38": 5, "chr1": 4, "paired150": 6}[wl] * 1000 + 500 + rank,
+        bases2, off2 = synth_reads(ref, n_reads, length, seed={"grch38": 5, "grch38-repeats": 7, "chr1": 4, "paired150": 6}[wl] * 1000 + 500 + rank,
                                    max_subs=2, indel_p=0.2 if wl == "paired150" else 0.0)
     read_sets = [(bases, off), (bases2, off2)]
     t0 = time.perf_counter()
@@ -497,6 +571,7 @@ def main():
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
                        "suffix_interval_table": {"K": ix.ktable[0], "top_level_carries_sa": ix.ktable[1]},
+                       "repeat_spectrum": composition,
                        "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world},
             "roofline": roof,
             "rooflines": roofs,

@@ -1103,19 +1103,17 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         } else
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc, src);   // quad per candidate
     }
-    if (!b->ascii_valid) {
-        // a packed batch keeps no ASCII copy of its reads: the DP kernels that read bytes get those of the candidates the prefilter
-        // queued (fp64 queue, DP queue) -- or of every read when no prefilter ran
-        if (!io.dq) { if ((rc = ascii_all(b))) return rc; }
-        else {
-            ProfScope ps(b, "ascii_reads");
-            Counters *dc = b->ctr.as<Counters>();
-            hipLaunchKernelGGL(k_ascii_reads, dim3((uint32_t)dev_cus * 4), dim3(256), 0, b->stream, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
-                               (const uint64_t *)io.c_qoff, (const uint32_t *)io.c_qlen, qplanes, b->bases.as<uint8_t>());
-            hipLaunchKernelGGL(k_ascii_reads, dim3((uint32_t)dev_cus), dim3(256), 0, b->stream, (const uint32_t *)io.fpq, (const unsigned int *)&dc->fp_count,
-                               (const uint64_t *)io.c_qoff, (const uint32_t *)io.c_qlen, qplanes, b->bases.as<uint8_t>());
-        }
-    }
+    // A packed batch keeps no ASCII copy of its reads.  The kernels of the generic DP path read bytes (k_sw_wave, k_sw_score,
+    // k_sw<...>): each gets, right in front of it, the bytes of the candidates queued for it, made from the planes; with no
+    // prefilter (no queues) the whole batch is expanded once.
+    if (!b->ascii_valid && !io.dq) { if ((rc = ascii_all(b))) return rc; }
+    const bool sparse_ascii = !b->ascii_valid;
+    auto ascii_for = [&](const uint32_t *queue, const unsigned int *count, uint32_t limit) {
+        if (!sparse_ascii) return;
+        ProfScope ps(b, "ascii_reads");
+        hipLaunchKernelGGL(k_ascii_reads, dim3((uint32_t)dev_cus * 8), dim3(256), 0, b->stream, queue, count, limit, (const uint64_t *)io.c_qoff,
+                           (const uint32_t *)io.c_qlen, qplanes, b->bases.as<uint8_t>());
+    };
     const uint32_t maxW1 = max_w + 1, strips = (max_lq + SW_R - 1) / SW_R;
 
     // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
@@ -1152,6 +1150,9 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         b->band_ran = true;
     }
 
+    const bool pk_ok_early = (max_lq == 100 || max_lq == 150) && b->opt.sw_pk != 0 && b->opt.sw_lds != 0;
+    // (the packed-i16 kernels read planes; the other lane-per-alignment kernels and the wave kernel read bytes)
+    if (io.dq) ascii_for(io.dq, &b->ctr.as<Counters>()->dq_count, pk_ok_early ? wv_thresh : 0xffffffffu);
     if (wv_thresh) {
         ProfScope ps(b, "sw_wave");
         hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),
@@ -1225,12 +1226,14 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     twaves = std::max<uint64_t>(4, std::min<uint64_t>(twaves, (4ull << 30) / std::max<uint64_t>(per_wave, 1)) / 4 * 4);
     if ((rc = b->slab_bnd_t.ensure(twaves * maxW1 * 64 * 4)) || (rc = b->slab_dir.ensure(twaves * maxW1 * 64 * 4 * strips)))
         return rc;
+    ascii_for(io.tq, &b->ctr.as<Counters>()->tq_count, 0xffffffffu);
     KLAUNCH(b, "sw_trace", (k_sw<SW_TRACE, false>), (uint32_t)(twaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
             b->slab_bnd_t.as<uint32_t>(), (double *)nullptr, b->slab_dir.as<uint32_t>());
     const uint64_t fwaves = std::max<uint64_t>(4, std::min<uint64_t>(twaves, 1024) / 4 * 4);
     if ((rc = b->slab_bnd_fp.ensure(fwaves * maxW1 * 64 * 4)) || (rc = b->slab_bndv.ensure(fwaves * maxW1 * 64 * 8)) ||
         (rc = b->slab_dir_fp.ensure(fwaves * maxW1 * 64 * 4 * strips)))
         return rc;
+    ascii_for(io.fpq, &b->ctr.as<Counters>()->fp_count, 0xffffffffu);
     KLAUNCH(b, "sw_extend_fp64", (k_sw<SW_FP, false>), (uint32_t)(fwaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
             b->slab_bnd_fp.as<uint32_t>(), b->slab_bndv.as<double>(), b->slab_dir_fp.as<uint32_t>());
     HIPCHK(hipGetLastError());

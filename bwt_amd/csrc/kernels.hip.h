@@ -3332,23 +3332,34 @@ __global__ __launch_bounds__(256) void k_unpack_exc(const uint64_t *__restrict__
 __global__ __launch_bounds__(256) void k_off_uniform(uint64_t *__restrict__ off, uint32_t n, uint32_t len) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) off[i] = i * len;
 }
-// ASCII bytes of single reads out of the planes (packed batches keep no ASCII copy of reads that never reach a byte-reading
-// kernel): wave per listed candidate's read, 'other' positions keep the byte k_unpack_exc stored
-__global__ __launch_bounds__(256) void k_ascii_reads(const uint32_t *__restrict__ queue, const unsigned int *__restrict__ count,
+// ASCII bytes of single reads out of the planes (packed batches keep no ASCII copy of their reads: only the kernels of the generic
+// DP path read bytes, and they get those of the candidates queued for them).  Eight lanes per listed candidate, 16 bases per
+// lane and pass; positions flagged `other` keep the byte k_unpack_exc stored.  Queues longer than `limit` are left alone (the
+// consumer of such a queue reads planes).
+__global__ __launch_bounds__(256) void k_ascii_reads(const uint32_t *__restrict__ queue, const unsigned int *__restrict__ count, uint32_t limit,
                                                       const uint64_t *__restrict__ c_qoff, const uint32_t *__restrict__ c_qlen,
                                                       const uint32_t *__restrict__ planes, uint8_t *__restrict__ ascii) {
-    const uint32_t nq = *count, lane = threadIdx.x & 63;
-    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nq; q += (gridDim.x * blockDim.x) >> 6) {
+    const uint32_t nq = *count;
+    if (nq > limit) return;
+    const uint32_t sub = threadIdx.x & 7;
+    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; q < nq; q += (gridDim.x * blockDim.x) >> 3) {
         const uint32_t c = queue[q];
         const uint64_t qo = c_qoff[c];
         const uint32_t lq = c_qlen[c];
-        for (uint32_t i = lane; i < lq; i += 64) {
-            const uint64_t pos = qo + i, w = pos >> 5;
-            const uint32_t sh = (uint32_t)pos & 31u;
-            const uint4 v = ((const uint4 *)planes)[w];
-            if ((v.w >> sh) & 1u) continue;
-            const uint32_t code = ((v.x >> sh) & 1u) | (((v.y >> sh) & 1u) << 1);
-            ascii[pos] = ((v.z >> sh) & 1u) ? (uint8_t)'N' : (uint8_t)("ACGT"[code]);
+        for (uint32_t i = 16 * sub; i < lq; i += 128) {
+            const uint4 v = planes4(planes, qo + i);
+            const uint32_t n = lq - i < 16 ? lq - i : 16;
+            uint8_t *dst = ascii + qo + i;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t L = up_spread4((v.x >> (4 * k)) & 15u), H = up_spread4((v.y >> (4 * k)) & 15u), N = up_spread4((v.z >> (4 * k)) & 15u);
+                uint32_t o = 0x41414141u + 2u * L + 6u * H + 0x0Bu * (L & H);
+                o = (o & ~(N * 0xffu)) | (N * 0x4Eu);
+                const uint32_t oth = (v.w >> (4 * k)) & 15u;
+#pragma unroll
+                for (uint32_t b = 0; b < 4; b++)
+                    if (4 * k + b < n && !((oth >> b) & 1u)) dst[4 * k + b] = (uint8_t)(o >> (8 * b));
+            }
         }
     }
 }

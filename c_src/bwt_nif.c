@@ -94,10 +94,13 @@ static ERL_NIF_TERM nif_index_meta(ErlNifEnv *env, int argc, const ERL_NIF_TERM 
 typedef struct {
     ERL_NIF_TERM *names; uint64_t *off; uint8_t *bases; int32_t *rstat; uint64_t *hoff;
     int32_t *score, *wlen; int64_t *pos, *woff; uint64_t *coff; char *cig; uint8_t *wins; uint64_t *woffs;
+    uint32_t *codes; uint64_t *exc;                                     /* the packed form of the reads (what crosses PCIe) */
+    int8_t *rstat8; bwt_hit_rec *hits; bwt_hit_extra *extra; char *xcig;   /* the compact hit table (what comes back) */
 } call_bufs;
 static void bufs_free(call_bufs *b) {
     free(b->names); free(b->off); free(b->bases); free(b->rstat); free(b->hoff); free(b->score); free(b->wlen);
     free(b->pos); free(b->woff); free(b->coff); free(b->cig); free(b->wins); free(b->woffs);
+    free(b->codes); free(b->exc); free(b->rstat8); free(b->hits); free(b->extra); free(b->xcig);
 }
 static ERL_NIF_TERM enomem(ErlNifEnv *env, call_bufs *b) {
     bufs_free(b);
@@ -144,24 +147,57 @@ static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM
     }
     if (i != n) { bufs_free(&B); return enif_make_badarg(env); }       /* improper list */
     uint64_t need[2] = {0, 0};
-    /* resident-batch interface: upload, run the three stages once, then size and fetch the hit tables
-     * (bwt_align_batch's two-call pattern would run the pipeline twice).  The handle's batch is used under its lock. */
+    /* The strings become the packed wire format on the host (2 bits per base + a list of the bases outside ACGT), go up, run the
+     * three stages once, and the compact hit table comes back (16 bytes per hit; window and CIGAR only for the hits that are not
+     * "<Lq>M" on a window of Lq bases) -- expanded here into the per-hit arrays the terms are built from.
+     * The handle's batch is used under its lock. */
     int nomem = 0;
+    uint64_t n_exc = 0, xneed[3] = {0, 0, 0}, exc_cap = used / 64 + 64;
+    B.codes = malloc(4 * (size_t)bwt_packed_words(used));
+    B.exc = malloc(8 * (size_t)exc_cap);
+    B.rstat8 = malloc((size_t)n + 1);
+    if (!B.codes || !B.exc || !B.rstat8) return enomem(env, &B);
+    int rc = bwt_pack_reads(B.bases, used, B.codes, B.exc, exc_cap, &n_exc, 1);
+    if (rc == BWT_ENOSPC) {                            /* many N: the count is known now */
+        free(B.exc);
+        exc_cap = n_exc;
+        B.exc = malloc(8 * (size_t)exc_cap + 8);
+        if (!B.exc) return enomem(env, &B);
+        rc = bwt_pack_reads(B.bases, used, B.codes, B.exc, exc_cap, &n_exc, 1);
+    }
+    if (rc) { ERL_NIF_TERM e = mk_error(env, rc); bufs_free(&B); return e; }
+    uint32_t shift_meta[5] = {0, 0, 0, 0, 0};
+    (void)bwt_index_meta(r->ix, shift_meta);
     enif_mutex_lock(r->lock);
-    int rc = bwt_batch_set_reads(r->batch, B.bases, B.off, n);
+    rc = bwt_batch_set_reads_packed(r->batch, B.codes, used, n, 0, B.off, B.exc, n_exc);
     if (!rc) rc = bwt_batch_run(r->batch, BWT_STAGE_EXTEND, NULL);
     if (!rc) {
-        rc = bwt_batch_fetch_hits(r->batch, B.rstat, B.hoff, 0, 0, 0, 0, 0, 0, 0, 0, need);
+        rc = bwt_batch_fetch_hits_compact(r->batch, 0, 0, 0, 0, 0, 0, 0, xneed);
         if (rc == BWT_ENOSPC || rc == 0) {
-            B.score = malloc(4 * (need[0] + 1)); B.wlen = malloc(4 * (need[0] + 1));
-            B.pos = malloc(8 * (need[0] + 1)); B.woff = malloc(8 * (need[0] + 1));
-            B.coff = malloc(8 * (need[0] + 2)); B.cig = malloc(need[1] + 1);
-            if (!B.score || !B.wlen || !B.pos || !B.woff || !B.coff || !B.cig) nomem = 1;
-            else rc = bwt_batch_fetch_hits(r->batch, B.rstat, B.hoff, B.score, B.pos, B.woff, B.wlen, B.coff, B.cig, need[0], need[1], need);
+            B.hits = malloc(sizeof(bwt_hit_rec) * (xneed[0] + 1)); B.extra = malloc(sizeof(bwt_hit_extra) * (xneed[1] + 1));
+            B.xcig = malloc(xneed[2] + 1);
+            if (!B.hits || !B.extra || !B.xcig) nomem = 1;
+            else rc = bwt_batch_fetch_hits_compact(r->batch, B.rstat8, B.hits, B.extra, B.xcig, xneed[0], xneed[1], xneed[2], xneed);
         }
     }
     enif_mutex_unlock(r->lock);
     if (nomem) return enomem(env, &B);
+    if (!rc) {
+        for (i = 0; i < n; i++) B.rstat[i] = B.rstat8[i];
+        need[0] = xneed[0];
+        B.score = malloc(4 * (need[0] + 1)); B.wlen = malloc(4 * (need[0] + 1));
+        B.pos = malloc(8 * (need[0] + 1)); B.woff = malloc(8 * (need[0] + 1));
+        B.coff = malloc(8 * (need[0] + 2));
+        if (!B.score || !B.wlen || !B.pos || !B.woff || !B.coff) return enomem(env, &B);
+        rc = bwt_hits_expand(n, 0, B.off, (int32_t)shift_meta[4], B.hits, xneed[0], B.extra, xneed[1], B.xcig, B.hoff, B.score, B.pos, B.woff,
+                             B.wlen, B.coff, NULL, 0, &need[1]);
+        if (!rc) {
+            B.cig = malloc(need[1] + 1);
+            if (!B.cig) return enomem(env, &B);
+            rc = bwt_hits_expand(n, 0, B.off, (int32_t)shift_meta[4], B.hits, xneed[0], B.extra, xneed[1], B.xcig, B.hoff, B.score, B.pos,
+                                 B.woff, B.wlen, B.coff, B.cig, need[1], &need[1]);
+        }
+    }
     /* RefSeq of every hit in one device gather (index-level call: thread-safe, no batch involved) */
     if (!rc && need[0]) {
         uint64_t tot = 0;
