@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-batch", action="store_true", help="one resident batch instead of two alternating ones")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="resident steps only (profiling: rocprofv3's tracing serialises the pipe's streams and inflates the event times; "
+                         "`value` is then the resident rate and says so)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -430,7 +433,7 @@ def main():
             a["ms"] += v["ms"]; a["launches"] += v["launches"]
 
     batches = []
-    if stages == lib.STAGE_EXTEND:
+    if stages == lib.STAGE_EXTEND and not args.no_pipeline:
         # ---- the timed region: K batches over the host boundary
         hp = HostPipeline(ix, packed_sets, n_reads, length, depth=3, options=opts, on_result=exchange if gather else None)
         hp.run(3)                                           # untimed set-up: every slot's device and pinned buffers at their final sizes
@@ -567,6 +570,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "value_is": ("host boundary (SURVEY 8d): packed reads in pinned host memory -> PCIe -> kernels -> compact hit tables in pinned "
                          "host memory, %d batches through bwt_pipe (depth 3) incl. pipeline fill and drain" % args.steps) if hp is not None
+                        else "resident steps only (--no-pipeline: a profiling run, not the metric)" if args.no_pipeline
                         else "search stage only, reads resident in HBM (BASELINE configs[1] times the kernel alone)",
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),

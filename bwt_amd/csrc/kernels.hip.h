@@ -2242,8 +2242,11 @@ struct CandSrc {
     const uint64_t *off; const uint32_t *r_K; const uint64_t *seed_off, *clus_off; const uint32_t *pos, *r_qty, *r_cl;
     uint32_t *c_S, *c_D; uint64_t *c_qoff; uint32_t *c_qlen; int64_t *c_woff; uint32_t *c_wlen;
 };
-template <bool FROM_READS>
-__global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
+// WPE: waves per SIMD the register allocation is held to (0 = the compiler's own choice: 91 VGPRs, 5 waves; 6 -> 80 VGPRs,
+// 8 -> 64 VGPRs and a few dwords of scratch): the kernel waits on dependent loads ~80 % of its time, more waves hide more
+template <bool FROM_READS, int WPE = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
+void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
     __shared__ uint32_t wq_[4][2][128];
     WaveQ qfp, qdp;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;

@@ -10,7 +10,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup 2 --workload $WL --no-cpu-baseline"
+# (resident steps only: under rocprofv3's tracing the pipe's streams are serialised against each other and a kernel's hipEvent
+# pair then also brackets its wait for another slot's copy / kernel -- the bytes per launch and the undisturbed durations are
+# what the profile is for; the default bench run times the same kernels live, inside the pipeline)
+BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup 2 --workload $WL --no-cpu-baseline --no-pipeline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${WL}_stats -o st -- $BENCH > $OUT/${WL}_bench_under_rocprof.json 2> $OUT/${WL}_stats.err || { tail -20 $OUT/${WL}_stats.err; exit 1; }
 echo "[profile] $WL kernel stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
