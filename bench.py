@@ -509,10 +509,9 @@ def main():
         kdepth, kwide = ix.ktable
         unfused = counts["n_small"] / max(counts["n_reads"], 1) if kwide else 1.0
         fast = "fm_lookup_rest" in per                     # k_seed_fast took the ordinary groups, k_seed_tasks the handed-back ones
-        rw_ = 64 // max(1, length // 8)
-        back = min(1.0, counts.get("n_handed_back", 0) * rw_ / max(counts["n_reads"], 1)) if fast else 1.0
-        # (of the groups k_seed_fast hands back, its two-register pass over that list keeps most; the general kernel takes the rest)
-        back2 = min(back, counts.get("n_general_groups", counts.get("n_handed_back", 0)) * rw_ / max(counts["n_reads"], 1)) if fast else 1.0
+        # (k_seed_fast hands single reads back to the general kernel)
+        back = min(1.0, counts.get("n_handed_back", 0) / max(counts["n_reads"], 1)) if fast else 1.0
+        back2 = back
         narrow = counts["n_reads"] * sum(1 for k in range(length // 8) if 8 <= length - 8 * k < kdepth) if kdepth else 0
         wide_l = max(0, counts["n_lookups"] - narrow) if kwide else 0
         narrow_l = counts["n_lookups"] - wide_l

@@ -877,7 +877,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         const unsigned int *nocount = nullptr;
         if (raw) KLAUNCH(b, "fm_lookup", (k_seed_tasks<true, false>), resident(0, (const void *)k_seed_tasks<true, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, 0u, nolist, nocount);
         else if (fast) {
-            if ((rc = b->gq.ensure(((size_t)n / (64 / maxT) + 2) * 4 + 256))) return rc;
+            if ((rc = b->gq.ensure(((size_t)n + 2) * 4 + 256))) return rc;          // (the reads k_seed_fast hands back: at most all of them)
             {
                 // reads of up to 14 sub-reads rarely pass 64 seeds: the one-register variant runs a wave more per SIMD
                 const bool big = b->opt.seed_big >= 0 ? b->opt.seed_big == 1 : maxT > 14;
@@ -1368,7 +1368,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     }
     if (!(stages & BWT_STAGE_EXTEND) && (rc = fetch_counters(b))) return rc;     // (the extend stage ends with the counters on the host)
     if (b->opt.debug > 0 && b->hctr.n_gq)
-        fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u groups: non-ACGT %u, table overflow %u, >64 seeds in a read %u, >%d clusters %u\n",
+        fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u reads: non-ACGT %u, table overflow %u, more seeds than its row holds %u, >%d clusters %u\n",
                 b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
     if (counts) {
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;

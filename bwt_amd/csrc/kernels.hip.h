@@ -760,14 +760,16 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
     const unsigned long long segmask = maxT == 64 ? ~0ull : ((1ull << maxT) - 1ull);
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    // glist != null: only the groups k_seed_fast handed back (it wrote nothing for them)
-    const uint32_t groups = glist ? *gcount : (n + rw - 1) / rw;
+    // glist != null: only the READS k_seed_fast handed back (it wrote nothing for them), rw of them per wave pass
+    const uint32_t nlisted = glist ? *gcount : 0u;
+    const uint32_t groups = glist ? (nlisted + rw - 1) / rw : (n + rw - 1) / rw;
     uint32_t live = 0, looked = 0, nsmall = 0, dmax = 0, had_pend = 0;
     unsigned long long Psum = 0;
     for (uint32_t gi = wave; gi < groups; gi += nwaves) {
-        const uint32_t g = glist ? glist[gi] : gi;
-        const uint32_t r = g * rw + lread;
+        const uint32_t li = gi * rw + lread;
+        const uint32_t r = !glist ? li : (lread < rw && li < nlisted) ? glist[li] : 0xffffffffu;
         const bool valid = lread < rw && r < n;
+        auto rid = [&](uint32_t j) { return (uint32_t)__shfl((int)r, (int)(j * maxT), 64); };      // the pass's j-th read (j wave-uniform)
         LfTask tk;
         tk.task = (uint64_t)r * maxT + slot;
         tk.sp = 0; tk.ep = 0; tk.lo16 = 0; tk.hi16 = 0; tk.status = TS_NONE; tk.n = 0; tk.nlim = 0;
@@ -980,12 +982,12 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                     bool fba, fbb = false;
                     if (last) {
                         pa = wave_sort_u32(pa);
-                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall, dmax);
+                        fba = cl_emit64(pa, Pa, qa, rid(ja), r_cl, r_K, r_P, r_qty, nsmall, dmax);
                     } else {
                         uint32_t pb = lane < Pj ? lp[j * CL_ROW + lane] : 0xffffffffu;
                         wave_sort2_u32(pa, pb);
-                        fba = cl_emit64(pa, Pa, qa, g * rw + ja, r_cl, r_K, r_P, r_qty, nsmall, dmax);
-                        fbb = cl_emit64(pb, Pj, qj, g * rw + j, r_cl, r_K, r_P, r_qty, nsmall, dmax);
+                        fba = cl_emit64(pa, Pa, qa, rid(ja), r_cl, r_K, r_P, r_qty, nsmall, dmax);
+                        fbb = cl_emit64(pb, Pj, qj, rid(j), r_cl, r_K, r_P, r_qty, nsmall, dmax);
                     }
                     if (lean && valid && ((fba && lread == ja) || (fbb && lread == j))) {
                         t_sp[tk.task] = tk.sp; t_ep[tk.task] = tk.ep; t_info[tk.task] = status | ((uint32_t)tk.n << 8); t_cnt[tk.task] = c;
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
                     held = 0xffffffffu;
                     continue;
                 }
-                const uint32_t rj = g * rw + j;
+                const uint32_t rj = rid(j);
                 const uint32_t nthr = 2 + qj / 7;                     // sga.erl:46
                 uint32_t *row = lp + j * CL_ROW;
                 {
@@ -1107,7 +1109,8 @@ __host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT, bool big) {
 // 5 % on batches whose reads rarely pass 64 seeds, e.g. 100-bp reads)
 // SUM: the batch's sub-read below the top level looks at the summary bit first (DevIndex::ktsum covers its level)
 template <bool BIG, bool SUM>
-__global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
+void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                     uint32_t *__restrict__ r_K, uint32_t *__restrict__ r_cl,
@@ -1201,7 +1204,6 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const bool valid = lread < rw && r < n;
         const bool act = valid && e > 0;
         const bool abn0 = abn0_c;
-        bool abn = abn0;
         live += (uint32_t)__popcll(__ballot(act));
         // transpose through LDS: afterwards slot t of the staging area holds the whole entry of lane t
         const uint32_t qb = (lane & ~3u) * SF_SLOT + ql;
@@ -1219,18 +1221,23 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         planes_raw(g + 2 * nwaves, wa, wb);
         const uint32_t wd = own.y & KT_OVF, nn = own.y >> 28;
         // bwa.erl:31-45 at the end of the search: the range check applies unless a step came back not_found (n < m)
-        const bool seeds = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
-        const uint32_t c = seeds ? wd + 1u : 0u;
-        // (a task with more seeds than a row holds: its read is over the limit anyway, and the packed scan below must not overflow)
-        abn = abn || (act && wd == KT_OVF) || c > ROW;
-        if (__ballot(abn)) {                                           // hand the group back
-            why += __ballot(abn0) ? 1u : __ballot(act && wd == KT_OVF) ? 1u << 8 : 0u;
-            if (!__ballot(abn0) && !__ballot(act && wd == KT_OVF)) why2 += 1u;          // (a task over the row limit counts as a read over it)
-            __builtin_amdgcn_wave_barrier();
-            waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
-            live -= (uint32_t)__popcll(__ballot(act));
-            continue;
+        const bool seeds0 = act && !((int)nn >= m && wd > BWT_MAX_RANGE) && nn >= BWT_MIN_LEN;
+        // A read that is not ordinary -- a base outside ACGT, a table entry that did not fit, a task with more seeds than a row
+        // holds (its read is over the limit anyway, and the packed scan below must not overflow) -- is handed back ALONE: its
+        // lanes take no further part in the pass (round 2 handed back the whole group of 64 / maxT reads: on a repeat-rich genome
+        // three quarters of all groups hold such a read and went through the general kernel for it).
+        const bool ovf = act && wd == KT_OVF, over = seeds0 && wd + 1u > ROW;
+        const unsigned long long b_abn0 = __ballot(abn0), b_ovf = __ballot(ovf), b_over = __ballot(over);
+        bool dropped = false;                                          // my read goes to the general kernel
+        if (b_abn0 | b_ovf | b_over) {
+            const unsigned long long segm = (((1ull << maxT) - 1ull) << seg0);
+            const bool d0 = (b_abn0 & segm) != 0, d1 = !d0 && (b_ovf & segm) != 0, d2 = !d0 && !d1 && (b_over & segm) != 0;
+            dropped = valid && (d0 || d1 || d2);
+            why += (uint32_t)__popcll(__ballot(valid && slot == 0 && d0)) + ((uint32_t)__popcll(__ballot(valid && slot == 0 && d1)) << 8);
+            why2 += (uint32_t)__popcll(__ballot(valid && slot == 0 && d2));
         }
+        const bool seeds = seeds0 && !dropped;
+        const uint32_t c = seeds ? wd + 1u : 0u;
         const uint32_t nadd = nn + shsk;                               // N + Shift (sga.erl:32,37-39; nothing skipped)
         // one packed scan: low half = seeds, high half = sub-reads that returned a seed list (Qty)
         const uint32_t v = c | (seeds ? 0x10000u : 0u);
@@ -1241,13 +1248,12 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
         const uint32_t lo = seg0 ? lo_any : 0u;
         const uint32_t Pq = hi - lo, P = Pq & 0xffffu, qty = Pq >> 16;
         const uint32_t dst = (incl - v - lo) & 0xffffu;
-        const bool fuse_read = valid && qty >= 2 && P > 0;             // sga.erl:42-43
-        if (__ballot(fuse_read && P > ROW)) {
-            why2 += 1u;
-            __builtin_amdgcn_wave_barrier();
-            waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
-            live -= (uint32_t)__popcll(__ballot(act));
-            continue;
+        bool fuse_read = valid && !dropped && qty >= 2 && P > 0;       // sga.erl:42-43
+        if (__ballot(fuse_read && P > ROW)) {                          // a read with more seeds than a row holds: handed back (P is the same in all its lanes)
+            const bool d = fuse_read && P > ROW;
+            why2 += (uint32_t)__popcll(__ballot(d && slot == 0));
+            dropped = dropped || d;
+            fuse_read = fuse_read && !d;
         }
         // every lane copies its own seeds (+ N + Shift) into its read's row
         {
@@ -1392,11 +1398,16 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
             em1 = lead ? ((sm1 >> 1) | last1) & vm1 & ok1 : 0ull;
         }
         const uint32_t Kc = (uint32_t)(__popcll(em0) + __popcll(em1));
-        if (__ballot(Kc > CL_STAGE)) {                                 // a read with more clusters than its staging row holds
-            why2 += 1u << 16;
-            waveq_push(q, lane == 0, g, gq, &ctr->n_gq);
-            live -= (uint32_t)__popcll(__ballot(act));
-            continue;
+        if (__ballot(Kc > CL_STAGE)) {                                 // a read with more clusters than its staging row holds: handed back
+            const unsigned long long bk = __ballot(lead && Kc > CL_STAGE);      // (bit seg0 of every such read)
+            why2 += (uint32_t)__popcll(bk) << 16;
+            if ((bk >> seg0) & 1ull) { dropped = dropped || valid; fuse_read = false; em0 = 0; em1 = 0; }
+        }
+        // the reads of this pass that go to the general kernel (which writes everything for them), and their tasks off this kernel's count
+        if (__ballot(dropped)) {
+            live -= (uint32_t)__popcll(__ballot(act && dropped));
+            __builtin_amdgcn_wave_barrier();
+            waveq_push(q, dropped && slot == 0, r, gq, &ctr->n_gq);
         }
         // the group's results
         {
@@ -1423,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_seed_fast(DevIndex ix, const uint32_t *
                 }
             }
         }
-        if (valid && slot == 0) {
+        if (valid && slot == 0 && !dropped) {
             // (r_pend and r_P of the reads this kernel keeps are zero: the host cleared both arrays before the launch)
             r_qty[r] = qty | (fuse_read ? RQ_DONE : 0u);
             if (fuse_read) { r_K[r] = Kc; Pacc += P; }

@@ -249,7 +249,7 @@ typedef struct {
     uint64_t n_dp;                   /* candidates the prefilter could not settle (ran the DP)  */
     uint64_t n_lookups;              /* tasks answered or started from the suffix-interval table */
     uint64_t n_small;                /* reads with 1..64 seeds left to k_cluster_small (the rest: none, fused, or wider kernels) */
-    uint64_t n_handed_back;          /* groups of reads k_seed_fast handed back to the general seed kernel (0 when it did not run) */
+    uint64_t n_handed_back;          /* reads k_seed_fast handed back to the general seed kernel (0 when it did not run) */
     uint64_t n_banded;               /* DP candidates settled by the banded kernel (exact by its certificate); n_dp counts them too */
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);

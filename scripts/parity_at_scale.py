@@ -57,12 +57,16 @@ def main():
     bases[dirty * L + rng.integers(0, L, len(dirty))] = np.frombuffer(b"NNNNRYKM", np.uint8)[rng.integers(0, 8, len(dirty))]
     off = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
     print("setup %.1f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+    # through the wire formats of the host boundary (round 3): packed upload, compact hit table, host-side expansion
     batch = lib.Batch(ix)
-    batch.set_reads(bases, off)
+    codes, exc = lib.pack_2bit(bases)
+    batch.set_reads_packed(codes, exc, n, read_len=L)
     t0 = time.perf_counter()
     c = batch.run(lib.STAGE_EXTEND)
     t_gpu = time.perf_counter() - t0
-    hits = batch.fetch_hits()
+    comp = batch.fetch_hits_compact()
+    hits = lib.hits_expand(n, L, None, ix.meta()[1], comp["hits"], comp["extra"], comp["cigar"])
+    hits["read_status"] = comp["read_status"].astype(np.int32)
     gpu = orc.hits_digest(hits)
     Lc, SA = ix.export()
     ptr, shift = ix.meta()
@@ -81,10 +85,10 @@ def main():
     out = {"workload": "i.i.d. genome of %d bp%s, %d reads of %d bp: 3/4 with 0-%d substitutions, 1/4 with an indel of 1-5 bp "
                        "as well, 2 %% of the reads with an N or IUPAC base%s" % (a.genome_len, (" with 40 segments of 600 bp in %d copies each" % a.repeats) if a.repeats else "",
                                                                                  n, L, a.max_subs, ", a tenth of the reads from the repeats" if a.repeats else ""),
-           "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order)",
+           "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order); GPU side: packed upload (%d exceptions), compact table (%d extras of %d hits), expanded on the host" % (len(exc), len(comp["extra"]), len(comp["hits"])),
            "reads": n, "reads_with_hits": int((np.diff(hits["hit_off"].astype(np.int64)) > 0).sum()), "hits": int(c["n_hits"]),
            "reads_status_minus1": int((hits["read_status"] == -1).sum()), "dp_candidates": int(c["n_dp"]), "fp64_candidates": int(c["n_float"]),
-           "handed_back_groups": int(c["n_handed_back"]), "banded": int(c.get("n_banded", 0)), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
+           "handed_back_reads": int(c["n_handed_back"]), "banded": int(c.get("n_banded", 0)), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
            "gpu_s": t_gpu, "cpu_s": t_cpu, "cpu_threads": cores}
     print(json.dumps(out))
     batch.destroy(); ix.close()
