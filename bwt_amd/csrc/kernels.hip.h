@@ -3255,8 +3255,17 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
         if (!(clf & CIG_DIAG)) {
             HitExtra x; x.hit = (uint32_t)ho; x.win_len = wl; x.cig_off = (uint32_t)co; x.cig_len = clf;
             x_rec[xo++] = x;
-            const uint8_t *src = cig + k * (uint64_t)cig_stride + (cig_stride - clf);
-            for (uint32_t i = 0; i < clf; i++) x_cig[co + i] = src[i];
+            // the text sits right-aligned in its slot (slots are multiples of 32 bytes, 16-byte aligned): it is taken 16 bytes at a
+            // time from the slot's end by aligned loads and stored byte by byte (stores do not stall the lane; a byte loop of
+            // dependent load / store pairs took 2.9 ms for the 15 M extras of a repeat-rich batch)
+            const uint8_t *slot_end = cig + (k + 1) * (uint64_t)cig_stride;
+            for (uint32_t done = 0; done < clf; done += 16) {
+                const uint4 v = *(const uint4 *)(slot_end - done - 16);
+                const unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
+                const uint32_t take = clf - done < 16 ? clf - done : 16;
+                uint8_t *dst = x_cig + co + (clf - done) - 16;                 // byte i of the chunk goes to dst[i], i = 16 - take .. 15
+                for (uint32_t i = 16 - take; i < 16; i++) dst[i] = (uint8_t)((i < 8 ? lo : hi) >> (8 * (i & 7)));
+            }
             co += clf;
         }
         ho++;

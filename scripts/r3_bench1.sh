@@ -1,5 +1,4 @@
 set -x
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r3_t8.log 2>&1; tail -6 gpurun_out/r3_t8.log
-bash scripts/r3_exp.sh grch38 BWT_X=0
-bash scripts/r3_exp.sh grch38-repeats BWT_DEBUG=1 BWT_SEED_BIG=1
+timeout -k 10 900 python -m pytest tests/test_gpu_packed.py tests/test_gpu_parity.py tests/test_gpu_modes.py -m gpu -q -x > gpurun_out/r3_t9.log 2>&1; tail -4 gpurun_out/r3_t9.log
+bash scripts/r3_exp.sh grch38-repeats BWT_X=0
 bash scripts/r3_exp.sh paired150 BWT_X=0
