@@ -369,7 +369,8 @@ struct bwt_batch {
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
     DevBuf bq, bq2, slab_band;         // k_sw_band: the queues of what its two tiers pass on, the direction slab
     bool band_ran = false;
-    int occ_prefilter = 0, occ_prefilter_wpe = -1;   // resident blocks per CU of k_sw_prefilter<true> (queried once per batch and variant)
+    int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
+    DevBuf pfq;                        // candidates the fused prefilter pass listed for the quad-per-candidate pass
     // hits
     uint64_t n_hits = 0, cig_bytes = 0;
     uint64_t n_extra = 0, xcig_bytes = 0;
@@ -508,7 +509,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
     (void)hipStreamSynchronize(b->stream);
     prof_collect(b);
     for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
-    DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->pk_codes, &b->pk_exc, &b->r_nx, &b->r_xcb, &b->x_off, &b->xcb_off, &b->x_rec, &b->x_cig, &b->h_xidx, &b->h_len, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
+    DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->pk_codes, &b->pk_exc, &b->pfq, &b->r_nx, &b->r_xcb, &b->x_off, &b->xcb_off, &b->x_rec, &b->x_cig, &b->h_xidx, &b->h_len, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
@@ -1090,21 +1091,22 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             src.r_cl = b->r_cl.as<uint32_t>(); src.c_S = b->c_S.as<uint32_t>(); src.c_D = b->c_D.as<uint32_t>(); src.c_qoff = b->c_qoff.as<uint64_t>();
             src.c_qlen = b->c_qlen.as<uint32_t>(); src.c_woff = b->c_woff.as<int64_t>(); src.c_wlen = b->c_wlen.as<uint32_t>();
             // grid = what is resident at once (the passes are uniform: a second, partly filled round of blocks would cost a quarter)
-            const int wpe = b->opt.pf_waves_per_eu == 6 ? 6 : b->opt.pf_waves_per_eu == 8 ? 8 : 0;
-            const void *kern = wpe == 6 ? (const void *)k_sw_prefilter<true, 6> : wpe == 8 ? (const void *)k_sw_prefilter<true, 8> : (const void *)k_sw_prefilter<true, 0>;
-            if (!b->occ_prefilter || b->occ_prefilter_wpe != wpe) {
+            if (!b->occ_prefilter) {
                 int per_cu = 5;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 5; }
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sw_prefilter<true>, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 5; }
                 b->occ_prefilter = std::max(1, std::min(per_cu, 8));
-                b->occ_prefilter_wpe = wpe;
                 if (b->opt.pf_blocks_per_cu > 0) b->occ_prefilter = std::max(1, std::min((int)b->opt.pf_blocks_per_cu, b->occ_prefilter));   // experiments
             }
+            // the candidates past the first PF_KCAP of a read are listed by the fused pass and tested by a second one, quad per candidate
+            if ((rc = b->pfq.ensure(nc * 4 + 256))) return rc;
+            Counters *dc = b->ctr.as<Counters>();
+            src.ovq = b->pfq.as<uint32_t>(); src.ov_count = &dc->pf_ov;
+            const uint32_t pf_grid = (uint32_t)std::min<uint64_t>(cdiv((uint64_t)b->n * 4, 256), (uint64_t)dev_cus * b->occ_prefilter);
+            KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, pf_grid, 256, io, b->n, src);
             {
-                const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv((uint64_t)b->n * 4, 256), (uint64_t)dev_cus * b->occ_prefilter);
-                ProfScope ps(b, "sw_prefilter");
-                if (wpe == 6) hipLaunchKernelGGL((k_sw_prefilter<true, 6>), dim3(grid), dim3(256), 0, b->stream, io, b->n, src);
-                else if (wpe == 8) hipLaunchKernelGGL((k_sw_prefilter<true, 8>), dim3(grid), dim3(256), 0, b->stream, io, b->n, src);
-                else hipLaunchKernelGGL((k_sw_prefilter<true, 0>), dim3(grid), dim3(256), 0, b->stream, io, b->n, src);
+                CandSrc rest{};
+                rest.list = b->pfq.as<uint32_t>(); rest.list_count = &dc->pf_ov;
+                KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, (uint32_t)dev_cus * (uint32_t)b->occ_prefilter, 256, io, (uint32_t)nc, rest);
             }
             b->cand_pending = false;
             if (!b->max_w_known && (rc = fetch_counters(b))) return rc;    // max_w / max_lq size the DP kernels' LDS and slabs

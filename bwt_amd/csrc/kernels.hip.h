@@ -2252,15 +2252,26 @@ __device__ __forceinline__ uint4 quad_planes4(const uint32_t *__restrict__ plane
 struct CandSrc {
     const uint64_t *off; const uint32_t *r_K; const uint64_t *seed_off, *clus_off; const uint32_t *pos, *r_qty, *r_cl;
     uint32_t *c_S, *c_D; uint64_t *c_qoff; uint32_t *c_qlen; int64_t *c_woff; uint32_t *c_wlen;
+    // FROM_READS: the candidates past the first PF_KCAP of a read are only described (window arithmetic) and listed here;
+    // !FROM_READS with list != null: the pass over that list, quad per candidate
+    uint32_t *ovq; unsigned int *ov_count;
+    const uint32_t *list; const unsigned int *list_count;
 };
-// WPE: waves per SIMD the register allocation is held to (0 = the compiler's own choice: 91 VGPRs, 5 waves; 6 -> 80 VGPRs,
-// 8 -> 64 VGPRs and a few dwords of scratch): the kernel waits on dependent loads ~80 % of its time, more waves hide more
-template <bool FROM_READS, int WPE = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
-void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
-    __shared__ uint32_t wq_[4][2][128];
-    WaveQ qfp, qdp;
+// A wave of the fused pass takes 16 reads and loops to the LARGEST cluster count among them: on a repeat-rich genome one read in
+// twelve has a dozen or more clusters, three waves in four hold such a read, and the other fifteen quads idle through its loop
+// (8.8 ms for 29 M candidates where 12 M take 1.0 ms).  So the fused pass tests at most PF_KCAP candidates per read; the others
+// get their descriptors written (four per quad step, stores only) and go into a list that a second launch works through with
+// a quad per candidate.
+#define PF_KCAP 2u
+// (Held to more waves per SIMD -- 6: 80 VGPRs, 8: 64 VGPRs, a few dwords of scratch each -- the kernel is slower: 1.12 / 1.55 ms
+// against 1.01 at the compiler's own 91 VGPRs and 5 waves, although it waits on dependent loads ~80 % of its time.)
+template <bool FROM_READS>
+__global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
+    __shared__ uint32_t wq_[4][3][128];
+    WaveQ qfp, qdp, qov;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
+    qov.buf = wq_[threadIdx.x >> 6][2]; qov.have = 0;
+    if (!FROM_READS && src.list) n_items = *src.list_count;
     const uint32_t *qp = io.qplanes, *wp = io.wplanes;
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t stride = (gridDim.x * blockDim.x) >> 2;                  // candidates (reads) per sweep
@@ -2295,11 +2306,29 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
                 maxlq = lq_r > maxlq ? lq_r : maxlq;
             }
         }
+        if (FROM_READS && kmax > PF_KCAP) {
+            // the candidates past the first PF_KCAP of every read of this pass: descriptors and list entries, four per quad step
+            for (uint32_t kb = PF_KCAP; kb < kmax; kb += 4) {
+                const uint32_t kc = kb + (uint32_t)ql;
+                const bool have = kc < K_r;
+                const uint32_t c = (uint32_t)(co_r + kc);
+                if (have) {
+                    const uint32_t S = cl_r[2 * kc], D = cl_r[2 * kc + 1], w = lq_r + D;
+                    src.c_S[c] = S; src.c_D[c] = D; src.c_qoff[c] = qo_r; src.c_qlen[c] = lq_r; src.c_wlen[c] = w;
+                    src.c_woff[c] = (int64_t)S - (int64_t)w + BWT_REF_EXT;
+                    cells += (unsigned long long)lq_r * w; wbytes += w;
+                    maxw = w > maxw ? w : maxw;
+                }
+                waveq_push(qov, have, c, src.ovq, src.ov_count);
+            }
+            kmax = PF_KCAP;
+            K_r = K_r < PF_KCAP ? K_r : PF_KCAP;
+        }
         for (uint32_t kc = 0; kc < kmax; kc++) {                              // (one pass unless FROM_READS)
-            const uint32_t c = FROM_READS ? (uint32_t)(co_r + kc) : item;
+            const uint32_t c = FROM_READS ? (uint32_t)(co_r + kc) : src.list ? (item < n_items ? src.list[item] : 0u) : item;
             int route = 0;                 // 0 nothing (idle / out of range / settled), 1 fp64 queue, 2 DP queue
             // quad-uniform from here on: the four lanes of a quad hold the same candidate
-            const bool have = FROM_READS ? kc < K_r : c < n_items;
+            const bool have = FROM_READS ? kc < K_r : item < n_items;
             uint32_t lq, w;
             int64_t wo;
             uint64_t qo;
@@ -2428,6 +2457,7 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
     waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
     waveq_drain(qdp, io.dq, &io.ctr->dq_count);
     if (FROM_READS) {
+        waveq_drain(qov, src.ovq, src.ov_count);
         cells = wave_sum_u64(cells); wbytes = wave_sum_u64(wbytes);
         maxw = wave_max_u32(maxw); maxlq = wave_max_u32(maxlq);
         if ((threadIdx.x & 63) == 0 && maxlq) {

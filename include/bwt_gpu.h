@@ -71,7 +71,6 @@ typedef struct {
     int32_t sw_pk;              /* 0: no packed-i16 DP kernels */
     int32_t sw_trace_all;       /* 0: score-only DP pass first, traceback for what needs it */
     int32_t pf_blocks_per_cu, sw_blocks_per_cu, sw_waves_per_cu;   /* occupancy caps (experiments) */
-    int32_t pf_waves_per_eu;    /* 6 / 8: the prefilter compiled for that many waves per SIMD (fewer registers) */
     int32_t debug;              /* 1: diagnostic lines on stderr (hand-back reasons of k_seed_fast) */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
