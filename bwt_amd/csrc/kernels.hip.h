@@ -1108,8 +1108,9 @@ __host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT, bool big) {
 // BIG: reads of up to 128 seeds (two registers per read; 106 VGPRs, 4 waves per SIMD); else up to 64 (95 VGPRs, 5 waves -- worth
 // 5 % on batches whose reads rarely pass 64 seeds, e.g. 100-bp reads)
 // SUM: the batch's sub-read below the top level looks at the summary bit first (DevIndex::ktsum covers its level)
+// (the two-register variant is held to five waves per SIMD: left alone it takes 104 VGPRs since reads are handed back one by one)
 template <bool BIG, bool SUM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIG ? 5 : 4, 8)))
 void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
                                                     uint32_t ulen, unsigned long long *__restrict__ r_pend,
                                                     uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
@@ -1201,7 +1202,7 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         }
         if ((why | why2) & 0x80808080u) { why = 0; why2 = 0; }
         const uint32_t r = g * rw + lread;
-        const bool valid = lread < rw && r < n;
+        bool valid = lread < rw && r < n;                              // (cleared for a read that is handed back)
         const bool act = valid && e > 0;
         const bool abn0 = abn0_c;
         live += (uint32_t)__popcll(__ballot(act));
@@ -1228,15 +1229,22 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         // three quarters of all groups hold such a read and went through the general kernel for it).
         const bool ovf = act && wd == KT_OVF, over = seeds0 && wd + 1u > ROW;
         const unsigned long long b_abn0 = __ballot(abn0), b_ovf = __ballot(ovf), b_over = __ballot(over);
-        bool dropped = false;                                          // my read goes to the general kernel
+        // handing a read back: its index into the queue of the general kernel (which writes everything for it), its tasks off this
+        // kernel's count, its lanes out of the rest of the pass (`valid` cleared: no flag of its own to keep in a register)
+        auto hand_back = [&](bool d) {
+            live -= (uint32_t)__popcll(__ballot(act && d));
+            __builtin_amdgcn_wave_barrier();
+            waveq_push(q, d && slot == 0, r, gq, &ctr->n_gq);
+            valid = valid && !d;
+        };
         if (b_abn0 | b_ovf | b_over) {
             const unsigned long long segm = (((1ull << maxT) - 1ull) << seg0);
             const bool d0 = (b_abn0 & segm) != 0, d1 = !d0 && (b_ovf & segm) != 0, d2 = !d0 && !d1 && (b_over & segm) != 0;
-            dropped = valid && (d0 || d1 || d2);
             why += (uint32_t)__popcll(__ballot(valid && slot == 0 && d0)) + ((uint32_t)__popcll(__ballot(valid && slot == 0 && d1)) << 8);
             why2 += (uint32_t)__popcll(__ballot(valid && slot == 0 && d2));
+            hand_back(valid && (d0 || d1 || d2));
         }
-        const bool seeds = seeds0 && !dropped;
+        const bool seeds = seeds0 && valid;
         const uint32_t c = seeds ? wd + 1u : 0u;
         const uint32_t nadd = nn + shsk;                               // N + Shift (sga.erl:32,37-39; nothing skipped)
         // one packed scan: low half = seeds, high half = sub-reads that returned a seed list (Qty)
@@ -1248,12 +1256,12 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         const uint32_t lo = seg0 ? lo_any : 0u;
         const uint32_t Pq = hi - lo, P = Pq & 0xffffu, qty = Pq >> 16;
         const uint32_t dst = (incl - v - lo) & 0xffffu;
-        bool fuse_read = valid && !dropped && qty >= 2 && P > 0;       // sga.erl:42-43
+        bool fuse_read = valid && qty >= 2 && P > 0;                   // sga.erl:42-43
         if (__ballot(fuse_read && P > ROW)) {                          // a read with more seeds than a row holds: handed back (P is the same in all its lanes)
             const bool d = fuse_read && P > ROW;
             why2 += (uint32_t)__popcll(__ballot(d && slot == 0));
-            dropped = dropped || d;
             fuse_read = fuse_read && !d;
+            hand_back(d);
         }
         // every lane copies its own seeds (+ N + Shift) into its read's row
         {
@@ -1401,13 +1409,9 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         if (__ballot(Kc > CL_STAGE)) {                                 // a read with more clusters than its staging row holds: handed back
             const unsigned long long bk = __ballot(lead && Kc > CL_STAGE);      // (bit seg0 of every such read)
             why2 += (uint32_t)__popcll(bk) << 16;
-            if ((bk >> seg0) & 1ull) { dropped = dropped || valid; fuse_read = false; em0 = 0; em1 = 0; }
-        }
-        // the reads of this pass that go to the general kernel (which writes everything for them), and their tasks off this kernel's count
-        if (__ballot(dropped)) {
-            live -= (uint32_t)__popcll(__ballot(act && dropped));
-            __builtin_amdgcn_wave_barrier();
-            waveq_push(q, dropped && slot == 0, r, gq, &ctr->n_gq);
+            const bool d = valid && ((bk >> seg0) & 1ull) != 0;
+            if (d) { fuse_read = false; em0 = 0; em1 = 0; }
+            hand_back(d);
         }
         // the group's results
         {
@@ -1434,7 +1438,7 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
                 }
             }
         }
-        if (valid && slot == 0 && !dropped) {
+        if (valid && slot == 0) {
             // (r_pend and r_P of the reads this kernel keeps are zero: the host cleared both arrays before the launch)
             r_qty[r] = qty | (fuse_read ? RQ_DONE : 0u);
             if (fuse_read) { r_K[r] = Kc; Pacc += P; }
