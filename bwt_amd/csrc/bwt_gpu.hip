@@ -358,6 +358,7 @@ struct bwt_batch {
     bool fused = false;                // ... and clustered what it could (r_K zeroed, RQ_DONE reads staged in r_cl)
     bool cand_pending = false;         // the candidate arrays are still to be made (by the prefilter, from the per-read clusters)
     bool max_w_known = false;          // ... and the largest window is known without asking the prefilter
+    bool desc_partial = false;         // the fused prefilter wrote c_qoff / c_qlen / c_woff only for the candidates it queued
     // reads
     DevBuf r_P, r_qty, r_K, r_nhit, r_cigb, r_status, bigq, mid2q, mid4q, seed_off, clus_off, hit_off, cigb_off;
     DevBuf pos, scan_tmp;
@@ -949,6 +950,7 @@ static int stage_search(bwt_batch *b, bool lean) {
 static int stage_cluster(bwt_batch *b, bool to_extend) {
     const uint32_t n = b->n, maxT = b->maxT;
     int rc;
+    b->desc_partial = false;
     if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
         (rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->bigq.ensure((size_t)n * 4 + 4)) ||
         (rc = b->mid2q.ensure((size_t)n * 4 + 4)) || (rc = b->mid4q.ensure((size_t)n * 4 + 4)) ||
@@ -1101,6 +1103,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             if ((rc = b->pfq.ensure(nc * 4 + 256))) return rc;
             Counters *dc = b->ctr.as<Counters>();
             src.ovq = b->pfq.as<uint32_t>(); src.ov_count = &dc->pf_ov;
+            src.ulen = b->ulen;
             const uint32_t pf_grid = (uint32_t)std::min<uint64_t>(cdiv((uint64_t)b->n * 4, 256), (uint64_t)dev_cus * b->occ_prefilter);
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, pf_grid, 256, io, b->n, src);
             {
@@ -1109,10 +1112,23 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
                 KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, (uint32_t)dev_cus * (uint32_t)b->occ_prefilter, 256, io, (uint32_t)nc, rest);
             }
             b->cand_pending = false;
+            b->desc_partial = true;        // read offset / length and window offset exist only for the candidates that were queued
             if (!b->max_w_known && (rc = fetch_counters(b))) return rc;    // max_w / max_lq size the DP kernels' LDS and slabs
             max_w = b->hctr.max_w; max_lq = b->hctr.max_lq;
-        } else
+        } else {
+            if (b->desc_partial) {
+                // a retry (wider CIGAR slots) after a fused first attempt: every candidate's descriptor is needed now; k_candidates
+                // writes them all (its totals go to a scratch block: the first attempt counted them already)
+                if ((rc = b->scan_tmp.ensure(sizeof(Counters) + 64))) return rc;
+                HIPCHK(hipMemsetAsync(b->scan_tmp.p, 0, sizeof(Counters), b->stream));
+                KLAUNCH(b, "candidates", k_candidates, std::min<uint32_t>(cdiv(b->n, 256), 2048), 256, b->n, b->off.as<uint64_t>(), b->r_K.as<uint32_t>(),
+                        b->seed_off.as<uint64_t>(), b->clus_off.as<uint64_t>(), b->pos.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_cl.as<uint32_t>(),
+                        b->c_read.as<uint32_t>(), b->c_S.as<uint32_t>(), b->c_D.as<uint32_t>(), b->c_qoff.as<uint64_t>(), b->c_qlen.as<uint32_t>(),
+                        b->c_woff.as<int64_t>(), b->c_wlen.as<uint32_t>(), b->scan_tmp.as<Counters>());
+                b->desc_partial = false;
+            }
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>(cdiv(nc * 4, 256), 2048), 256, io, (uint32_t)nc, src);   // quad per candidate
+        }
     }
     // A packed batch keeps no ASCII copy of its reads.  The kernels of the generic DP path read bytes (k_sw_wave, k_sw_score,
     // k_sw<...>): each gets, right in front of it, the bytes of the candidates queued for it, made from the planes; with no

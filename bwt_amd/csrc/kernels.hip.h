@@ -2260,6 +2260,7 @@ struct CandSrc {
     // !FROM_READS with list != null: the pass over that list, quad per candidate
     uint32_t *ovq; unsigned int *ov_count;
     const uint32_t *list; const unsigned int *list_count;
+    uint32_t ulen;                               // > 0: every read has this length (no offset loads)
 };
 // A wave of the fused pass takes 16 reads and loops to the LARGEST cluster count among them: on a repeat-rich genome one read in
 // twelve has a dozen or more clusters, three waves in four hold such a read, and the other fifteen quads idle through its loop
@@ -2270,7 +2271,8 @@ struct CandSrc {
 // (Held to more waves per SIMD -- 6: 80 VGPRs, 8: 64 VGPRs, a few dwords of scratch each -- the kernel is slower: 1.12 / 1.55 ms
 // against 1.01 at the compiler's own 91 VGPRs and 5 waves, although it waits on dependent loads ~80 % of its time.)
 template <bool FROM_READS>
-__global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
     __shared__ uint32_t wq_[4][3][128];
     WaveQ qfp, qdp, qov;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
@@ -2282,6 +2284,24 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
     const uint32_t first = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 2;
     unsigned long long cells = 0, wbytes = 0;                               // FROM_READS: what k_candidates totals
     uint32_t maxw = 0, maxlq = 0;
+    // FROM_READS: everything a read's first candidate needs is asked for at once -- its cluster count, offsets, flags and the first
+    // staged cluster of its r_cl row, whether or not that row turns out to be in use -- and ONE PASS AHEAD: the pass that tests
+    // read i's windows starts by asking for read i + stride's words, so that they travel together with this pass's window planes
+    // and a pass is one round trip to memory, not two dependent ones (the kernel is bound by the latency of its loads)
+    // (the read offsets are not carried ahead: batches of one read length compute them, the others load them in the pass itself)
+    struct Pre { uint32_t K, rq; uint64_t co; uint2 cl0; };
+    auto prefetch = [&](uint32_t it) {
+        Pre p;
+        const bool inr = it < n_items;
+        p.K = inr ? src.r_K[it] : 0u;
+        p.co = inr ? src.clus_off[it] : 0ull;
+        p.rq = inr ? src.r_qty[it] : 0u;
+        p.cl0 = make_uint2(0u, 0u);
+        if (inr && src.r_cl) p.cl0 = *(const uint2 *)(src.r_cl + (uint64_t)it * (2 * CL_STAGE));
+        return p;
+    };
+    Pre nx{};
+    if (FROM_READS) nx = prefetch(first + ((threadIdx.x & 63) >> 2));
     for (uint32_t c0 = first; c0 < n_items; c0 += stride) {                 // whole waves iterate together
         const uint32_t item = c0 + ((threadIdx.x & 63) >> 2);
         uint32_t K_r = 1, kmax = 1;
@@ -2291,15 +2311,15 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
         uint2 cl0 = make_uint2(0u, 0u);
         bool cl0_ok = false;
         if (FROM_READS) {
-            // everything a read's first candidate needs is asked for at once -- its cluster count, offsets, flags and the first
-            // staged cluster of its r_cl row, whether or not that row turns out to be in use -- so that the window planes are the
-            // second round trip of the pass, not the fourth (the kernel is bound by the latency of its dependent loads)
-            const bool inr = item < n_items;
-            K_r = inr ? src.r_K[item] : 0u;
-            const uint64_t o0 = inr ? src.off[item] : 0ull, o1 = inr ? src.off[item + 1] : 0ull;
-            const uint64_t co = inr ? src.clus_off[item] : 0ull;
-            const uint32_t rq = inr ? src.r_qty[item] : 0u;
-            if (inr && src.r_cl) cl0 = *(const uint2 *)(src.r_cl + (uint64_t)item * (2 * CL_STAGE));
+            const Pre cur = nx;
+            nx = prefetch(item + stride);
+            K_r = cur.K;
+            uint64_t o0, o1;
+            if (src.ulen) { o0 = (uint64_t)item * src.ulen; o1 = o0 + src.ulen; }
+            else { const bool inr = item < n_items; o0 = inr ? src.off[item] : 0ull; o1 = inr ? src.off[item + 1] : 0ull; }
+            const uint64_t co = cur.co;
+            const uint32_t rq = cur.rq;
+            cl0 = cur.cl0;
             kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(K_r));
             if (K_r) {
                 qo_r = o0; lq_r = (uint32_t)(o1 - o0);
@@ -2342,7 +2362,9 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
                 lq = have ? lq_r : 0u; w = have ? lq_r + D : 0u; qo = qo_r;
                 wo = (int64_t)S - (int64_t)w + BWT_REF_EXT;
                 if (have && ql == 0) {
-                    src.c_S[c] = S; src.c_D[c] = D; src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_wlen[c] = w; src.c_woff[c] = wo;
+                    // (what the hit tables need of every candidate; read offset / length and window offset only matter to the DP
+                    // kernels and are written below for the candidates that are queued for one: 20 bytes less per settled candidate)
+                    src.c_S[c] = S; src.c_D[c] = D; src.c_wlen[c] = w;
                     cells += (unsigned long long)lq * w; wbytes += w;
                     maxw = w > maxw ? w : maxw;
                 }
@@ -2453,6 +2475,7 @@ __global__ __launch_bounds__(256) void k_sw_prefilter(SwIO io, uint32_t n_items,
                     io.c_status[c] = len > io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
                 }
             }
+            if (FROM_READS && route != 0 && ql == 0) { src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_woff[c] = wo; }
             // the two queues, staged in LDS (one atomic per 64 entries)
             waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
             waveq_push(qdp, route == 2 && ql == 0, c, io.dq, &io.ctr->dq_count);
