@@ -1108,7 +1108,7 @@ __host__ __device__ inline uint32_t sf_lds_bytes(uint32_t maxT, bool big) {
 // BIG: reads of up to 128 seeds (two registers per read; 106 VGPRs, 4 waves per SIMD); else up to 64 (95 VGPRs, 5 waves -- worth
 // 5 % on batches whose reads rarely pass 64 seeds, e.g. 100-bp reads)
 // SUM: the batch's sub-read below the top level looks at the summary bit first (DevIndex::ktsum covers its level)
-// (the two-register variant is held to five waves per SIMD: left alone it takes 104 VGPRs since reads are handed back one by one)
+// (the two-register variant is held to the five waves per SIMD its LDS allows: left alone it takes 100 VGPRs)
 template <bool BIG, bool SUM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIG ? 5 : 4, 8)))
 void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, uint32_t maxT,
@@ -1228,7 +1228,6 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         // lanes take no further part in the pass (round 2 handed back the whole group of 64 / maxT reads: on a repeat-rich genome
         // three quarters of all groups hold such a read and went through the general kernel for it).
         const bool ovf = act && wd == KT_OVF, over = seeds0 && wd + 1u > ROW;
-        const unsigned long long b_abn0 = __ballot(abn0), b_ovf = __ballot(ovf), b_over = __ballot(over);
         // handing a read back: its index into the queue of the general kernel (which writes everything for it), its tasks off this
         // kernel's count, its lanes out of the rest of the pass (`valid` cleared: no flag of its own to keep in a register)
         auto hand_back = [&](bool d) {
@@ -1237,7 +1236,29 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
             waveq_push(q, d && slot == 0, r, gq, &ctr->n_gq);
             valid = valid && !d;
         };
-        if (b_abn0 | b_ovf | b_over) {
+        // (the two-register variant leaves the pass when it hands a read back and sends the other reads of the pass -- two at most --
+        // along: carrying on costs it registers it does not have, 104 VGPRs = a wave per SIMD less, or spills; its batches are long
+        // reads, where a pass holds three reads and hand-backs are rare)
+#define SF_HAND_BACK(d)                                                                                       \
+        if (BIG) {                                                                                            \
+            if (__ballot(d)) {                                                                                \
+                live -= (uint32_t)__popcll(__ballot(act && valid));                                           \
+                __builtin_amdgcn_wave_barrier();                                                              \
+                waveq_push(q, valid && slot == 0, r, gq, &ctr->n_gq);                                         \
+                continue;                                                                                     \
+            }                                                                                                 \
+        } else hand_back(d)
+        if (BIG) {
+            if (__ballot(abn0 || ovf || over)) {                       // (leaves the pass: see SF_HAND_BACK)
+                why += __ballot(abn0) ? 1u : __ballot(ovf) ? 1u << 8 : 0u;
+                if (!__ballot(abn0) && !__ballot(ovf)) why2 += 1u;
+                live -= (uint32_t)__popcll(__ballot(act));
+                __builtin_amdgcn_wave_barrier();
+                waveq_push(q, valid && slot == 0, r, gq, &ctr->n_gq);
+                continue;
+            }
+        } else if (__ballot(abn0 || ovf || over)) {
+            const unsigned long long b_abn0 = __ballot(abn0), b_ovf = __ballot(ovf), b_over = __ballot(over);
             const unsigned long long segm = (((1ull << maxT) - 1ull) << seg0);
             const bool d0 = (b_abn0 & segm) != 0, d1 = !d0 && (b_ovf & segm) != 0, d2 = !d0 && !d1 && (b_over & segm) != 0;
             why += (uint32_t)__popcll(__ballot(valid && slot == 0 && d0)) + ((uint32_t)__popcll(__ballot(valid && slot == 0 && d1)) << 8);
@@ -1261,7 +1282,7 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
             const bool d = fuse_read && P > ROW;
             why2 += (uint32_t)__popcll(__ballot(d && slot == 0));
             fuse_read = fuse_read && !d;
-            hand_back(d);
+            SF_HAND_BACK(d);
         }
         // every lane copies its own seeds (+ N + Shift) into its read's row
         {
@@ -1411,7 +1432,7 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
             why2 += (uint32_t)__popcll(bk) << 16;
             const bool d = valid && ((bk >> seg0) & 1ull) != 0;
             if (d) { fuse_read = false; em0 = 0; em1 = 0; }
-            hand_back(d);
+            SF_HAND_BACK(d);
         }
         // the group's results
         {
@@ -1444,6 +1465,7 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
             if (fuse_read) { r_K[r] = Kc; Pacc += P; }
         }
     }
+#undef SF_HAND_BACK
     waveq_drain(q, gq, &ctr->n_gq);
     if (lane == 0 && (why | why2)) {
         atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);

@@ -277,9 +277,10 @@ def test_fast_seed_kernel_read_lengths(repeat_index, length):
         b.destroy()
         assert check_against_oracle(out, reads, ofm, ref1) > 100
         kept.append(len(reads) - c["n_handed_back"])
-    # the fast kernel really took reads (on this small genome the 8..10-base last sub-reads of the longest reads alone bring ~30
-    # seeds: past 64 per read for the one-register variant); the two-register variant keeps at least as many
-    assert kept[1] > 0 and kept[1] >= kept[0]
+    # both variants of the fast kernel really took reads (on this small genome the 8..10-base last sub-reads of the longest reads
+    # alone bring ~30 seeds: past 64 per read for the one-register variant; the two-register variant holds up to 128 but sends the
+    # other reads of a pass along with one it hands back)
+    assert kept[0] > 0 and kept[1] > 0
 
 
 @pytest.mark.parametrize("length", [48, 64, 100, 150, 175, 400])
