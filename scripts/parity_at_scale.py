@@ -25,10 +25,15 @@ def main():
     ap.add_argument("--length", type=int, default=100)
     ap.add_argument("--max-subs", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=0, help="plant this many copies of 40 segments of 600 bp each (reads from them: many seeds, several clusters)")
+    ap.add_argument("--spectrum", action="store_true", help="the bench's repeat-rich genome (bench.synth_genome_repeats: SINE / LINE-like families, mid-copy families, tandem and low-complexity tracts, segmental duplications)")
     ap.add_argument("--seed", type=int, default=91)
     a = ap.parse_args()
     t0 = time.perf_counter()
-    ref = bench.synth_genome(a.genome_len, seed=5)
+    composition = None
+    if a.spectrum:
+        ref, composition = bench.synth_genome_repeats(a.genome_len, seed=5)
+    else:
+        ref = bench.synth_genome(a.genome_len, seed=5)
     rep_starts = []
     if a.repeats:
         ref = ref.copy()
@@ -82,7 +87,8 @@ def main():
         print("cpu %d / %d" % (hi, n), file=sys.stderr, flush=True)
     t_cpu = time.perf_counter() - t0
     bad = np.nonzero(gpu != cpu)[0]
-    out = {"workload": "i.i.d. genome of %d bp%s, %d reads of %d bp: 3/4 with 0-%d substitutions, 1/4 with an indel of 1-5 bp "
+    out = {"repeat_spectrum": composition,
+           "workload": "i.i.d. genome of %d bp%s, %d reads of %d bp: 3/4 with 0-%d substitutions, 1/4 with an indel of 1-5 bp "
                        "as well, 2 %% of the reads with an N or IUPAC base%s" % (a.genome_len, (" with 40 segments of 600 bp in %d copies each" % a.repeats) if a.repeats else "",
                                                                                  n, L, a.max_subs, ", a tenth of the reads from the repeats" if a.repeats else ""),
            "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order); GPU side: packed upload (%d exceptions), compact table (%d extras of %d hits), expanded on the host" % (len(exc), len(comp["extra"]), len(comp["hits"])),

@@ -162,3 +162,25 @@ def test_compact_table_on_a_repeat_genome():
         b.destroy()
     finally:
         ix.close()
+
+
+def test_pipe_packs_a_batch_that_is_mostly_exceptions(gpu_index, orc_fm, ref_bytes):
+    """bwt_pipe_submit_ascii on a batch whose exception list outgrows the slot's buffer (reads that are mostly N): the slot's thread
+    grows the pinned buffer and packs again; the answers are still the oracle's."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = synth_reads(ref_bytes, 200, 100, 77) + [b"N" * 100] * 300 + synth_reads(ref_bytes, 100, 100, 78, n_frac=1.0)
+    bases, off = lib.pack_reads(reads)
+    pipe = lib.Pipe(gpu_index, depth=1)
+    try:
+        s, v = pipe.acquire_packed(len(bases), len(reads), 16)            # room for 16 exceptions; the batch has > 30 000
+        v["off"][:] = off
+        v["ascii"][:len(bases)] = bases
+        pipe.submit_ascii(s, len(reads), 100)
+        r = pipe.wait()
+        out = pipe.expand(r)
+        pipe.release(r["slot"])
+    finally:
+        pipe.close()
+    assert oracle_check(out, reads, orc_fm, ref1) > 100
