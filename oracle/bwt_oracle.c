@@ -295,10 +295,19 @@ done:
 int orc_align_read(const orc_fm *fm, const uint8_t *ref1, int64_t ref1_len, const uint8_t *q, int lq,
                    int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len,
                    char *cigars, int cig_cap, int cap, int64_t *cells) {
-    enum { MAXC = 4096 };
-    int64_t *S = (int64_t *)malloc(sizeof(int64_t) * MAXC);
-    int32_t *D = (int32_t *)malloc(sizeof(int32_t) * MAXC);
-    int nc = orc_sga(fm, q, lq, S, D, MAXC, 0);
+    /* room for 4096 clusters, and once more with 2^20 when a read has more (low-complexity reads on a repeat-rich genome have
+     * tens of thousands: round 3's parity runs met them) */
+    int maxc = 4096;
+    int64_t *S = (int64_t *)malloc(sizeof(int64_t) * maxc);
+    int32_t *D = (int32_t *)malloc(sizeof(int32_t) * maxc);
+    int nc = orc_sga(fm, q, lq, S, D, maxc, 0);
+    if (nc == -2) {
+        free(S); free(D);
+        maxc = 1 << 20;
+        S = (int64_t *)malloc(sizeof(int64_t) * maxc);
+        D = (int32_t *)malloc(sizeof(int32_t) * maxc);
+        nc = orc_sga(fm, q, lq, S, D, maxc, 0);
+    }
     if (nc <= 0) { free(S); free(D); return nc == 0 ? -1 : (nc == -1 ? -2 : -4); }
     int kept = 0, cp = 0;
     /* Seeds1 is in descending order; Cigars is built by prepending => process clusters in
@@ -346,10 +355,11 @@ typedef struct {
 
 static void *job_run(void *p) {
     job_t *j = (job_t *)p;
-    enum { CAP = 256 };
+    int CAP = 256, CIGCAP = 1 << 16;                    /* grown once for a read with more alignments (repeat-rich genomes) */
     int64_t S[4096]; int32_t D[4096];
-    int32_t score[CAP]; int64_t pos[CAP], woff[CAP]; int32_t wlen[CAP];
-    char *cig = (char *)malloc(1 << 16);
+    int32_t *score = (int32_t *)malloc(sizeof(int32_t) * CAP), *wlen = (int32_t *)malloc(sizeof(int32_t) * CAP);
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * CAP), *woff = (int64_t *)malloc(sizeof(int64_t) * CAP);
+    char *cig = (char *)malloc(CIGCAP);
     for (uint32_t r = j->lo; r < j->hi; r++) {
         const uint8_t *q = j->bases + j->off[r];
         int lq = (int)(j->off[r + 1] - j->off[r]);
@@ -360,15 +370,25 @@ static void *job_run(void *p) {
                 for (int k = 0; k < nc; k++) j->checksum += S[k] * 31 + D[k];
             }
         } else {
+            int64_t cells0 = j->cells;
             int n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen,
-                                   cig, 1 << 16, CAP, &j->cells);
+                                   cig, CIGCAP, CAP, &j->cells);
+            if (n == -4 && CAP < (1 << 20)) {
+                free(score); free(wlen); free(pos); free(woff); free(cig);
+                CAP = 1 << 20; CIGCAP = 1 << 26;
+                score = (int32_t *)malloc(sizeof(int32_t) * CAP); wlen = (int32_t *)malloc(sizeof(int32_t) * CAP);
+                pos = (int64_t *)malloc(sizeof(int64_t) * CAP); woff = (int64_t *)malloc(sizeof(int64_t) * CAP);
+                cig = (char *)malloc(CIGCAP);
+                j->cells = cells0;
+                n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen, cig, CIGCAP, CAP, &j->cells);
+            }
             if (n > 0) {
                 j->aligned++; j->clusters += n;
                 for (int k = 0; k < n; k++) j->checksum += pos[k] * 31 + score[k];
             }
         }
     }
-    free(cig);
+    free(cig); free(score); free(wlen); free(pos); free(woff);
     return 0;
 }
 
@@ -404,7 +424,7 @@ typedef struct { const orc_fm *fm; const uint8_t *ref1; int64_t ref1_len; const 
                  uint32_t lo, hi; uint64_t *dig; } djob_t;
 static void *djob_run(void *p) {
     djob_t *j = (djob_t *)p;
-    enum { CAP = 4096, CIGCAP = 1 << 20 };             /* (a read from a 300-copy repeat has 300 alignments; orc_sga itself stops at 4096 clusters) */
+    int CAP = 4096, CIGCAP = 1 << 20;                  /* (a read from a 300-copy repeat has 300 alignments; grown once for the reads that have more) */
     int32_t *score = (int32_t *)malloc(sizeof(int32_t) * CAP), *wlen = (int32_t *)malloc(sizeof(int32_t) * CAP);
     int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * CAP), *woff = (int64_t *)malloc(sizeof(int64_t) * CAP);
     char *cig = (char *)malloc(CIGCAP);
@@ -412,6 +432,14 @@ static void *djob_run(void *p) {
         const uint8_t *q = j->bases + j->off[r];
         int lq = (int)(j->off[r + 1] - j->off[r]);
         int n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen, cig, CIGCAP, CAP, 0);
+        if (n == -4 && CAP < (1 << 20)) {               /* more than 4096 alignments: the buffers grow once, the read is done again */
+            free(score); free(wlen); free(pos); free(woff); free(cig);
+            CAP = 1 << 20; CIGCAP = 1 << 26;
+            score = (int32_t *)malloc(sizeof(int32_t) * CAP); wlen = (int32_t *)malloc(sizeof(int32_t) * CAP);
+            pos = (int64_t *)malloc(sizeof(int64_t) * CAP); woff = (int64_t *)malloc(sizeof(int64_t) * CAP);
+            cig = (char *)malloc(CIGCAP);
+            n = orc_align_read(j->fm, j->ref1, j->ref1_len, q, lq, score, pos, woff, wlen, cig, CIGCAP, CAP, 0);
+        }
         uint64_t d = 0;
         if (n == -4) d = 2;                              /* the oracle's own capacity: not an answer (never equals a GPU digest) */
         else if (n < -1) d = 1;

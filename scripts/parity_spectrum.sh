@@ -1,6 +1,6 @@
 set -x
 mkdir -p gpurun_out/parity_r3
-timeout -k 10 300 python -m pytest tests/test_gpu_packed.py -m gpu -q -x 2>&1 | tail -2
+
 python scripts/parity_at_scale.py --reads 1500000 --spectrum > gpurun_out/parity_r3/parity_at_scale_spectrum.json 2> gpurun_out/parity_r3/d.err || { tail -5 gpurun_out/parity_r3/d.err; }
 python scripts/parity_at_scale.py --reads 1000000 --spectrum --length 150 > gpurun_out/parity_r3/parity_at_scale_spectrum_150bp.json 2> gpurun_out/parity_r3/e.err || { tail -5 gpurun_out/parity_r3/e.err; }
 cat gpurun_out/parity_r3/parity_at_scale_spectrum*.json | cut -c1-300
