@@ -606,7 +606,6 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
 
 // ------------------------------------------------------------------------------------------------
 // Packed upload (include/bwt_gpu.h): 2 bits per base + an exception list up, the planes made on the device.
-extern "C" uint64_t bwt_packed_words(uint64_t total_bases) { return 2 * ((total_bases + 31) / 32) + 2; }
 
 extern "C" int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, uint64_t total, uint32_t n, uint32_t read_len,
                                           const uint64_t *off, const uint64_t *exc, uint64_t n_exc) {
@@ -1525,45 +1524,6 @@ extern "C" int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, b
         (rc = d2h(b, (HitExtra *)extra, b->x_rec, b->n_extra)) || (rc = d2h(b, cigar, b->x_cig, b->xcig_bytes)))
         return rc;
     HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
-}
-
-// the same expansion as k_hits_expand, on the host, for a compact table that has left the device (pipe results, gathered tables)
-extern "C" int bwt_hits_expand(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const bwt_hit_rec *hits, uint64_t n_hits,
-                               const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t *hit_off, int32_t *score,
-                               int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t cig_cap,
-                               uint64_t *cig_needed) {
-    if ((!hits && n_hits) || (!extra && n_extra) || (!read_len && !off && n_hits)) return fail(BWT_EINVAL, "bwt_hits_expand: null argument");
-    auto lq_of = [&](uint32_t r) { return read_len ? read_len : (uint32_t)(off[r + 1] - off[r]); };
-    auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; };
-    uint64_t xi = 0, co = 0, r_next = 0;
-    for (uint64_t h = 0; h < n_hits; h++) {
-        const bwt_hit_rec &hr = hits[h];
-        if (hr.read >= n || (h && hr.read < hits[h - 1].read)) return fail(BWT_EINVAL, "bwt_hits_expand: hits must be ascending by read");
-        if (hit_off) while (r_next <= hr.read) hit_off[r_next++] = h;
-        const bool ex = xi < n_extra && extra[xi].hit == h;
-        const uint32_t lq = lq_of(hr.read), cl = ex ? extra[xi].cig_len : digits(lq) + 1;
-        if (score) score[h] = hr.score;
-        if (pos) pos[h] = hr.pos;
-        if (win_off) win_off[h] = hr.pos - shift + BWT_REF_EXT;
-        if (win_len) win_len[h] = (int32_t)(ex ? extra[xi].win_len : lq);
-        if (cig_off) cig_off[h] = co;
-        if (cigar && co + cl <= cig_cap) {
-            if (ex) memcpy(cigar + co, xcigar + extra[xi].cig_off, cl);
-            else {
-                cigar[co + cl - 1] = 'M';
-                uint32_t v = lq;
-                for (uint32_t x = cl - 1; x-- > 0;) { cigar[co + x] = (char)('0' + v % 10); v /= 10; }
-            }
-        }
-        co += cl;
-        if (ex) xi++;
-    }
-    if (xi != n_extra) return fail(BWT_EINVAL, "bwt_hits_expand: extras must be ascending by hit and name existing hits");
-    if (hit_off) while (r_next <= n) hit_off[r_next++] = n_hits;
-    if (cig_off) cig_off[n_hits] = co;
-    if (cig_needed) *cig_needed = co;
-    if (cigar && co > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
     return 0;
 }
 

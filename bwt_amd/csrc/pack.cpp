@@ -1,5 +1,8 @@
-// libbwtgpu: bwt_pack_reads -- ASCII bases -> the packed wire format of the host boundary (include/bwt_gpu.h): two bits per
-// base as a low and a high bit-plane word per 32 bases, plus an exception list for everything outside ACGT.  Host only.
+// libbwtgpu: the host side of the boundary's wire formats (include/bwt_gpu.h).  Host only: no HIP in this file (the sanitizer
+// harness tests/fuzz/host_fuzz.cpp builds it with g++).
+//   bwt_pack_reads   ASCII bases -> two bits per base as a low and a high bit-plane word per 32 bases, plus an exception list for
+//                    everything outside ACGT;
+//   bwt_hits_expand  a compact hit table -> the per-hit arrays of bwt_align_batch (what k_hits_expand does on the device).
 //
 // Eight bases at a time: with x the 8 ASCII bytes, bit 1 and bit 2 of every byte give the code (A 41 -> 00, C 43 -> 01,
 // G 47 -> 10, T 54 -> 11: hi = bit 2, lo = bit 1 ^ bit 2); the byte the code stands for is rebuilt arithmetically
@@ -51,6 +54,8 @@ void pack_range(const uint8_t *bases, uint64_t a, uint64_t e, uint32_t *codes, s
 }
 }  // namespace
 
+extern "C" uint64_t bwt_packed_words(uint64_t total_bases) { return 2 * ((total_bases + 31) / 32) + 2; }
+
 extern "C" int bwt_pack_reads(const uint8_t *bases, uint64_t total, uint32_t *codes, uint64_t *exc, uint64_t exc_cap,
                               uint64_t *n_exc, uint32_t threads) {
     if ((!bases && total) || !codes || (!exc && exc_cap)) return bwt_fail(BWT_EINVAL, "bwt_pack_reads: null argument");
@@ -77,5 +82,51 @@ extern "C" int bwt_pack_reads(const uint8_t *bases, uint64_t total, uint32_t *co
     if (k > exc_cap) return bwt_fail(BWT_ENOSPC, "bwt_pack_reads: exception capacity too small");
     uint64_t o = 0;
     for (auto &v : ex) { if (!v.empty()) memcpy(exc + o, v.data(), v.size() * 8); o += v.size(); }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same expansion as k_hits_expand, on the host, for a compact table that has left the device (pipe results, gathered tables).
+// Every index and offset of the table is checked against its array: a table from elsewhere (another rank, a file) cannot make this
+// read or write out of bounds.
+extern "C" int bwt_hits_expand(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const bwt_hit_rec *hits, uint64_t n_hits,
+                               const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t xcigar_len, uint64_t *hit_off,
+                               int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar,
+                               uint64_t cig_cap, uint64_t *cig_needed) {
+    enum { REF_EXT = 200 };                                   // ?REF_EXTENSION_LEN, src/worker_bwt.erl:17 (bwt_constants().ref_extension_len)
+    if ((!hits && n_hits) || (!extra && n_extra) || (!xcigar && xcigar_len) || (!read_len && !off && n_hits))
+        return bwt_fail(BWT_EINVAL, "bwt_hits_expand: null argument");
+    auto lq_of = [&](uint32_t r) { return read_len ? read_len : (uint32_t)(off[r + 1] - off[r]); };
+    auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; };
+    uint64_t xi = 0, co = 0, r_next = 0;
+    for (uint64_t h = 0; h < n_hits; h++) {
+        const bwt_hit_rec &hr = hits[h];
+        if (hr.read >= n || (h && hr.read < hits[h - 1].read)) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: hits must be ascending by read");
+        if (hit_off) while (r_next <= hr.read) hit_off[r_next++] = h;
+        const bool ex = xi < n_extra && extra[xi].hit == h;
+        if (ex && ((uint64_t)extra[xi].cig_off + extra[xi].cig_len > xcigar_len))
+            return bwt_fail(BWT_EINVAL, "bwt_hits_expand: an extra's text lies outside the text buffer");
+        const uint32_t lq = lq_of(hr.read), cl = ex ? extra[xi].cig_len : digits(lq) + 1;
+        if (score) score[h] = hr.score;
+        if (pos) pos[h] = hr.pos;
+        if (win_off) win_off[h] = hr.pos - shift + REF_EXT;
+        if (win_len) win_len[h] = (int32_t)(ex ? extra[xi].win_len : lq);
+        if (cig_off) cig_off[h] = co;
+        if (cigar && co + cl <= cig_cap) {
+            if (ex) memcpy(cigar + co, xcigar + extra[xi].cig_off, cl);
+            else {
+                cigar[co + cl - 1] = 'M';
+                uint32_t v = lq;
+                for (uint32_t x = cl - 1; x-- > 0;) { cigar[co + x] = (char)('0' + v % 10); v /= 10; }
+            }
+        }
+        co += cl;
+        if (ex) xi++;
+    }
+    if (xi != n_extra) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: extras must be ascending by hit and name existing hits");
+    if (hit_off) while (r_next <= n) hit_off[r_next++] = n_hits;
+    if (cig_off) cig_off[n_hits] = co;
+    if (cig_needed) *cig_needed = co;
+    if (cigar && co > cig_cap) return bwt_fail(BWT_ENOSPC, "cigar capacity too small");
     return 0;
 }

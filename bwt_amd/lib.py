@@ -194,7 +194,7 @@ def hits_expand(n, read_len, off, shift, hits, extra, xcigar):
 
     def call(cig, cap):
         return load().bwt_hits_expand(C.c_uint32(n), C.c_uint32(read_len), _p(off64), C.c_int32(shift), _p(hits), C.c_uint64(nh), _p(extra),
-                                      C.c_uint64(len(extra)), _p(xc), _p(hoff), _p(score), _p(pos), _p(woff), _p(wlen), _p(coff), _p(cig),
+                                      C.c_uint64(len(extra)), _p(xc), C.c_uint64(len(xc)), _p(hoff), _p(score), _p(pos), _p(woff), _p(wlen), _p(coff), _p(cig),
                                       C.c_uint64(cap), C.byref(need))
     _chk(call(None, 0))
     cig = np.empty(need.value, np.uint8)

@@ -189,13 +189,13 @@ static ERL_NIF_TERM nif_align_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM
         B.pos = malloc(8 * (need[0] + 1)); B.woff = malloc(8 * (need[0] + 1));
         B.coff = malloc(8 * (need[0] + 2));
         if (!B.score || !B.wlen || !B.pos || !B.woff || !B.coff) return enomem(env, &B);
-        rc = bwt_hits_expand(n, 0, B.off, (int32_t)shift_meta[4], B.hits, xneed[0], B.extra, xneed[1], B.xcig, B.hoff, B.score, B.pos, B.woff,
-                             B.wlen, B.coff, NULL, 0, &need[1]);
+        rc = bwt_hits_expand(n, 0, B.off, (int32_t)shift_meta[4], B.hits, xneed[0], B.extra, xneed[1], B.xcig, xneed[2], B.hoff, B.score, B.pos,
+                             B.woff, B.wlen, B.coff, NULL, 0, &need[1]);
         if (!rc) {
             B.cig = malloc(need[1] + 1);
             if (!B.cig) return enomem(env, &B);
-            rc = bwt_hits_expand(n, 0, B.off, (int32_t)shift_meta[4], B.hits, xneed[0], B.extra, xneed[1], B.xcig, B.hoff, B.score, B.pos,
-                                 B.woff, B.wlen, B.coff, B.cig, need[1], &need[1]);
+            rc = bwt_hits_expand(n, 0, B.off, (int32_t)shift_meta[4], B.hits, xneed[0], B.extra, xneed[1], B.xcig, xneed[2], B.hoff, B.score,
+                                 B.pos, B.woff, B.wlen, B.coff, B.cig, need[1], &need[1]);
         }
     }
     /* RefSeq of every hit in one device gather (index-level call: thread-safe, no batch involved) */

@@ -336,11 +336,12 @@ int bwt_batch_compact_to_device(bwt_batch *b, void *dst_hits, uint64_t cap_hits,
                                 void *dst_cigar, uint64_t cap_cigar, uint32_t read_base);
 /* Host-side expansion of a compact table into the arrays of bwt_align_batch (no GPU): read_len > 0 for a uniform batch,
  * else off[0..n] gives the read lengths.  hit_off n+1, score/pos/win_off/win_len n_hits, cig_off n_hits+1; cigar
- * capacity cig_cap (BWT_ENOSPC + *cig_needed otherwise). */
+ * capacity cig_cap (BWT_ENOSPC + *cig_needed otherwise).  Every index of the table is checked (read ids < n and ascending,
+ * extras ascending and naming hits, their text inside xcigar[0 .. xcigar_len)): BWT_EINVAL, never an access out of bounds. */
 int bwt_hits_expand(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const bwt_hit_rec *hits, uint64_t n_hits,
-                    const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t *hit_off, int32_t *score,
-                    int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar, uint64_t cig_cap,
-                    uint64_t *cig_needed);
+                    const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t xcigar_len, uint64_t *hit_off,
+                    int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar,
+                    uint64_t cig_cap, uint64_t *cig_needed);
 
 /* ------------------------------------------------------------------ host-buffer pipeline
  * The worker's `running` clause as a pipeline over host buffers: `depth` slots, each with a resident batch (own HIP

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -106,6 +107,76 @@ int main(int argc, char **argv) {
         }
     }
     remove(tmp);
-    printf("fm: %d parsed, %d refused; fastq calls: %d ok, %d refused\n", ok_fm, bad_fm, ok_fq, bad_fq);
+    // ---- the wire formats (bwt_amd/csrc/pack.cpp): the packer on arbitrary bytes with EXACTLY sized buffers (any overrun is an ASan
+    // report), its output against a byte-by-byte restatement; the table expansion on tables with every field mutated
+    int ok_pk = 0, ok_ex = 0, bad_ex = 0;
+    for (int r = 0; r < rounds * 4; r++) {
+        const size_t total = r < 70 ? (size_t)r : (size_t)(rnd() % 70000);
+        std::vector<uint8_t> b(total);
+        for (auto &c : b) c = (rnd() % 13) ? (uint8_t)"ACGT"[rnd() % 4] : (uint8_t)rnd();
+        std::vector<uint32_t> codes((size_t)bwt_packed_words(total), 0xdeadbeefu);
+        uint64_t nexc = 0;
+        std::vector<uint64_t> exc(4);
+        int rc = bwt_pack_reads(b.data(), total, codes.data(), exc.data(), exc.size(), &nexc, 1 + (uint32_t)(rnd() % 5));
+        if (rc == BWT_ENOSPC) {
+            exc.assign((size_t)nexc, 0);
+            rc = bwt_pack_reads(b.data(), total, codes.data(), exc.data(), exc.size(), &nexc, 1 + (uint32_t)(rnd() % 5));
+        }
+        if (rc) { fprintf(stderr, "bwt_pack_reads failed: %s\n", g_err.c_str()); return 1; }
+        size_t xi = 0;
+        for (size_t i = 0; i < total; i++) {
+            const uint8_t c = b[i];
+            const int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+            const uint32_t lo = (codes[2 * (i / 32)] >> (i % 32)) & 1u, hi = (codes[2 * (i / 32) + 1] >> (i % 32)) & 1u;
+            if (code < 0) {
+                if (xi >= nexc || exc[xi] != ((uint64_t)i | (uint64_t)c << 56) || lo || hi) { fprintf(stderr, "packer: exception %zu wrong\n", i); return 1; }
+                xi++;
+            } else if ((int)(lo | hi << 1) != code) { fprintf(stderr, "packer: code %zu wrong\n", i); return 1; }
+        }
+        if (xi != nexc) { fprintf(stderr, "packer: exception count\n"); return 1; }
+        ok_pk++;
+    }
+    for (int r = 0; r < rounds * 20; r++) {
+        // a well-formed table of nh hits over n reads, some with extras; then mutate any field
+        const uint32_t n = 1 + (uint32_t)(rnd() % 40);
+        const uint64_t nh = rnd() % 60;
+        std::vector<uint64_t> off(n + 1, 0);
+        for (uint32_t i = 0; i < n; i++) off[i + 1] = off[i] + 20 + rnd() % 300;
+        std::vector<bwt_hit_rec> hits((size_t)nh);
+        std::vector<bwt_hit_extra> extra;
+        std::string text;
+        uint32_t rd = 0;
+        for (uint64_t h = 0; h < nh; h++) {
+            rd = std::min<uint32_t>(n - 1, rd + (uint32_t)(rnd() % 3));
+            hits[(size_t)h] = {rd, (int32_t)(rnd() % 400), (int64_t)(rnd() % 100000) - 300};
+            if (rnd() % 3 == 0) { const std::string t = std::to_string(1 + rnd() % 90) + "M2D" + std::to_string(1 + rnd() % 90) + "M"; extra.push_back({(uint32_t)h, (uint32_t)(100 + rnd() % 30), (uint32_t)text.size(), (uint32_t)t.size()}); text += t; }
+        }
+        const bool mutated = r % 3 != 0;
+        if (mutated) {
+            const int what = (int)(rnd() % 6);
+            if (what == 0 && nh) hits[(size_t)(rnd() % nh)].read = (uint32_t)rnd();
+            else if (what == 1 && !extra.empty()) extra[rnd() % extra.size()].hit = (uint32_t)rnd();
+            else if (what == 2 && !extra.empty()) extra[rnd() % extra.size()].cig_off = (uint32_t)rnd();
+            else if (what == 3 && !extra.empty()) extra[rnd() % extra.size()].cig_len = (uint32_t)rnd();
+            else if (what == 4 && nh > 1) std::swap(hits[0], hits[(size_t)nh - 1]);
+            else if (!extra.empty()) extra.pop_back(), extra.insert(extra.begin(), {(uint32_t)nh + 5, 100, 0, 1});
+        }
+        std::vector<uint64_t> hoff(n + 1), coff((size_t)nh + 1);
+        std::vector<int32_t> sc((size_t)nh), wl((size_t)nh);
+        std::vector<int64_t> ps((size_t)nh), wo((size_t)nh);
+        uint64_t need = 0;
+        int rc = bwt_hits_expand(n, 0, off.data(), 1, hits.data(), nh, extra.data(), extra.size(), text.data(), text.size(), hoff.data(), sc.data(),
+                                 ps.data(), wo.data(), wl.data(), coff.data(), nullptr, 0, &need);
+        if (rc == 0) {
+            std::vector<char> cg((size_t)need);                    // exactly sized: an overrun is an ASan report
+            rc = bwt_hits_expand(n, 0, off.data(), 1, hits.data(), nh, extra.data(), extra.size(), text.data(), text.size(), hoff.data(), sc.data(),
+                                 ps.data(), wo.data(), wl.data(), coff.data(), cg.data(), need, &need);
+            if (rc) { fprintf(stderr, "bwt_hits_expand: second call failed\n"); return 1; }
+            ok_ex++;
+        } else bad_ex++;
+        if (!mutated && rc) { fprintf(stderr, "bwt_hits_expand refused a well-formed table: %s\n", g_err.c_str()); return 1; }
+    }
+    printf("fm: %d parsed, %d refused; fastq calls: %d ok, %d refused; packer: %d streams ok; table expansion: %d ok, %d refused\n", ok_fm, bad_fm, ok_fq, bad_fq,
+           ok_pk, ok_ex, bad_ex);
     return 0;
 }
