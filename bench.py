@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--genome-len", type=int, default=0, help="override the synthetic genome length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-batch", action="store_true", help="one resident batch instead of two alternating ones")
+    ap.add_argument("--depth", type=int, default=0, help="slots of the host pipeline (0 = the default)")
+    ap.add_argument("--ktable", default="", help="K,wide: suffix-interval table depth and whether its top level carries SA values (default: the "
+                                                 "library's choice for the index, K=15 wide at GRCh38 scale: 71.6 GB); e.g. 15,0 = 11.5 GB, 0,0 = none")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="resident steps only (profiling: rocprofv3's tracing serialises the pipe's streams and inflates the event times; "
                          "`value` is then the resident rate and says so)")
@@ -367,6 +370,9 @@ def main():
         log("rank %d: synthetic genome of %d bp in %.1f s%s" % (rank, glen, time.perf_counter() - t0, "" if composition is None else " " + json.dumps(composition)))
         t0 = time.perf_counter()
         ix = lib.Index.build(ref, shift=1, device=local_rank)
+        if args.ktable:
+            k_, w_ = (int(x) for x in args.ktable.split(","))
+            ix.set_ktable(k_, w_)
         log("rank %d: FM index built on the GPU in %.1f s (%s)" % (rank, time.perf_counter() - t0, ix.device_bytes()))
         t0 = time.perf_counter()
         bases, off = synth_reads(ref, n_reads, length, seed={"grch38": 5, "grch38-repeats": 7, "chr1": 4, "paired150": 6}[wl] * 1000 + rank,
@@ -435,8 +441,11 @@ def main():
     batches = []
     if stages == lib.STAGE_EXTEND and not args.no_pipeline:
         # ---- the timed region: K batches over the host boundary
-        hp = HostPipeline(ix, packed_sets, n_reads, length, depth=3, options=opts, on_result=exchange if gather else None)
-        hp.run(3)                                           # untimed set-up: every slot's device and pinned buffers at their final sizes
+        # (with the exchange step a fourth slot: the copy into the gather's send buffer is a small kernel that has to wait for CUs
+        # while another slot's persistent seed kernel runs, and the slot it belongs to cannot be released before it is done)
+        depth = args.depth or (4 if gather else 3)
+        hp = HostPipeline(ix, packed_sets, n_reads, length, depth=depth, options=opts, on_result=exchange if gather else None)
+        hp.run(depth)                                       # untimed set-up: every slot's device and pinned buffers at their final sizes
         hp.run(args.warmup)
         drain()
         hp.pipe.profile(True)                               # hipEvents around every kernel, on the slots' own streams
@@ -568,7 +577,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "value_is": ("host boundary (SURVEY 8d): packed reads in pinned host memory -> PCIe -> kernels -> compact hit tables in pinned "
-                         "host memory, %d batches through bwt_pipe (depth 3) incl. pipeline fill and drain" % args.steps) if hp is not None
+                         "host memory, %d batches through bwt_pipe (depth %d) incl. pipeline fill and drain" % (args.steps, hp.depth)) if hp is not None
                         else "resident steps only (--no-pipeline: a profiling run, not the metric)" if args.no_pipeline
                         else "search stage only, reads resident in HBM (BASELINE configs[1] times the kernel alone)",
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
