@@ -184,3 +184,51 @@ def test_pipe_packs_a_batch_that_is_mostly_exceptions(gpu_index, orc_fm, ref_byt
     finally:
         pipe.close()
     assert oracle_check(out, reads, orc_fm, ref1) > 100
+
+
+def test_reference_with_n_runs_and_iupac_codes():
+    """A reference whose .ref bytes hold N runs and IUPAC codes (fm_index.erl:130-137 keeps them in the .ref and substitutes bases
+    only in the indexed sequence): windows over them score with sigma's 1.6 / IUPAC clauses (src/sw.erl:164-202).  Reads
+    inside, across and next to those stretches, against the oracle."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(321)
+    n = 400_000
+    g = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)].copy()
+    spots = []
+    for st in range(1500, n - 1500, 1900):
+        k = int(rng.integers(1, 60))
+        g[st:st + k] = ord("N")                                          # an N run
+        j = st + 700 + int(rng.integers(0, 300))
+        g[j] = int(rng.choice(list(b"RYKMSWBDV")))                       # an IUPAC code (no H: fm_index.erl:136 has no clause for it)
+        spots += [st, j]
+    ref = g.tobytes()
+    ix = lib.Index.build(ref, shift=1)
+    try:
+        L, SA = ix.export()
+        ptr, shift = ix.meta()
+        ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+        ref1 = E.make_ref1(ref)
+        reads = []
+        for s_ in spots:                                                 # reads that start before, across and after every spot
+            for d in (-130, -99, -60, -20, -1, 0, 3, 31, 33, 64):
+                a = s_ + d
+                q = bytearray(ref[a:a + 100])
+                for i in range(len(q)):                                  # reads carry bases, not the reference's codes (one in four keeps an N)
+                    if q[i] not in b"ACGT" and (q[i] != ord("N") or rng.random() < 0.75):
+                        q[i] = int(rng.choice(list(b"ACGT")))
+                if rng.random() < 0.3:
+                    q[int(rng.integers(0, 100))] = int(rng.choice(list(b"ACGT")))
+                reads.append(bytes(q))
+        reads += synth_reads(ref.replace(b"N", b"A"), 500, 100, 5)
+        bases, off = lib.pack_reads(reads)
+        b = lib.Batch(ix)
+        codes, exc = lib.pack_2bit(bases)
+        b.set_reads_packed(codes, exc, len(reads), read_len=100)
+        c = b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        b.destroy()
+        assert oracle_check(out, reads, ofm, ref1) > 1000
+        assert c["n_float"] > 200                                        # windows with N / IUPAC went to the fp64 kernel
+    finally:
+        ix.close()
