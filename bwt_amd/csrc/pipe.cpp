@@ -48,7 +48,7 @@ enum SlotMode { M_ASCII = 0, M_PACKED, M_PACK_ASCII };
 struct Slot {
     bwt_batch *batch = nullptr;
     PinBuf bases, off, codes, exc;                 // inputs (pinned): ASCII form / packed form
-    std::vector<uint8_t> ascii;                    // pageable staging for bwt_pipe_submit_ascii
+    uint8_t *ascii = nullptr; size_t ascii_cap = 0; // pageable staging for bwt_pipe_submit_ascii (malloc: not zero-filled)
     PinBuf rstat, rec, extra, cig;                 // results (pinned): the compact hit table
     SlotState state = FREE;
     SlotMode mode = M_ASCII;
@@ -96,7 +96,7 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
             // the caller left ASCII in the staging buffer: pack it into the pinned buffers here, off the caller's thread
             for (int attempt = 0; attempt < 2; attempt++) {
                 uint64_t k = 0;
-                rc = bwt_pack_reads(s.ascii.data(), s.total, (uint32_t *)s.codes.p, (uint64_t *)s.exc.p, s.exc.cap / 8, &k, 0);
+                rc = bwt_pack_reads(s.ascii, s.total, (uint32_t *)s.codes.p, (uint64_t *)s.exc.p, s.exc.cap / 8, &k, 0);
                 s.n_exc = k;
                 if (rc != BWT_ENOSPC) break;
                 if ((rc = s.exc.ensure((size_t)k * 8 + 64))) break;
@@ -192,6 +192,7 @@ extern "C" void bwt_pipe_destroy(bwt_pipe *p) {
         if (s.batch) bwt_batch_destroy(s.batch);
         PinBuf *all[] = {&s.bases, &s.off, &s.codes, &s.exc, &s.rstat, &s.rec, &s.extra, &s.cig};
         for (auto b : all) b->release();
+        free(s.ascii);
     }
     delete p;
 }
@@ -289,10 +290,14 @@ extern "C" int bwt_pipe_acquire_packed(bwt_pipe *p, uint64_t bases_cap, uint32_t
         s.state = FREE;
         return rc;
     }
-    try { if (s.ascii.size() < bases_cap + 16) s.ascii.resize((size_t)bases_cap + 16); }
-    catch (...) { std::lock_guard<std::mutex> lk(p->mu); s.state = FREE; return fail(BWT_ENOMEM, "bwt_pipe_acquire_packed: no memory for the ASCII staging buffer"); }
+    if (s.ascii_cap < bases_cap + 16) {
+        free(s.ascii);
+        s.ascii_cap = (size_t)bases_cap + bases_cap / 4 + 4096;
+        s.ascii = (uint8_t *)malloc(s.ascii_cap);
+        if (!s.ascii) { s.ascii_cap = 0; std::lock_guard<std::mutex> lk(p->mu); s.state = FREE; return fail(BWT_ENOMEM, "bwt_pipe_acquire_packed: no memory for the ASCII staging buffer"); }
+    }
     s.mode = M_PACKED; s.bases_cap = bases_cap; s.reads_cap = reads_cap; s.exc_cap = s.exc.cap / 8;
-    in->codes = (uint32_t *)s.codes.p; in->exc = (uint64_t *)s.exc.p; in->off = (uint64_t *)s.off.p; in->ascii = s.ascii.data();
+    in->codes = (uint32_t *)s.codes.p; in->exc = (uint64_t *)s.exc.p; in->off = (uint64_t *)s.off.p; in->ascii = s.ascii;
     in->bases_cap = bases_cap; in->exc_cap = s.exc_cap; in->reads_cap = reads_cap;
     *slot = si;
     return 0;

@@ -232,3 +232,49 @@ def test_reference_with_n_runs_and_iupac_codes():
         assert c["n_float"] > 200                                        # windows with N / IUPAC went to the fp64 kernel
     finally:
         ix.close()
+
+
+def test_pipe_api_errors(gpu_index):
+    """The pipe's error behaviour: every misuse is a BWT_EINVAL / BWT_ENOSPC with a text, never a crash; a failed batch is reported
+    by wait and its slot can be released and used again."""
+    from bwt_amd import lib
+    pipe = lib.Pipe(gpu_index, depth=2)
+    try:
+        with pytest.raises(lib.BwtError) as e:                      # nothing submitted
+            pipe.wait()
+        assert e.value.code == -22
+        with pytest.raises(lib.BwtError):                           # no such slot
+            pipe.submit_packed(7, 1, 100, 100, 0)
+        with pytest.raises(lib.BwtError):                           # slot not acquired
+            pipe.submit_packed(0, 1, 100, 100, 0)
+        s, v = pipe.acquire_packed(400, 4, 4)
+        with pytest.raises(lib.BwtError):                           # more reads than acquired for
+            pipe.submit_packed(s, 5, 100, 500, 0)
+        with pytest.raises(lib.BwtError):                           # total_bases disagrees with n * read_len
+            pipe.submit_packed(s, 4, 100, 399, 0)
+        with pytest.raises(lib.BwtError):                           # an ASCII submit on a slot acquired for packed input is fine, the other way round is not
+            pipe.submit(s, 4)
+        s2, v2 = pipe.acquire_packed(400, 4, 4)
+        assert pipe.acquire_packed(16, 1, 0) is None                 # both slots taken: BWT_ENOSPC -> None
+        # a batch that fails on the device side of the boundary: an exception record that names one of ACGT
+        v["codes"][:] = 0
+        v["exc"][0] = 5 | (ord("C") << 56)
+        pipe.submit_packed(s, 4, 100, 400, 1)
+        with pytest.raises(lib.BwtError) as e:
+            pipe.wait()
+        assert e.value.code == -22 and "ACGT" in str(e.value)
+        pipe.release(s)
+        pipe.release(s2)                                              # (acquired, never submitted: may be given back)
+        with pytest.raises(lib.BwtError):
+            pipe.release(s2)                                          # ... once
+        # and the pipe still works
+        s, v = pipe.acquire_packed(400, 4, 4)
+        bases, off = lib.pack_reads([b"ACGTACGTAC" * 10] * 4)
+        codes, exc = lib.pack_2bit(bases)
+        v["codes"][:len(codes)] = codes
+        pipe.submit_packed(s, 4, 100, 400, 0)
+        r = pipe.wait()
+        assert r["n_reads"] == 4 and r["read_len"] == 100
+        pipe.release(r["slot"])
+    finally:
+        pipe.close()
