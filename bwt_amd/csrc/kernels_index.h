@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t rp_gather16(uint32_t f0, uint32_t f1, uint32
     const uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
     return lo | (hi << 8);
 }
-static __global__ __launch_bounds__(256) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
+static __global__ __launch_bounds__(256) __attribute__((unused)) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
                                                       uint32_t *__restrict__ planes) {
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t nseg = (((total + 15) >> 4) + 1) & ~1ull;      // 16-base segments, lane pairs finish whole words

@@ -59,7 +59,24 @@ struct Slot {
     bwt_batch_counts counts{};
     uint64_t n_hits = 0, n_extra = 0, cig_bytes = 0;
     double ms[4] = {0, 0, 0, 0};                   // upload, kernels, download, waiting for a turn
+    uint64_t seq = 0;                              // submission number: the order of the turns below
     std::thread th;
+};
+
+// A stage of the pipeline that one batch at a time passes through, IN SUBMISSION ORDER (a plain mutex lets a later batch overtake
+// an earlier one whose results the caller is waiting for).  Every submitted batch enters and leaves every stage exactly once,
+// failed or not.
+struct Turn {
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t now = 0;
+    void enter(uint64_t seq) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return now == seq; }); }
+    void leave() { { std::lock_guard<std::mutex> lk(m); now++; } cv.notify_all(); }
+};
+struct InTurn {                                    // scope of a batch's turn
+    Turn &t;
+    InTurn(Turn &turn, uint64_t seq) : t(turn) { t.enter(seq); }
+    ~InTurn() { t.leave(); }
 };
 }  // namespace
 
@@ -70,11 +87,12 @@ struct bwt_pipe {
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false;
-    // one upload, one batch's kernels and one download at a time: slots that copy side by side share the link and stay in lock
-    // step (all upload, all compute, all download -- no overlap between the phases); taking turns staggers them into a real
-    // pipeline.  The kernels of a batch fill the chip by themselves (persistent grids): two batches' kernels side by side gain
+    // one upload, one batch's kernels and one download at a time, in submission order: slots that copy side by side share the link
+    // and stay in lock step (all upload, all compute, all download -- no overlap between the phases); taking turns staggers them
+    // into a real pipeline.  The kernels of a batch fill the chip by themselves (persistent grids): two batches' kernels side by side gain
     // nothing, and taking turns keeps the per-kernel event times those of undisturbed launches.
-    std::mutex h2d_turn, gpu_turn, d2h_turn;
+    Turn h2d_turn, gpu_turn, d2h_turn;
+    uint64_t next_seq = 0;
     bool debug = false;                  // BWT_PIPE_DEBUG: a timeline line per event on stderr
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void trace(uint32_t slot, const char *what) const {
@@ -107,45 +125,51 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
         using clk = std::chrono::steady_clock;
         auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
         s.ms[0] = s.ms[1] = s.ms[2] = s.ms[3] = 0;
-        if (!rc) {
+        {
             const auto tw = clk::now();
-            std::lock_guard<std::mutex> turn(p->h2d_turn);
+            InTurn turn(p->h2d_turn, s.seq);
             s.ms[3] += ms_since(tw);
-            p->trace(si, "upload begins");
-            const auto t0 = clk::now();
-            struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[0], t0};
-            if (s.mode == M_ASCII) rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
-            else rc = bwt_batch_set_reads_packed(s.batch, (const uint32_t *)s.codes.p, s.total, s.n, s.read_len,
-                                                 s.read_len ? nullptr : (const uint64_t *)s.off.p, (const uint64_t *)s.exc.p, s.n_exc);
+            if (!rc) {
+                p->trace(si, "upload begins");
+                const auto t0 = clk::now();
+                struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[0], t0};
+                if (s.mode == M_ASCII) rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
+                else rc = bwt_batch_set_reads_packed(s.batch, (const uint32_t *)s.codes.p, s.total, s.n, s.read_len,
+                                                     s.read_len ? nullptr : (const uint64_t *)s.off.p, (const uint64_t *)s.exc.p, s.n_exc);
+            }
         }
-        if (!rc) {
+        {
             const auto tw = clk::now();
-            std::lock_guard<std::mutex> turn(p->gpu_turn);
+            InTurn turn(p->gpu_turn, s.seq);
             s.ms[3] += ms_since(tw);
-            p->trace(si, "kernels begin");
-            const auto t0 = clk::now();
-            rc = bwt_batch_run(s.batch, BWT_STAGE_EXTEND, &s.counts);
-            s.ms[1] = ms_since(t0);
-            p->trace(si, "kernels done");
+            if (!rc) {
+                p->trace(si, "kernels begin");
+                const auto t0 = clk::now();
+                rc = bwt_batch_run(s.batch, BWT_STAGE_EXTEND, &s.counts);
+                s.ms[1] = ms_since(t0);
+                p->trace(si, "kernels done");
+            }
         }
         uint64_t need[3] = {0, 0, 0};
         if (!rc) {
-            // sizes first (no table copied), then the compact table into the slot's pinned buffers
+            // sizes first (no table copied); the pinned result buffers grow outside the download's turn
             rc = bwt_batch_fetch_hits_compact(s.batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, need);
-            if (rc == BWT_ENOSPC || rc == 0) {
-                rc = 0;
-                if ((rc = s.rstat.ensure((size_t)s.n + 16)) || (rc = s.rec.ensure(((size_t)need[0] + 1) * 16)) ||
-                    (rc = s.extra.ensure(((size_t)need[1] + 1) * 16)) || (rc = s.cig.ensure((size_t)need[2] + 16))) {
-                } else {
-                    const auto tw = clk::now();
-                    std::lock_guard<std::mutex> turn(p->d2h_turn);
-                    s.ms[3] += ms_since(tw);
-                    p->trace(si, "download begins");
-                    const auto t0 = clk::now();
-                    struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[2], t0};
-                    rc = bwt_batch_fetch_hits_compact(s.batch, (int8_t *)s.rstat.p, (bwt_hit_rec *)s.rec.p, (bwt_hit_extra *)s.extra.p,
-                                                      (char *)s.cig.p, need[0], need[1], need[2], need);
-                }
+            if (rc == BWT_ENOSPC) rc = 0;
+            if (!rc && ((rc = s.rstat.ensure((size_t)s.n + 16)) || (rc = s.rec.ensure(((size_t)need[0] + 1) * 16)) ||
+                        (rc = s.extra.ensure(((size_t)need[1] + 1) * 16)) || (rc = s.cig.ensure((size_t)need[2] + 16)))) {
+            }
+        }
+        {
+            const auto tw = clk::now();
+            InTurn turn(p->d2h_turn, s.seq);
+            s.ms[3] += ms_since(tw);
+            if (!rc) {
+                // the compact table into the slot's pinned buffers
+                p->trace(si, "download begins");
+                const auto t0 = clk::now();
+                struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[2], t0};
+                rc = bwt_batch_fetch_hits_compact(s.batch, (int8_t *)s.rstat.p, (bwt_hit_rec *)s.rec.p, (bwt_hit_extra *)s.extra.p,
+                                                  (char *)s.cig.p, need[0], need[1], need[2], need);
             }
         }
         {
@@ -307,6 +331,7 @@ static int queue_slot(bwt_pipe *p, uint32_t slot) {
     p->trace(slot, "submitted");
     {
         std::lock_guard<std::mutex> lk(p->mu);
+        p->slots[slot].seq = p->next_seq++;
         p->slots[slot].state = QUEUED;
         p->order.push_back(slot);
     }
