@@ -391,6 +391,7 @@ struct bwt_batch {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
     std::map<std::string, KernelStat> stats;
+    hipEvent_t ev_uploaded = nullptr;    // bwt_batch_set_reads_packed_hook: the host buffers have crossed the link
 };
 
 static int prof_collect(bwt_batch *b) {
@@ -510,6 +511,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
     (void)hipStreamSynchronize(b->stream);
     prof_collect(b);
     for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
+    if (b->ev_uploaded) (void)hipEventDestroy(b->ev_uploaded);
     DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->pk_codes, &b->pk_exc, &b->pfq, &b->r_nx, &b->r_xcb, &b->x_off, &b->xcb_off, &b->x_rec, &b->x_cig, &b->h_xidx, &b->h_len, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
@@ -609,6 +611,13 @@ extern "C" int bwt_batch_set_reads(bwt_batch *b, const uint8_t *bases, const uin
 
 extern "C" int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, uint64_t total, uint32_t n, uint32_t read_len,
                                           const uint64_t *off, const uint64_t *exc, uint64_t n_exc) {
+    return bwt_batch_set_reads_packed_hook(b, codes, total, n, read_len, off, exc, n_exc, nullptr, nullptr);
+}
+
+// (common.h) `uploaded(arg)` is called once, as soon as the host buffers have crossed the link -- before the unpack kernels are
+// waited for -- or not at all when the call fails earlier: bwt_pipe passes its upload turn on there
+int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_t total, uint32_t n, uint32_t read_len,
+                                    const uint64_t *off, const uint64_t *exc, uint64_t n_exc, void (*uploaded)(void *), void *arg) {
     if (!b || (!codes && total) || (!exc && n_exc)) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: null argument");
     if (!read_len && !off) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: offsets are needed when the reads differ in length");
     if (read_len > 65535) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: read longer than 65535 bases");
@@ -616,6 +625,7 @@ extern "C" int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, u
     if (!read_len && (off[0] != 0 || off[n] != total)) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: off[0] must be 0 and off[n] the number of bases");
     if (total >> 56) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: too many bases");
     HIPCHK(hipSetDevice(b->device));
+    if (uploaded && !b->ev_uploaded) HIPCHK(hipEventCreateWithFlags(&b->ev_uploaded, hipEventDisableTiming));
     const uint64_t nwords = (total + 31) / 32;
     int rc;
     if ((rc = b->bases.ensure(nwords * 32 + 16)) || (rc = b->off.ensure(((size_t)n + 1) * 8)) || (rc = b->scan_tmp.ensure(64)) ||
@@ -631,10 +641,12 @@ extern "C" int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, u
     unsigned int *dchk = b->scan_tmp.as<unsigned int>();
     HIPCHK(hipMemcpyAsync(dchk, chk, sizeof chk, hipMemcpyHostToDevice, b->stream));
     if (read_len) {
+        if (uploaded) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
         if (n) hipLaunchKernelGGL(k_off_uniform, dim3(std::min<uint32_t>(cdiv((uint64_t)n + 1, 256), (uint32_t)cus * 8)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, read_len);
         else HIPCHK(hipMemsetAsync(b->off.p, 0, 8, b->stream));
     } else {
         HIPCHK(hipMemcpyAsync(b->off.p, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+        if (uploaded) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
         if (n) hipLaunchKernelGGL(k_off_check, dim3(std::min<uint32_t>(cdiv(n, 256), 1024)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, dchk);
     }
     {
@@ -653,6 +665,11 @@ extern "C" int bwt_batch_set_reads_packed(bwt_batch *b, const uint32_t *codes, u
         b->ascii_valid = all_ascii;
     }
     HIPCHK(hipMemcpyAsync(chk, dchk, sizeof chk, hipMemcpyDeviceToHost, b->stream));
+    if (uploaded) {
+        const hipError_t e = hipEventSynchronize(b->ev_uploaded);
+        uploaded(arg);
+        HIPCHK(e);
+    }
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipGetLastError());
     if (!read_len) {

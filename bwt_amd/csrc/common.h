@@ -66,3 +66,8 @@ struct bwt_index {
 
 // builds the Ref1 bit-planes of an index whose ref1 buffer is resident (used by both constructors)
 int bwt_index_make_refplanes(bwt_index *ix, hipStream_t stream);
+
+// bwt_batch_set_reads_packed with a hook: `uploaded(arg)` is called once, as soon as the host buffers have crossed the link
+// (before the unpack kernels are waited for), or not at all when the call fails before that point (bwt_gpu.hip; used by bwt_pipe)
+int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_t total, uint32_t n, uint32_t read_len,
+                                    const uint64_t *off, const uint64_t *exc, uint64_t n_exc, void (*uploaded)(void *), void *arg);

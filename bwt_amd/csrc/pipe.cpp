@@ -73,10 +73,12 @@ struct Turn {
     void enter(uint64_t seq) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return now == seq; }); }
     void leave() { { std::lock_guard<std::mutex> lk(m); now++; } cv.notify_all(); }
 };
-struct InTurn {                                    // scope of a batch's turn
+struct InTurn {                                    // scope of a batch's turn (or up to leave_now)
     Turn &t;
+    bool in = true;
     InTurn(Turn &turn, uint64_t seq) : t(turn) { t.enter(seq); }
-    ~InTurn() { t.leave(); }
+    void leave_now() { if (in) { in = false; t.leave(); } }
+    ~InTurn() { leave_now(); }
 };
 }  // namespace
 
@@ -132,10 +134,21 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
             if (!rc) {
                 p->trace(si, "upload begins");
                 const auto t0 = clk::now();
-                struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[0], t0};
-                if (s.mode == M_ASCII) rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
-                else rc = bwt_batch_set_reads_packed(s.batch, (const uint32_t *)s.codes.p, s.total, s.n, s.read_len,
-                                                     s.read_len ? nullptr : (const uint64_t *)s.off.p, (const uint64_t *)s.exc.p, s.n_exc);
+                if (s.mode == M_ASCII) {
+                    rc = bwt_batch_set_reads(s.batch, (const uint8_t *)s.bases.p, (const uint64_t *)s.off.p, s.n);
+                    s.ms[0] = ms_since(t0);
+                } else {
+                    // the link is the next batch's as soon as this one's buffers are across: the unpack kernels run beside its upload
+                    struct Hook { bwt_pipe *p; uint32_t si; InTurn *turn; double *ms; clk::time_point t0; } hk{p, si, &turn, &s.ms[0], t0};
+                    rc = bwt_batch_set_reads_packed_hook(s.batch, (const uint32_t *)s.codes.p, s.total, s.n, s.read_len,
+                                                         s.read_len ? nullptr : (const uint64_t *)s.off.p, (const uint64_t *)s.exc.p, s.n_exc,
+                                                         [](void *a) {
+                                                             Hook *h = (Hook *)a;
+                                                             *h->ms = std::chrono::duration<double, std::milli>(clk::now() - h->t0).count();
+                                                             h->p->trace(h->si, "upload across");
+                                                             h->turn->leave_now();
+                                                         }, &hk);
+                }
             }
         }
         {
