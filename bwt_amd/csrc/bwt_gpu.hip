@@ -1089,7 +1089,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     // the queue counters: zero since the stage that started this run zeroed the whole block; a retry (wider CIGAR slots) resets them
     if (!first) {
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 32, b->stream));
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 48, b->stream));      // band_*, pf_ov, band2_*, band3_*
     }
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
@@ -1172,12 +1172,14 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     const uint32_t band_min = std::min<uint32_t>(wv_thresh, b->opt.sw_band_min >= 0 ? (uint32_t)b->opt.sw_band_min : 16384u);   // queues up to this size are left to k_sw_wave
     if (io.dq && max_lq >= 2 && max_lq <= SWB_MAX_LQ && b->opt.sw_band != 0) {
         const uint32_t rows = max_lq + 1;
-        // resident grids: 4 (3 for the wide tier) waves per SIMD; the direction slab (rows x up to 1 KiB per wave) stays under 1 GiB
+        // resident grids: 4 (3 for the wide tiers) waves per SIMD; the direction slab (rows x 1 KiB per wave, 2 KiB in the third tier)
+        // stays under 1 GiB
         const uint64_t cap_blocks = (1ull << 30) / ((uint64_t)4 * rows * 4 * 64 * 4);
         const uint32_t blocks1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4), cap_blocks));
         const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 3), cap_blocks));
+        const uint32_t blocks3 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks2, cap_blocks / 2));
         if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->bq2.ensure(nc * 4 + 4)) ||
-            (rc = b->slab_band.ensure((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4)))
+            (rc = b->slab_band.ensure(std::max<uint64_t>((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4, (uint64_t)blocks3 * 4 * rows * 8 * 64 * 4))))
             return rc;
         Counters *dc = b->ctr.as<Counters>();
         {
@@ -1186,10 +1188,15 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
                                b->bq.as<uint32_t>(), &dc->band_in, b->slab_band.as<uint32_t>(), rows, band_min);
             hipLaunchKernelGGL(k_sw_band<32>, dim3(blocks2), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq.as<uint32_t>(),
                                (const unsigned int *)&dc->band_left, b->bq2.as<uint32_t>(), &dc->band2_in, b->slab_band.as<uint32_t>(), rows, band_min);
+            // (the first tier's output queue is free again: the third tier passes on into it; bwt_options.sw_band = 2 makes it
+            // pass everything on -- the two-tier path, for comparisons)
+            hipLaunchKernelGGL(k_sw_band<64>, dim3(blocks3), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq2.as<uint32_t>(),
+                               (const unsigned int *)&dc->band2_left, b->bq.as<uint32_t>(), &dc->band3_in, b->slab_band.as<uint32_t>(), rows,
+                               b->opt.sw_band == 2 ? 0xffffffffu : band_min);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&dc->dq_count, &dc->band2_left, 4, hipMemcpyDeviceToDevice, b->stream));
-        io.dq = b->bq2.as<uint32_t>();
+        HIPCHK(hipMemcpyAsync(&dc->dq_count, &dc->band3_left, 4, hipMemcpyDeviceToDevice, b->stream));
+        io.dq = b->bq.as<uint32_t>();
         b->band_ran = true;
     }
 
@@ -1412,7 +1419,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
         if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
         counts->n_dp = b->band_ran ? b->hctr.band_in : b->hctr.dq_count;
-        counts->n_banded = b->band_ran ? b->hctr.band_in - b->hctr.band2_left : 0;
+        counts->n_banded = b->band_ran ? b->hctr.band_in - b->hctr.band3_left : 0;
         counts->n_traced += counts->n_banded;
         counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
         counts->n_handed_back = b->hctr.n_gq;

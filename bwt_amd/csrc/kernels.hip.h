@@ -2938,20 +2938,22 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 #define SWB_MAX_LQ 1500            // 8 V + code of both candidates of a lane in 16 bits each
 // Two candidates per lane (low / high 16 bits of every register, the cell algebra of k_sw_pk): they share the row loop and
 // the cell index k, each has its own band offset x, window and last row.
-// The queue goes through two tiers: B = 20 first (a sixth fewer cells than 24; with D = 5 it covers a loss of 24 against the
+// The queue goes through three tiers: B = 20 first (a sixth fewer cells than 24; with D = 5 it covers a loss of 24 against the
 // perfect score, e.g. a 5-base insertion and two substitutions), then B = 32 for what that certificate did not cover (a loss
-// of up to 39-42), then the full rectangle.  in_q / in_count: this tier's queue; rest / ctl[1]: what it passes on; ctl[0]: the
-// number of candidates it was given; ctl[2]: its work counter.
+// of up to 39-42), then B = 64 (a loss of up to 96 on a square window: with Lq = 100 everything sw.erl:62 does not abort --
+// reads from diverged copies of a repeat family, 20-30 mismatches, are this tier's), then the full rectangle.  in_q / in_count:
+// this tier's queue; rest / ctl[1]: what it passes on; ctl[0]: the number of candidates it was given; ctl[2]: its work counter.
 #define SWB_WAVES(B) ((B) > 24 ? 3 : 4)
+#define SWB_RB(B) ((B) > 32 ? 4 : 8)      // rows of directions a traceback stages in LDS at a time (B / 8 words per row and lane)
 template <int B>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWB_WAVES(B), SWB_WAVES(B))))
 void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count, uint32_t *__restrict__ rest,
                unsigned int *__restrict__ ctl, uint32_t *__restrict__ slab, uint32_t slab_rows, uint32_t skip_upto) {
-    static_assert(B > 16 && B <= 32, "cells 16.. come from the second match word");
-    constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8;
+    static_assert(B > 16 && B <= 64, "one or two match words per row");
+    constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8, NW = (B + 31) / 32;     // NW: 32-cell match words of a row
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    constexpr int RB = 8;                                                           // rows of directions a traceback stages in LDS at a time
+    constexpr int RB = SWB_RB(B);                                                   // rows of directions a traceback stages in LDS at a time
     __shared__ uint32_t tb_lds[4][RB * NDW * 64];
     uint32_t *const tb = tb_lds[threadIdx.x >> 6] + lane;                           // [(r * NDW + k / 8) * 64]: every lane its own column
     const uint32_t n_items = *in_count;
@@ -2994,17 +2996,23 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
             uint32_t H[B];
 #pragma unroll
             for (int k = 0; k < B; k++) H[k] = 0x00010001u;                            // row 0: V = 0, stored as `left` (Uvalue -2 like undef)
-            uint32_t qlw[2] = {0, 0}, qhw[2] = {0, 0}, rl0[2] = {0, 0}, rh0[2] = {0, 0}, rl1[2], rh1[2];
+            // window plane words: rlw[h][t] = the 32 bases from P0 + 32 (b / 32 + t - 1) of the low plane, rhw of the high one; a row
+            // needs NW + 1 of them (cells k = 0 .. B - 1 sit on bases P0 + b + k); word 0 is filled by the first row's shift
+            uint32_t qlw[2] = {0, 0}, qhw[2] = {0, 0}, rlw[2][NW + 1], rhw[2][NW + 1];
             uint64_t P0[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 P0[h] = (uint64_t)wo[h] - (uint32_t)x[h];                                // Ref1 base of cell (1, k = 0)'s column
-                const uint4 v = planes4(io.wplanes, P0[h]);
-                rl1[h] = v.x; rh1[h] = v.y;
+                rlw[h][0] = 0; rhw[h][0] = 0;
+#pragma unroll
+                for (int t = 1; t <= NW; t++) {
+                    const uint4 v = planes4(io.wplanes, P0[h] + 32 * (t - 1));
+                    rlw[h][t] = v.x; rhw[h][t] = v.y;
+                }
             }
             auto row = [&](uint32_t i, auto first) {
                 const uint32_t b = i - 1, sh = b & 31u;
-                uint32_t e[2];
+                uint32_t e[2][NW];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     if (sh == 0) {
@@ -3013,15 +3021,25 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
                         const uint32_t bb = b < lq[h] ? b : 0u;
                         const uint4 qv = planes4(io.qplanes, qo[h] + bb);
                         qlw[h] = qv.x; qhw[h] = qv.y;
-                        rl0[h] = rl1[h]; rh0[h] = rh1[h];
-                        const uint4 v = planes4(io.wplanes, P0[h] + bb + 32);
-                        rl1[h] = v.x; rh1[h] = v.y;
+#pragma unroll
+                        for (int t = 0; t < NW; t++) { rlw[h][t] = rlw[h][t + 1]; rhw[h][t] = rhw[h][t + 1]; }
+                        const uint4 v = planes4(io.wplanes, P0[h] + bb + 32 * NW);
+                        rlw[h][NW] = v.x; rhw[h][NW] = v.y;
                     }
                     const uint32_t QL = 0u - ((qlw[h] >> sh) & 1u), QH = 0u - ((qhw[h] >> sh) & 1u);
-                    const uint32_t rl = __builtin_amdgcn_alignbit(rl1[h], rl0[h], sh), rh = __builtin_amdgcn_alignbit(rh1[h], rh0[h], sh);
-                    e[h] = ~((rl ^ QL) | (rh ^ QH));                                     // bit k: the row's base equals the base of cell k's column
+#pragma unroll
+                    for (int t = 0; t < NW; t++) {
+                        const uint32_t rl = __builtin_amdgcn_alignbit(rlw[h][t + 1], rlw[h][t], sh), rh = __builtin_amdgcn_alignbit(rhw[h][t + 1], rhw[h][t], sh);
+                        e[h][t] = ~((rl ^ QL) | (rh ^ QH));                              // bit k: the row's base equals the base of cell 32 t + k's column
+                    }
                 }
-                const uint32_t E0 = (e[0] & 0xffffu) | (e[1] << 16), E1 = (e[0] >> 16) | (e[1] & 0xffff0000u);
+                // 16 cells of both candidates per word: cell k's bit of candidate 0 at bit k % 16, of candidate 1 at 16 + k % 16
+                uint32_t E[2 * NW];
+#pragma unroll
+                for (int t = 0; t < NW; t++) {
+                    E[2 * t] = (e[0][t] & 0xffffu) | (e[1][t] << 16);
+                    E[2 * t + 1] = (e[0][t] >> 16) | (e[1][t] & 0xffff0000u);
+                }
                 const int kc0 = x[0] - (int)i, kc1 = x[1] - (int)i;                      // column 0 sits at k = kc in this row (rows <= x)
                 const uint32_t col0 = (uint32_t)(-(int)(i + 1) * 8 + 2) & 0xffffu;       // V(i, 0) = -(i + 1), up (sw.erl:73-77)
                 uint32_t left = 0x80008000u;
@@ -3029,7 +3047,7 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
 #pragma unroll
                 for (int k = 0; k < B; k++) {
                     const uint32_t old = H[k];
-                    const uint32_t xk = ((k < 16 ? E0 >> k : E1 >> (k - 16))) & 0x00010001u;
+                    const uint32_t xk = (E[k >> 4] >> (k & 15)) & 0x00010001u;
                     const uint32_t cd = pk_add(old & F8, pk_mad(xk, K24, KM4));          // 8 sigma + 4
                     uint32_t hh = pk_max(cd, left);
                     if (k + 1 < B) {

@@ -65,7 +65,7 @@ typedef struct {
     int32_t sw_prefilter;       /* 0: every candidate goes to the DP kernels */
     int32_t sw_fuse_cand;       /* 0: separate k_candidates pass in front of the prefilter */
     int32_t sw_wave;            /* 0: no wave-per-alignment kernel for short DP queues */
-    int32_t sw_band;            /* 0: no banded DP tier (full rectangles only) */
+    int32_t sw_band;            /* 0: no banded DP tiers (full rectangles only); 2: the 20- and 32-diagonal tiers only; else all three */
     int32_t sw_band_min;        /* DP queues up to this many candidates skip the banded tier (default 16384) */
     int32_t sw_lds;             /* 0: boundary rows in HBM slabs instead of LDS */
     int32_t sw_pk;              /* 0: no packed-i16 DP kernels */

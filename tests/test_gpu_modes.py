@@ -35,7 +35,7 @@ def check_against_oracle(out, reads, orc_fm, ref1):
 
 
 # every execution option of bwt_options (include/bwt_gpu.h) that selects between equivalent kernels, and the table's summary bitmap
-MODES = [{"seed_big": 1}, {"ktab_summary": 2}, {"ktab_summary": 0}, {"sw_band": 0}, {"sw_band_min": 0}, {"sw_band_min": 0, "sw_wave": 0},
+MODES = [{"seed_big": 1}, {"ktab_summary": 2}, {"ktab_summary": 0}, {"sw_band": 0}, {"sw_band": 2, "sw_band_min": 0}, {"sw_band_min": 0}, {"sw_band_min": 0, "sw_wave": 0},
          {"seed_fuse": 0}, {"sw_prefilter": 0}, {"sw_pk": 0}, {"sw_lds": 0}, {"sw_trace_all": 0, "sw_wave": 0},
          {"sw_wave": 0, "sw_prefilter": 0}, {"search_ilp": 2}, {"seed_fast": 0}, {"sw_fuse_cand": 0}]
 
@@ -285,7 +285,7 @@ def test_fast_seed_kernel_read_lengths(repeat_index, length):
 
 @pytest.mark.parametrize("length", [48, 64, 100, 150, 175, 400])
 def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_bytes, length):
-    """k_sw_band runs the DP on 20 (then 32) diagonals around the cluster and keeps its result only when the best score proves that
+    """k_sw_band runs the DP on 20 (then 32, then 64) diagonals around the cluster and keeps its result only when the best score proves that
     nothing outside the band can matter (kernels.hip.h); everything else goes on to the full-rectangle kernels.
     Reads with one indel and up to 4 substitutions (most are settled by the band), reads with up to 14 substitutions (few are):
     every answer must be the oracle's, and both routes must have been taken."""
@@ -294,6 +294,21 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
     ref1 = E.make_ref1(ref_bytes)
     reads = (synth_reads(ref_bytes, 500, length, 900 + length, max_subs=4, indel_frac=1.0) +
              synth_reads(ref_bytes, 300, length, 901 + length, max_subs=14, indel_frac=0.5))
+    # the third tier's: a clean stretch that brings the seeds and the cluster, the rest of the read at 20-45 % substitutions (what a
+    # read from a diverged copy of a repeat family looks like against another copy: a loss of 40..100 on a square window)
+    rng = np.random.default_rng(77 + length)
+    n_heavy = 0
+    if length >= 100:
+        for _ in range(400):
+            a = int(rng.integers(0, len(ref_bytes) - length))
+            q = bytearray(ref_bytes[a:a + length])
+            c0 = int(rng.integers(0, length - 40))
+            rate = float(rng.uniform(0.2, 0.45))
+            for i in range(length):
+                if not (c0 <= i < c0 + 40) and rng.random() < rate:
+                    q[i] = int(rng.choice([x for x in b"ACGT" if x != q[i]]))
+            reads.append(bytes(q))
+            n_heavy += 1
     b = lib.Batch(gpu_index)
     b.set_options(sw_band_min=0)                                # (queues this short are k_sw_wave's otherwise)
     try:
@@ -302,6 +317,16 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
         out = b.fetch_hits()
         assert check_against_oracle(out, reads, orc_fm, ref1) > 200
         assert c["n_banded"] > 100 and c["n_dp"] > c["n_banded"], c
+        # the first two tiers alone: the same tables, and (long reads) fewer candidates settled -- the 64-diagonal tier took the rest
+        b.set_options(sw_band_min=0, sw_band=2)
+        c2 = b.run(lib.STAGE_EXTEND)
+        out2 = b.fetch_hits()
+        assert c2["n_dp"] == c["n_dp"] and c2["n_banded"] <= c["n_banded"]
+        if n_heavy:
+            assert c["n_banded"] - c2["n_banded"] > 50, (c, c2)
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(out[k], out2[k]), k
+        assert out["cigar"] == out2["cigar"]
         # the same batch without the band: the same tables
         b.set_options(sw_band_min=0, sw_band=0)
         c0 = b.run(lib.STAGE_EXTEND)
