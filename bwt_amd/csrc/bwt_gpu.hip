@@ -368,7 +368,7 @@ struct bwt_batch {
     uint32_t cig_stride = 32;
     // sw slabs
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
-    DevBuf bq, bq2, slab_band;         // k_sw_band: the queues of what its two tiers pass on, the direction slab
+    DevBuf bq, bq2, bq3, slab_band;    // k_sw_band: the queues of what its tiers pass on (bq3: first tier -> third), the direction slab
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     DevBuf pfq;                        // candidates the fused prefilter pass listed for the quad-per-candidate pass
@@ -516,7 +516,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->bq2, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -1178,20 +1178,26 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         const uint32_t blocks1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4), cap_blocks));
         const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 3), cap_blocks));
         const uint32_t blocks3 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks2, cap_blocks / 2));
-        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->bq2.ensure(nc * 4 + 4)) ||
+        if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->bq2.ensure(nc * 4 + 4)) || (rc = b->bq3.ensure(nc * 4 + 4)) ||
             (rc = b->slab_band.ensure(std::max<uint64_t>((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4, (uint64_t)blocks3 * 4 * rows * 8 * 64 * 4))))
             return rc;
         Counters *dc = b->ctr.as<Counters>();
         {
             ProfScope ps(b, "sw_band");
-            hipLaunchKernelGGL(k_sw_band<20>, dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
-                               b->bq.as<uint32_t>(), &dc->band_in, b->slab_band.as<uint32_t>(), rows, band_min);
-            hipLaunchKernelGGL(k_sw_band<32>, dim3(blocks2), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq.as<uint32_t>(),
-                               (const unsigned int *)&dc->band_left, b->bq2.as<uint32_t>(), &dc->band2_in, b->slab_band.as<uint32_t>(), rows, band_min);
+            const uint32_t *nullq = nullptr;
+            const unsigned int *nullc = nullptr;
+            // first tier: what the second cannot settle either goes straight to the third's second queue (bq3 / band_direct)
+            hipLaunchKernelGGL((k_sw_band<20, 32>), dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
+                               nullq, nullc, b->bq.as<uint32_t>(), &dc->band_in, b->bq3.as<uint32_t>(), &dc->band_direct,
+                               b->slab_band.as<uint32_t>(), rows, band_min);
+            hipLaunchKernelGGL((k_sw_band<32, 0>), dim3(blocks2), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq.as<uint32_t>(),
+                               (const unsigned int *)&dc->band_left, nullq, nullc, b->bq2.as<uint32_t>(), &dc->band2_in, (uint32_t *)nullptr,
+                               (unsigned int *)nullptr, b->slab_band.as<uint32_t>(), rows, band_min);
             // (the first tier's output queue is free again: the third tier passes on into it; bwt_options.sw_band = 2 makes it
             // pass everything on -- the two-tier path, for comparisons)
-            hipLaunchKernelGGL(k_sw_band<64>, dim3(blocks3), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq2.as<uint32_t>(),
-                               (const unsigned int *)&dc->band2_left, b->bq.as<uint32_t>(), &dc->band3_in, b->slab_band.as<uint32_t>(), rows,
+            hipLaunchKernelGGL((k_sw_band<64, 0>), dim3(blocks3), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq2.as<uint32_t>(),
+                               (const unsigned int *)&dc->band2_left, (const uint32_t *)b->bq3.as<uint32_t>(), (const unsigned int *)&dc->band_direct,
+                               b->bq.as<uint32_t>(), &dc->band3_in, (uint32_t *)nullptr, (unsigned int *)nullptr, b->slab_band.as<uint32_t>(), rows,
                                b->opt.sw_band == 2 ? 0xffffffffu : band_min);
         }
         HIPCHK(hipGetLastError());

@@ -2942,13 +2942,27 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 // perfect score, e.g. a 5-base insertion and two substitutions), then B = 32 for what that certificate did not cover (a loss
 // of up to 39-42), then B = 64 (a loss of up to 96 on a square window: with Lq = 100 everything sw.erl:62 does not abort --
 // reads from diverged copies of a repeat family, 20-30 mismatches, are this tier's), then the full rectangle.  in_q / in_count:
-// this tier's queue; rest / ctl[1]: what it passes on; ctl[0]: the number of candidates it was given; ctl[2]: its work counter.
+// this tier's queue (in_q2 / in_count2: a second one behind it, or null); rest / ctl[1]: what it passes on; ctl[0]: the number of
+// candidates it was given; ctl[2]: its work counter.  NEXT > 0: the next tier has NEXT diagonals, and a candidate that cannot be
+// settled there -- not eligible, or run here with a best score below the next tier's own threshold: a wider band only adds paths, so
+// its best score is at least this one, but for the substitution-rich candidates that fail here it is the same diagonal again --
+// goes to skip_q / skip_ctr instead (the queue of the tier after the next), and the next tier does not compute it in vain.
 #define SWB_WAVES(B) ((B) > 24 ? 3 : 4)
 #define SWB_RB(B) ((B) > 32 ? 4 : 8)      // rows of directions a traceback stages in LDS at a time (B / 8 words per row and lane)
-template <int B>
+// is a candidate one a tier of BB diagonals runs?  (x: its band offset there)
+template <int BB>
+__device__ __forceinline__ bool swb_eligible(const SwIO &io, uint32_t lq, uint32_t w, int64_t wo, uint32_t slab_rows, int &x) {
+    const int D = (int)w - (int)lq;
+    x = (BB - 1 - D) >> 1;
+    return D >= 0 && D <= BB - 1 - 2 * SWB_XMIN && lq >= 2 && lq < slab_rows && lq <= SWB_MAX_LQ && 3 * x + 3 <= 2 * (int)(lq / 2) && wo >= 32 &&
+           (uint64_t)wo + w <= io.rbuf_len;
+}
+template <int B, int NEXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWB_WAVES(B), SWB_WAVES(B))))
-void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count, uint32_t *__restrict__ rest,
-               unsigned int *__restrict__ ctl, uint32_t *__restrict__ slab, uint32_t slab_rows, uint32_t skip_upto) {
+void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count, const uint32_t *__restrict__ in_q2,
+               const unsigned int *__restrict__ in_count2, uint32_t *__restrict__ rest, unsigned int *__restrict__ ctl,
+               uint32_t *__restrict__ skip_q, unsigned int *__restrict__ skip_ctr, uint32_t *__restrict__ slab, uint32_t slab_rows,
+               uint32_t skip_upto) {
     static_assert(B > 16 && B <= 64, "one or two match words per row");
     constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8, NW = (B + 31) / 32;     // NW: 32-cell match words of a row
     const uint32_t lane = threadIdx.x & 63;
@@ -2956,10 +2970,11 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
     constexpr int RB = SWB_RB(B);                                                   // rows of directions a traceback stages in LDS at a time
     __shared__ uint32_t tb_lds[4][RB * NDW * 64];
     uint32_t *const tb = tb_lds[threadIdx.x >> 6] + lane;                           // [(r * NDW + k / 8) * 64]: every lane its own column
-    const uint32_t n_items = *in_count;
+    const uint32_t n1 = *in_count, n_items = n1 + (in_q2 ? *in_count2 : 0u);
+    auto item_at = [&](uint32_t t) { return t < n1 ? in_q[t] : in_q2[t - n1]; };
     if (n_items <= skip_upto) {
         // a short queue is k_sw_wave's (a lane per alignment would run a handful of waves for the serial length of a DP): passed through
-        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = in_q[t];
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = item_at(t);
         if (wave == 0 && lane == 0) { ctl[0] = n_items; ctl[1] = n_items; }
         return;
     }
@@ -2978,20 +2993,25 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
         int64_t wo[2];
         uint64_t qo[2];
         int x[2], D[2];
-        bool have[2], run[2], settled[2] = {false, false};
+        bool have[2], run[2], settled[2] = {false, false}, ran[2], next_ok[2] = {true, true};
+        int next_thr[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t item = g * 128 + h * 64 + lane;
             have[h] = item < n_items;
             c[h] = 0; lq[h] = 0; w[h] = 0; wo[h] = 0; qo[h] = 0;
-            if (have[h]) { c[h] = in_q[item]; lq[h] = io.c_qlen[c[h]]; w[h] = io.c_wlen[c[h]]; wo[h] = io.c_woff[c[h]]; qo[h] = io.c_qoff[c[h]]; }
+            if (have[h]) { c[h] = item_at(item); lq[h] = io.c_qlen[c[h]]; w[h] = io.c_wlen[c[h]]; wo[h] = io.c_woff[c[h]]; qo[h] = io.c_qoff[c[h]]; }
             D[h] = (int)w[h] - (int)lq[h];
-            x[h] = (B - 1 - D[h]) >> 1;
-            run[h] = have[h] && D[h] >= 0 && D[h] <= B - 1 - 2 * SWB_XMIN && lq[h] >= 2 && lq[h] < slab_rows && lq[h] <= SWB_MAX_LQ &&
-                     3 * x[h] + 3 <= 2 * (int)(lq[h] / 2) && wo[h] >= 32 && (uint64_t)wo[h] + w[h] <= io.rbuf_len;
+            run[h] = have[h] && swb_eligible<B>(io, lq[h], w[h], wo[h], slab_rows, x[h]);
+            if (NEXT > 0 && have[h]) {                                                   // (before the idle half's values are replaced below)
+                int xn;
+                next_ok[h] = swb_eligible<(NEXT > 0 ? NEXT : B)>(io, lq[h], w[h], wo[h], slab_rows, xn);
+                next_thr[h] = 2 * (int)lq[h] - 3 * xn - 3;
+            }
             if (!run[h]) { lq[h] = 0; wo[h] = 64; qo[h] = 0; x[h] = XMAX; D[h] = 0; }     // (its half computes on, harmlessly, on words that exist)
         }
         int best[2] = {-(1 << 28), -(1 << 28)}, kb[2] = {0, 0};
+        ran[0] = run[0]; ran[1] = run[1];
         if (run[0] || run[1]) {
             uint32_t H[B];
 #pragma unroll
@@ -3154,17 +3174,22 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
                     settled[h] = true;
                 }
         }
-        // what is left goes on
+        // what is left goes on: to the next tier, or past it when it cannot settle the candidate either
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const bool pass = have[h] && !settled[h];
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                const int first = __ffsll((long long)m) - 1;
-                uint32_t base = 0;
-                if ((int)lane == first) base = atomicAdd(&ctl[1], (uint32_t)__popcll(m));
-                base = (uint32_t)__shfl((int)base, first, 64);
-                if (pass) rest[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c[h];
+            const bool left = have[h] && !settled[h];
+            const bool past = NEXT > 0 && left && (!next_ok[h] || (ran[h] && best[h] < next_thr[h]));
+#pragma unroll
+            for (int way = 0; way < (NEXT > 0 ? 2 : 1); way++) {
+                const bool pass = way ? past : left && !past;
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const int first = __ffsll((long long)m) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == first) base = atomicAdd(way ? skip_ctr : &ctl[1], (uint32_t)__popcll(m));
+                    base = (uint32_t)__shfl((int)base, first, 64);
+                    if (pass) (way ? skip_q : rest)[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c[h];
+                }
             }
         }
     }

@@ -153,7 +153,7 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned int max_D, n_pend;  // (n_pend: wave passes of the seed kernels that left a task to k_search_pending; 0 = it has nothing to do) // largest cluster width D the seed kernels staged (window = Lq + D: sizes the extend stage without a round trip)
     unsigned int why[6];       // ... by reason: [0] base outside ACGT, [1] table overflow, [4] > 64 seeds in a read, [5] > CL_STAGE clusters
     unsigned int band_in, band_left, band_next, pf_ov;   // (pf_ov: candidates the fused prefilter pass listed for the quad-per-candidate pass)   // k_sw_band, first tier: DP candidates it was given, those it passed on, its work counter
-    unsigned int band2_in, band2_left, band2_next, pad4_;   // ... second tier (wider band)
+    unsigned int band2_in, band2_left, band2_next, band_direct;   // ... second tier (wider band); band_direct: candidates the first tier sent straight to the third
     unsigned int band3_in, band3_left, band3_next, pad5_;   // ... third tier (64 diagonals); what it passes on goes to the full-rectangle kernels
     unsigned long long cig_total;                            // bytes of all CIGAR texts of the batch's hits (k_hits_count)
 };
