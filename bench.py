@@ -611,7 +611,7 @@ def main():
                               "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"],
                               "dp_candidates": counts["n_dp"],
                               "settled_by_banded_dp": counts.get("n_banded", 0),
-                              "dp_kernel": ("k_sw_band (20, then 32 diagonals + certificate), then " if banded else "") +
+                              "dp_kernel": ("k_sw_band (20, then 32, then 64 diagonals + certificate), then " if banded else "") +
                                            ("k_sw_wave (wave per alignment: short queue)" if left <= 32768 else "k_sw_pk"),
                               # cells of the reference's full rectangles for these candidates, per second of DP kernels (the banded
                               # kernel fills 24 diagonals of them)

@@ -31,4 +31,9 @@ out = {"genome_len": glen, "reads": n, "hits": int(len(score)), "counts": {k: in
 for name, sel in (("D=0", D == 0), ("D 1..13", (D > 0) & (D <= 13)), ("D 14..25", (D > 13) & (D <= 25)), ("D 26..57", (D > 25) & (D <= 57)), ("D>57", D > 57)):
     h, _ = np.histogram(loss[sel], bins=edges)
     out[name] = {"hits": int(sel.sum()), "loss_bins": {"%d..%d" % (edges[i], edges[i + 1] - 1): int(h[i]) for i in range(len(h))}}
+wide = D[D > 154]          # W > 254: past the packed kernels' cap, the lane-per-alignment trace kernel's
+out["W>254"] = {"hits": int(len(wide)), "D_percentiles": {str(q): int(np.percentile(wide, q)) for q in (50, 90, 99, 100)} if len(wide) else {},
+                "cells": int(((wide.astype(np.int64) + L) * L).sum())}
+mid = D[(D > 57) & (D <= 154)]
+out["57<D<=154"] = {"hits": int(len(mid)), "cells": int(((mid.astype(np.int64) + L) * L).sum())}
 print(json.dumps(out, indent=1))
