@@ -563,7 +563,8 @@ def main():
                                   "share_of_step": kt["sw_extend"]["ms"] / total_ms}
         if "sw_band" in per and counts.get("n_banded", 0) > 0:
             # banded DP: 20 cells per row in the first tier (nearly everything it settles is settled there), 17.6 instructions per
-            # cell PAIR (two candidates per lane) = 8.8 lane-ops per cell
+            # cell PAIR (two candidates per lane) = 8.8 lane-ops per cell.  A lower bound: what the 32- and 64-diagonal tiers compute
+            # (and what the first tier computes for candidates it passes on) is not counted as work, only its time.
             bcells = counts["n_banded"] * length * 20.0
             ops = bcells * 8.8 / (per["sw_band"] / 1e3) / 1e12
             roofs["sw_band"] = {"kernel": "k_sw_band", "bound": "valu", "achieved": ops, "peak": VALU_PEAK_TOPS, "unit": "Tlane-op/s",
