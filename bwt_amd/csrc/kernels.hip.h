@@ -3314,6 +3314,7 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
 // that are not "plain" -- plain = settled on a square window with CIGAR "<Lq>M" (CIG_DIAG), for which window and text follow
 // from the record.  The per-hit arrays of bwt_align_batch (window offset / length, CIGAR offsets, all texts) are expanded from
 // it on demand (k_hits_expand) -- a batch whose results leave as compact tables never writes them.
+#define HITS_FAT 128u          // candidates of a read from which on the wave takes the read together (k_hits_count, k_hits_write)
 __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *__restrict__ clus_off,
                                                      const int32_t *__restrict__ c_status,
                                                      const uint32_t *__restrict__ c_ciglen,
@@ -3321,16 +3322,22 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
                                                      uint32_t *__restrict__ r_nhit, uint32_t *__restrict__ r_nx,
                                                      uint32_t *__restrict__ r_xcb, int8_t *__restrict__ r_status, Counters *ctr) {
     // grid-stride over a capped grid: one atomic per wave for the whole launch (same-address atomics are rated at ~88 per us:
-    // one per wave of a 12.5 M-read batch would be 2 ms of them)
+    // one per wave of a 12.5 M-read batch would be 2 ms of them).  Lane per read -- but a read with more than HITS_FAT candidates
+    // (low-complexity reads have tens of thousands) is taken by the whole wave, 64 candidates at a time: as one lane's loop it was
+    // the kernel's duration (0.98 ms on the repeat-rich batch for 0.3 ms of work).
+    const uint32_t lane = threadIdx.x & 63u;
     unsigned long long cb = 0;                        // bytes of all CIGAR texts (plain ones included): bwt_batch_counts.cigar_bytes
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += gridDim.x * blockDim.x) {   // whole waves iterate together
+        const uint32_t r = base + lane;
+        const bool valid = r < n;
         uint32_t nh = 0, nx = 0, xcb = 0;
         unsigned long long cbr = 0;
         int32_t st = 1;                                   // sga returned []
-        if (r_qty[r] >> 31) st = -1;
-        const uint64_t a = clus_off[r], b = clus_off[r + 1];
+        if (valid && (r_qty[r] >> 31)) st = -1;
+        const uint64_t a = valid ? clus_off[r] : 0ull, b = valid ? clus_off[r + 1] : 0ull;
         if (b > a) st = 0;
-        for (uint64_t k = a; k < b; k++) {
+        const bool fat = b - a > HITS_FAT;
+        auto one = [&](uint64_t k) {
             const int32_t cs = c_status[k];
             if (cs == CS_OK) {
                 const uint32_t clf = c_ciglen[k];
@@ -3338,13 +3345,31 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
                 if (!(clf & CIG_DIAG)) { nx++; xcb += clf; }
             } else if (cs == CS_WINDOW_OOR) st = -2;
             else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
+        };
+        if (!fat) for (uint64_t k = a; k < b; k++) one(k);
+        for (unsigned long long fm = __ballot(fat); fm; fm &= fm - 1ull) {
+            const int src = __ffsll((long long)fm) - 1;
+            const uint64_t fa = (uint64_t)__shfl((long long)a, src, 64), fb = (uint64_t)__shfl((long long)b, src, 64);
+            // every lane totals its share of the read's candidates; the read's own lane takes the sums
+            uint32_t nh1 = 0, nx1 = 0, xcb1 = 0, oor1 = 0;
+            unsigned long long cb1 = 0;
+            {
+                const uint32_t nh0 = nh, nx0 = nx, xcb0 = xcb; const unsigned long long cbr0 = cbr; const int32_t st0 = st;
+                nh = 0; nx = 0; xcb = 0; cbr = 0; st = 0;
+                for (uint64_t k = fa + lane; k < fb; k += 64) one(k);
+                nh1 = nh; nx1 = nx; xcb1 = xcb; cb1 = cbr; oor1 = st == -2 ? 1u : 0u;
+                nh = nh0; nx = nx0; xcb = xcb0; cbr = cbr0; st = st0;
+            }
+            const unsigned long long tnh = wave_sum_u64(nh1), tnx = wave_sum_u64(nx1), txcb = wave_sum_u64(xcb1), tcb = wave_sum_u64(cb1);
+            const bool oor = __ballot(oor1 != 0) != 0;
+            if ((int)lane == src) { nh = (uint32_t)tnh; nx = (uint32_t)tnx; xcb = (uint32_t)txcb; cbr = tcb; if (oor) st = -2; }
         }
         if (st == -2) { nh = 0; nx = 0; xcb = 0; cbr = 0; }
         cb += cbr;
-        r_nhit[r] = nh; r_nx[r] = nx; r_xcb[r] = xcb; r_status[r] = (int8_t)st;
+        if (valid) { r_nhit[r] = nh; r_nx[r] = nx; r_xcb[r] = xcb; r_status[r] = (int8_t)st; }
     }
     cb = wave_sum_u64(cb);
-    if ((threadIdx.x & 63) == 0 && cb) atomicAdd(&ctr->cig_total, cb);
+    if (lane == 0 && cb) atomicAdd(&ctr->cig_total, cb);
 }
 
 struct HitRec { uint32_t read; int32_t score; int64_t pos; };   // the 16-byte record gathered over RCCL
@@ -3361,22 +3386,20 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
                                                      const uint8_t *__restrict__ cig, uint32_t cig_stride,
                                                      HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec,
                                                      uint8_t *__restrict__ x_cig) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (r_status[r] != 0) return;
-    const uint64_t a = clus_off[r], b = clus_off[r + 1];
-    uint64_t ho = hit_off[r];
-    if (ho == hit_off[r + 1]) return;
-    uint64_t xo = x_off[r], co = xcb_off[r];
-    for (uint64_t k = b; k-- > a;) {                  // reverse of the cluster order
-        if (c_status[k] != CS_OK) continue;
-        const uint32_t wl = c_wlen[k], clf = c_ciglen[k];
-        HitRec hr; hr.read = r; hr.score = c_score[k];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool live0 = r < n && r_status[r] == 0;
+    const uint64_t a = live0 ? clus_off[r] : 0ull, b = live0 ? clus_off[r + 1] : 0ull;
+    uint64_t ho = live0 ? hit_off[r] : 0ull;
+    const bool live = live0 && ho != hit_off[r + 1];
+    uint64_t xo = live ? x_off[r] : 0ull, co = live ? xcb_off[r] : 0ull;
+    // one hit: its record, and for a hit that is not plain its extra record and text
+    auto put = [&](uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf) {
+        HitRec hr; hr.read = rd; hr.score = c_score[k];
         hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
-        h_rec[ho] = hr;
+        h_rec[ho1] = hr;
         if (!(clf & CIG_DIAG)) {
-            HitExtra x; x.hit = (uint32_t)ho; x.win_len = wl; x.cig_off = (uint32_t)co; x.cig_len = clf;
-            x_rec[xo++] = x;
+            HitExtra x; x.hit = (uint32_t)ho1; x.win_len = wl; x.cig_off = (uint32_t)co1; x.cig_len = clf;
+            x_rec[xo1] = x;
             // the text sits right-aligned in its slot (slots are multiples of 32 bytes, 16-byte aligned): it is taken 16 bytes at a
             // time from the slot's end by aligned loads and stored byte by byte (stores do not stall the lane; a byte loop of
             // dependent load / store pairs took 2.9 ms for the 15 M extras of a repeat-rich batch)
@@ -3385,12 +3408,40 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
                 const uint4 v = *(const uint4 *)(slot_end - done - 16);
                 const unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
                 const uint32_t take = clf - done < 16 ? clf - done : 16;
-                uint8_t *dst = x_cig + co + (clf - done) - 16;                 // byte i of the chunk goes to dst[i], i = 16 - take .. 15
+                uint8_t *dst = x_cig + co1 + (clf - done) - 16;                // byte i of the chunk goes to dst[i], i = 16 - take .. 15
                 for (uint32_t i = 16 - take; i < 16; i++) dst[i] = (uint8_t)((i < 8 ? lo : hi) >> (8 * (i & 7)));
             }
-            co += clf;
         }
-        ho++;
+    };
+    const bool fat = live && b - a > HITS_FAT;
+    if (live && !fat)
+        for (uint64_t k = b; k-- > a;) {                  // reverse of the cluster order
+            if (c_status[k] != CS_OK) continue;
+            const uint32_t wl = c_wlen[k], clf = c_ciglen[k];
+            put(r, k, ho, xo, co, wl, clf);
+            if (!(clf & CIG_DIAG)) { xo++; co += clf; }
+            ho++;
+        }
+    // a read with many candidates: the wave takes it together, 64 candidates at a time in the same (reverse) order -- lane l the
+    // l-th of the chunk; where a hit goes follows from the lanes before it (ballots; a scan of the text lengths)
+    for (unsigned long long fm = __ballot(fat); fm; fm &= fm - 1ull) {
+        const int src = __ffsll((long long)fm) - 1;
+        const uint64_t fa = (uint64_t)__shfl((long long)a, src, 64), fb = (uint64_t)__shfl((long long)b, src, 64);
+        uint64_t fho = (uint64_t)__shfl((long long)ho, src, 64), fxo = (uint64_t)__shfl((long long)xo, src, 64), fco = (uint64_t)__shfl((long long)co, src, 64);
+        const uint32_t fr = (uint32_t)__shfl((int)r, src, 64);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (uint64_t kend = fb; kend > fa; kend = kend - fa > 64 ? kend - 64 : fa) {
+            const bool in = kend - fa > lane;
+            const uint64_t k = in ? kend - 1 - lane : fa;
+            const bool ok = in && c_status[k] == CS_OK;
+            const uint32_t wl = ok ? c_wlen[k] : 0u, clf = ok ? c_ciglen[k] : 0u;
+            const bool ex = ok && !(clf & CIG_DIAG);
+            const unsigned long long mok = __ballot(ok), mex = __ballot(ex);
+            const uint32_t tl = ex ? clf : 0u, incl = dpp_scan_incl_u32(tl);
+            if (ok) put(fr, k, fho + (uint64_t)__popcll(mok & lt), fxo + (uint64_t)__popcll(mex & lt), fco + (incl - tl), wl, clf);
+            fho += (uint64_t)__popcll(mok); fxo += (uint64_t)__popcll(mex);
+            fco += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
     }
 }
 

@@ -99,14 +99,19 @@ def align_read(fm, ref1, q, cap=256):
     """-> None (read emits nothing) | [(score, cigar, pos, win_off, win_len)] in reference list order;
     raises RuntimeError on the inputs the reference would crash on."""
     q = bytes(q)
-    score = np.empty(cap, np.int32); pos = np.empty(cap, np.int64)
-    woff = np.empty(cap, np.int64); wlen = np.empty(cap, np.int32)
-    cigcap = 1 << 16
-    cig = C.create_string_buffer(cigcap)
-    n = lib().orc_align_read(C.byref(fm.c), ref1, C.c_int64(len(ref1)), q, len(q),
-                             score.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
-                             woff.ctypes.data_as(C.c_void_p), wlen.ctypes.data_as(C.c_void_p),
-                             cig, cigcap, cap, None)
+    while True:
+        score = np.empty(cap, np.int32); pos = np.empty(cap, np.int64)
+        woff = np.empty(cap, np.int64); wlen = np.empty(cap, np.int32)
+        cigcap = max(1 << 16, 64 * cap)
+        cig = C.create_string_buffer(cigcap)
+        n = lib().orc_align_read(C.byref(fm.c), ref1, C.c_int64(len(ref1)), q, len(q),
+                                 score.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+                                 woff.ctypes.data_as(C.c_void_p), wlen.ctypes.data_as(C.c_void_p),
+                                 cig, cigcap, cap, None)
+        if n == -4 and cap < (1 << 20):           # the caller's arrays were too small (a read with hundreds of hits): once more, larger
+            cap *= 16
+            continue
+        break
     if n == -1:
         return None
     if n < 0:

@@ -164,6 +164,65 @@ def test_compact_table_on_a_repeat_genome():
         ix.close()
 
 
+def test_reads_with_hundreds_of_hits():
+    """A 100-base unit in 300 exact copies and 60 copies with a 2-base deletion.  A 15-mer of it has 360 occurrences -- too many
+    seeds (bwa.erl:33) -- but a sub-read whose search dies on a substituted base after 12 steps returns its WHOLE interval
+    (fmi:get_seed_ends has no range check on that path): two such sub-reads and the read has a cluster at every copy.
+    360 candidates per read: the hit kernels take such a read with the whole wave (HITS_FAT); plain hits (two mismatches on a
+    square window), DP hits (six mismatches) and windows with the deletion in them, all in one read's list -- against the oracle,
+    and the compact table against the per-hit one."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(4711)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    g = bytearray(acgt[rng.integers(0, 4, 2_000_000, dtype=np.uint8)].tobytes())
+    unit = bytes(acgt[rng.integers(0, 4, 100, dtype=np.uint8)].tobytes())
+    for k in range(360):
+        at = 3000 + 5000 * k
+        if k % 6 == 5:
+            g[at:at + 98] = unit[:40] + unit[42:]
+        else:
+            g[at:at + 100] = unit
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=1)
+    ix.set_ktable(15, 1)
+    try:
+        L, SA = ix.export()
+        ptr, shift = ix.meta()
+        ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+        ref1 = E.make_ref1(ref)
+
+        def sub(q, ps):
+            q = bytearray(q)
+            for p_ in ps:
+                q[p_] = b"ACGT"[(b"ACGT".index(q[p_]) + 1 + p_ % 3) & 3]
+            return bytes(q)
+        # a substitution 13 bases left of a sub-read's end (ends at 100, 92, 84, ...): that sub-read dies after 12 matched bases
+        reads = [sub(unit, (87, 71)), sub(unit, (87, 71, 55, 39, 23, 7)), sub(unit, (87, 23)), sub(unit, (87, 55, 23))] * 2
+        reads += synth_reads(ref, 200, 100, 12, max_subs=2)
+        exp = [orc.align_read(ofm, ref1, q) for q in reads[:4]]
+        assert min(len(e) for e in exp) > 300                   # (more than HITS_FAT candidates each)
+        bases, off = lib.pack_reads(reads)
+        codes, exc = lib.pack_2bit(bases)
+        for opts in ({}, {"sw_band_min": 0}):
+            b = lib.Batch(ix)
+            b.set_options(**opts)
+            b.set_reads_packed(codes, exc, len(reads), read_len=100)
+            c = b.run(lib.STAGE_EXTEND)
+            full = b.fetch_hits()
+            comp = b.fetch_hits_compact()
+            assert oracle_check(full, reads, ofm, ref1) > 8 * 300
+            assert 0 < len(comp["extra"]) < len(comp["hits"]) == c["n_hits"]        # plain and non-plain hits
+            assert np.all(np.diff(comp["hits"]["read"].astype(np.int64)) >= 0) and np.all(np.diff(comp["extra"]["hit"].astype(np.int64)) > 0)
+            ex = lib.hits_expand(len(reads), 100, None, shift, comp["hits"], comp["extra"], comp["cigar"])
+            for k in KEYS[1:]:
+                assert np.array_equal(ex[k], full[k]), k
+            assert ex["cigar"] == full["cigar"]
+            b.destroy()
+    finally:
+        ix.close()
+
+
 def test_pipe_packs_a_batch_that_is_mostly_exceptions(gpu_index, orc_fm, ref_bytes):
     """bwt_pipe_submit_ascii on a batch whose exception list outgrows the slot's buffer (reads that are mostly N): the slot's thread
     grows the pinned buffer and packs again; the answers are still the oracle's."""
