@@ -392,6 +392,13 @@ struct bwt_batch {
     std::vector<hipEvent_t> ev_pool;
     std::map<std::string, KernelStat> stats;
     hipEvent_t ev_uploaded = nullptr;    // bwt_batch_set_reads_packed_hook: the host buffers have crossed the link
+    // small device -> host values of a run (counters, scan totals) do not go through the copy engines: a batch in a pipe shares
+    // those with the other slots' 0.2-0.3 GB transfers, and an 8-byte copy queued behind one of them stalls the kernels' turn for
+    // milliseconds.  A one-wave kernel writes them into pinned host memory instead (mail), delivered at the next synchronisation.
+    uint8_t *mbox = nullptr;             // pinned, MBOX_BYTES
+    struct Mail { void *dst; uint32_t at, bytes; };
+    std::vector<Mail> mail_pending;
+    uint32_t mbox_used = 0;
 };
 
 static int prof_collect(bwt_batch *b) {
@@ -512,6 +519,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
     prof_collect(b);
     for (auto ev : b->ev_pool) (void)hipEventDestroy(ev);
     if (b->ev_uploaded) (void)hipEventDestroy(b->ev_uploaded);
+    if (b->mbox) (void)hipHostFree(b->mbox);
     DevBuf *all[] = {&b->bases, &b->off, &b->rplanes, &b->pk_codes, &b->pk_exc, &b->pfq, &b->r_nx, &b->r_xcb, &b->x_off, &b->xcb_off, &b->x_rec, &b->x_cig, &b->h_xidx, &b->h_len, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty,
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
@@ -843,11 +851,42 @@ static int read_planes(bwt_batch *b) {
     return launch_planes(b->bases.as<uint8_t>(), b->total_bases, b->rplanes.as<uint32_t>(), b->device, b->stream);
 }
 
-static int fetch_counters(bwt_batch *b) {
-    HIPCHK(hipMemcpyAsync(&b->hctr, b->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+enum { MBOX_BYTES = 4096 };
+static __global__ void k_mail(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t words) {
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+}
+// `bytes` (a multiple of 4) at device address `src` -> host `dst`, valid after the next mail_sync
+static int mail(bwt_batch *b, void *dst, const void *src, uint32_t bytes) {
+    if (!b->mbox) {
+        if (hipHostMalloc((void **)&b->mbox, MBOX_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            b->mbox = nullptr;
+            return fail(BWT_ENOMEM, "hipHostMalloc of the batch's mailbox failed");
+        }
+    }
+    if ((bytes & 3u) || b->mbox_used + bytes > MBOX_BYTES) return fail(BWT_EHIP, "internal: mailbox overflow");
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, b->stream, (const uint32_t *)src, (uint32_t *)(b->mbox + b->mbox_used), bytes / 4);
+    b->mail_pending.push_back({dst, b->mbox_used, bytes});
+    b->mbox_used += (bytes + 15u) & ~15u;
     return 0;
 }
+static int mail_sync(bwt_batch *b) {
+    const hipError_t e = hipStreamSynchronize(b->stream);
+    for (auto &m : b->mail_pending) memcpy(m.dst, b->mbox + m.at, m.bytes);
+    b->mail_pending.clear();
+    b->mbox_used = 0;
+    HIPCHK(e);
+    return 0;
+}
+static int fetch_counters(bwt_batch *b) {
+    int rc = mail(b, &b->hctr, b->ctr.p, (uint32_t)sizeof(Counters));
+    return rc ? rc : mail_sync(b);
+}
+// (a function that mails into its own locals: nothing stays queued for them when it returns early)
+struct MailGuard {
+    bwt_batch *b;
+    ~MailGuard() { b->mail_pending.clear(); b->mbox_used = 0; }
+};
 
 // The seed search.  With a suffix-interval table (and reads of at most 64 sub-reads): k_seed_tasks (sub-reads, table
 // lookups, per-read totals) + k_search_pending (the LF steps the table left over) -- the per-read totals of the cluster
@@ -965,6 +1004,7 @@ static int stage_search(bwt_batch *b, bool lean) {
 
 static int stage_cluster(bwt_batch *b, bool to_extend) {
     const uint32_t n = b->n, maxT = b->maxT;
+    MailGuard mail_guard{b};
     int rc;
     b->desc_partial = false;
     if ((rc = b->r_P.ensure((size_t)n * 4 + 4)) || (rc = b->r_qty.ensure((size_t)n * 4 + 4)) ||
@@ -988,17 +1028,16 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         // Most batches leave none: the candidate offsets are scanned before the counters come back, so that such a batch needs
         // one synchronisation here, not two.
         if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
-        HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = mail(b, &ncand, b->clus_off.as<uint64_t>() + n, 8))) return rc;
         if ((rc = fetch_counters(b))) return rc;                               // sync #1
         all_clustered = !(b->hctr.n_small || b->hctr.n_mid2 || b->hctr.n_mid4 || b->hctr.n_big);
         if (!all_clustered) {
             if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
-            HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-            HIPCHK(hipStreamSynchronize(b->stream));
+            if ((rc = mail(b, &total_seeds, b->seed_off.as<uint64_t>() + n, 8)) || (rc = mail_sync(b))) return rc;
         }
     } else {
         if ((rc = dev_scan(b, b->r_P.as<uint32_t>(), b->seed_off.as<uint64_t>(), n))) return rc;
-        HIPCHK(hipMemcpyAsync(&total_seeds, b->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = mail(b, &total_seeds, b->seed_off.as<uint64_t>() + n, 8))) return rc;
         if ((rc = fetch_counters(b))) return rc;                               // sync #1
     }
     if (b->hctr.err_flags & 1) return fail(BWT_EOVERFLOW, "a read produced more than 2^31 seeds");
@@ -1041,7 +1080,7 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
                 b->r_K.as<uint32_t>());
     if (!all_clustered) {
         if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
-        HIPCHK(hipMemcpyAsync(&ncand, b->clus_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = mail(b, &ncand, b->clus_off.as<uint64_t>() + n, 8))) return rc;
         if ((rc = fetch_counters(b))) return rc;                               // sync #2
     }
     if (b->hctr.err_flags & 8) return fail(BWT_EHIP, "internal: cluster queue count mismatch");
@@ -1301,6 +1340,7 @@ static int dev_scan3(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const ui
 
 static int stage_hits(bwt_batch *b, int32_t shift) {
     const uint32_t n = b->n;
+    MailGuard mail_guard{b};
     int rc;
     b->expanded = false;
     if ((rc = b->r_nhit.ensure((size_t)n * 4 + 4)) || (rc = b->r_nx.ensure((size_t)n * 4 + 4)) || (rc = b->r_xcb.ensure((size_t)n * 4 + 4)) ||
@@ -1331,9 +1371,9 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
             b->c_score.as<int32_t>(), b->c_ciglen.as<uint32_t>(), b->c_S.as<uint32_t>(), b->c_wlen.as<uint32_t>(),
             b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->x_rec.as<HitExtra>(), b->x_cig.as<uint8_t>());
     uint64_t tot[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(&tot[0], b->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(&tot[1], b->x_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(&tot[2], b->xcb_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = mail(b, &tot[0], b->hit_off.as<uint64_t>() + n, 8)) || (rc = mail(b, &tot[1], b->x_off.as<uint64_t>() + n, 8)) ||
+        (rc = mail(b, &tot[2], b->xcb_off.as<uint64_t>() + n, 8)))
+        return rc;
     if ((rc = fetch_counters(b))) return rc;                                   // sync
     HIPCHK(hipGetLastError());
     b->n_hits = tot[0]; b->n_extra = tot[1]; b->xcig_bytes = tot[2]; b->cig_bytes = b->hctr.cig_total;
