@@ -32,6 +32,12 @@ import time
 
 import numpy as np
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default).  This process has more
+# streams than that (the pipe's slots, the resident batches, the index, RCCL): two that share a queue serialise, and a slot's
+# kernels then sit behind another slot's 0.3 GB copy (measured: the kernels' turn 6.3 -> 7.8 ms per batch with four slots,
+# 6.3 -> 6.1 with three).  A deployment setting, like the pipe's depth; read by the runtime when it starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
