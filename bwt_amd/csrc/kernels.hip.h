@@ -2121,49 +2121,75 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
             double dcarv = s == 0 ? 0.0 : -(double)(i0 + 1);
             const int tl = (int)(lq - 1 - i0);          // register slot of the last query row (last strip only)
             const bool last = (s == ns - 1);
-            for (uint32_t j = 1; j <= w; j++) {
-                const uint32_t rc = rw[j - 1];
-                if (!FP && s == 0 && !is_acgt(rc)) { needfp = true; break; }
-                int d = dcar, u;
-                if (LDSB) u = (int)(int16_t)bl[j * 64]; else u = (int)bnd[j * 64];
-                double dv = dcarv, uv = 0.0;
-                if (FP) uv = bndv[j * 64];
-                dcar = u; dcarv = uv;
-                uint32_t dirw = 0;
+            // Columns in chunks of four, one chunk ahead: the window bytes and the boundary values (row i0 of the strip above) of
+            // columns jc + 4 .. jc + 7 are asked for before the cells of columns jc .. jc + 3 are computed, so that a lane meets
+            // one memory latency per chunk and most of it behind those cells.  (A lane per alignment leaves the chip a wave or
+            // two per SIMD when this kernel gets the few hundred-base-wide windows of a batch: a dependent byte load and a
+            // dependent boundary load per COLUMN were most of its time, 5.7 ms for 56 k windows on the repeat-rich batch.)
+            // A column's boundary value is read a chunk before the column is written: nothing of this strip is read back.
+            auto fetch = [&](uint32_t jc, uint32_t (&rcn)[4], int (&un)[4], double (&uvn)[4]) {
 #pragma unroll
-                for (int t = 0; t < SW_R; t++) {
-                    if (FP) {
-                        const int lcode = H[t]; const double lv = Hv[t];
-                        const double cd = dv + sigma_gen(qc[t], rc);
-                        const double cl = lv + (lcode == DIR_LEFT ? -1.0 : -2.0);
-                        const double cu = uv + (u == DIR_UP ? -1.0 : -2.0);
-                        double hv = cd; int hc = DIR_UL;
-                        if (cu > hv) { hv = cu; hc = DIR_UP; }
-                        if (cl > hv) { hv = cl; hc = DIR_LEFT; }
-                        dirw |= (uint32_t)hc << (2 * t);
-                        d = lcode; dv = lv; u = hc; uv = hv; H[t] = hc; Hv[t] = hv;
-                    } else {
-                        const int old = H[t];
-                        const int sig = (qc[t] == rc) ? 7 : -5;                       // 4*sigma - 1
-                        const int cd = (d | 3) + sig;                                 // 4(Vul+sigma) + up_left
-                        const int cl = old + (int)(int8_t)(0xF5F6F7FCu >> ((old & 3) * 8));   // {-4,-9,-10,-11}
-                        const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));       // {-7,-4,-9,-10}
-                        int h = cd > cl ? cd : cl;
-                        h = h > cu ? h : cu;
-                        if (DIRS) dirw |= (uint32_t)(h & 3) << (2 * t);
-                        d = old; u = h; H[t] = h;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t col = jc + (uint32_t)k;
+                    const bool in = col <= w;
+                    rcn[k] = in ? (uint32_t)rw[col - 1] : 0u;
+                    if (LDSB) un[k] = in ? (int)(int16_t)bl[col * 64] : 0; else un[k] = in ? (int)bnd[col * 64] : 0;
+                    uvn[k] = 0.0;
+                    if (FP) uvn[k] = in ? bndv[col * 64] : 0.0;
+                }
+            };
+            uint32_t rcA[4]; int uA[4]; double uvA[4];
+            fetch(1u, rcA, uA, uvA);
+            for (uint32_t jc = 1; jc <= w && !needfp; jc += 4) {
+                uint32_t rcB[4]; int uB[4]; double uvB[4];
+                fetch(jc + 4, rcB, uB, uvB);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t j = jc + (uint32_t)k;
+                    if (j > w || needfp) continue;
+                    const uint32_t rc = rcA[k];
+                    if (!FP && s == 0 && !is_acgt(rc)) { needfp = true; continue; }
+                    int d = dcar, u = uA[k];
+                    double dv = dcarv, uv = uvA[k];
+                    dcar = u; dcarv = uv;
+                    uint32_t dirw = 0;
+#pragma unroll
+                    for (int t = 0; t < SW_R; t++) {
+                        if (FP) {
+                            const int lcode = H[t]; const double lv = Hv[t];
+                            const double cd = dv + sigma_gen(qc[t], rc);
+                            const double cl = lv + (lcode == DIR_LEFT ? -1.0 : -2.0);
+                            const double cu = uv + (u == DIR_UP ? -1.0 : -2.0);
+                            double hv = cd; int hc = DIR_UL;
+                            if (cu > hv) { hv = cu; hc = DIR_UP; }
+                            if (cl > hv) { hv = cl; hc = DIR_LEFT; }
+                            dirw |= (uint32_t)hc << (2 * t);
+                            d = lcode; dv = lv; u = hc; uv = hv; H[t] = hc; Hv[t] = hv;
+                        } else {
+                            const int old = H[t];
+                            const int sig = (qc[t] == rc) ? 7 : -5;                       // 4*sigma - 1
+                            const int cd = (d | 3) + sig;                                 // 4(Vul+sigma) + up_left
+                            const int cl = old + (int)(int8_t)(0xF5F6F7FCu >> ((old & 3) * 8));   // {-4,-9,-10,-11}
+                            const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));       // {-7,-4,-9,-10}
+                            int h = cd > cl ? cd : cl;
+                            h = h > cu ? h : cu;
+                            if (DIRS) dirw |= (uint32_t)(h & 3) << (2 * t);
+                            d = old; u = h; H[t] = h;
+                        }
+                    }
+                    if (LDSB) bl[j * 64] = (uint16_t)H[SW_R - 1]; else bnd[j * 64] = (uint32_t)H[SW_R - 1];
+                    if (FP) bndv[j * 64] = Hv[SW_R - 1];
+                    if (DIRS) dirs[((uint64_t)s * maxW1 + j) * 64] = dirw;
+                    if (last) {       // value of query row Lq in this column (register slot tl of the last strip)
+                        int lastp = H[0]; double lastv = Hv[0];
+#pragma unroll
+                        for (int t = 1; t < SW_R; t++) { if (t == tl) { lastp = H[t]; lastv = Hv[t]; } }
+                        if (FP) { if (lastv > bestv) { bestv = lastv; bestj = j; } }
+                        else if ((lastp >> 2) > (bestp >> 2)) { bestp = lastp; bestj = j; }
                     }
                 }
-                if (LDSB) bl[j * 64] = (uint16_t)H[SW_R - 1]; else bnd[j * 64] = (uint32_t)H[SW_R - 1];
-                if (FP) bndv[j * 64] = Hv[SW_R - 1];
-                if (DIRS) dirs[((uint64_t)s * maxW1 + j) * 64] = dirw;
-                if (last) {       // value of query row Lq in this column (register slot tl of the last strip)
-                    int lastp = H[0]; double lastv = Hv[0];
 #pragma unroll
-                    for (int t = 1; t < SW_R; t++) { if (t == tl) { lastp = H[t]; lastv = Hv[t]; } }
-                    if (FP) { if (lastv > bestv) { bestv = lastv; bestj = j; } }
-                    else if ((lastp >> 2) > (bestp >> 2)) { bestp = lastp; bestj = j; }
-                }
+                for (int k = 0; k < 4; k++) { rcA[k] = rcB[k]; uA[k] = uB[k]; uvA[k] = uvB[k]; }
             }
         }
         if (!FP && needfp) {          // a base outside ACGT: sigma may return 1.6 -> the fp64 kernel (runs last)
