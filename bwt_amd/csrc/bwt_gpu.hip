@@ -367,7 +367,7 @@ struct bwt_batch {
     DevBuf c_read, c_S, c_D, c_qoff, c_qlen, c_woff, c_wlen, c_status, c_score, c_ciglen, cig, fpq;
     uint32_t cig_stride = 32;
     // sw slabs
-    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2;
+    DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2, tqw;
     DevBuf bq, bq2, bq3, slab_band;    // k_sw_band: the queues of what its tiers pass on (bq3: first tier -> third), the direction slab
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
@@ -524,7 +524,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->r_K, &b->r_nhit, &b->r_cigb, &b->r_status, &b->bigq, &b->mid2q, &b->mid4q, &b->seed_off, &b->clus_off, &b->hit_off,
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
-                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
+                     &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->tqw, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -1138,6 +1138,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.c_ciglen = b->c_ciglen.as<uint32_t>(); io.cig = b->cig.as<uint8_t>(); io.cig_stride = b->cig_stride;
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
     io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.wave_upto = 0;
+    io.tq_in = nullptr; io.tq_in_count = nullptr;
     if (qplanes && wplanes && b->opt.sw_prefilter != 0) {
         io.dq = b->dq.as<uint32_t>();
         CandSrc src{};
@@ -1268,6 +1269,8 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         const uint32_t qw = (max_lq + 31) / 32;
         const uint64_t lds_pk = (uint64_t)(2 * ((wcap + 31) / 32) + 2 * qw) * 64 * 4 * 2 * 4;     // 2 sets x 4 waves
         const uint32_t per_cu = 2;                                                             // VGPR-limited (181 / 247 VGPRs)
+        const uint32_t *const NOQ = nullptr; const unsigned int *const NOC = nullptr;          // (k_sw_pk's queue overrides: none)
+        uint32_t *const NOOQ = nullptr; unsigned int *const NOOC = nullptr;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * per_cu);
         // After the prefilter the DP queue holds hardly any plain diagonal (those with <= 2 mismatches in a square window are
         // gone): a score-only pass would hand most of it on to the traced pass anyway (measured, 150 bp reads with indels:
@@ -1280,10 +1283,10 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             ProfScope ps(b, "sw_extend");
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   (uint32_t *)nullptr, 0u, wv_thresh);
+                                   (uint32_t *)nullptr, 0u, wv_thresh, NOQ, NOC, NOOQ, NOOC);
             else
                 hipLaunchKernelGGL((k_sw_pk<150, false>), dim3(blocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   (uint32_t *)nullptr, 0u, wv_thresh);
+                                   (uint32_t *)nullptr, 0u, wv_thresh, NOQ, NOC, NOOQ, NOOC);
         }
         // packed traceback pass over the alignments that are not the plain diagonal: per-wave direction slab
         const uint32_t ndg = (max_lq + 7) / 8, w1 = wcap + 1;
@@ -1294,10 +1297,36 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             ProfScope ps(b, trace_all ? "sw_extend" : "sw_trace_pk");
             if (max_lq == 100)
                 hipLaunchKernelGGL((k_sw_pk<100, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
+                                   b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh, NOQ, NOC, NOOQ, NOOC);
             else
                 hipLaunchKernelGGL((k_sw_pk<150, true>), dim3(tblocks), dim3(256), (size_t)lds_pk, b->stream, io, (uint32_t)nc, wcap,
-                                   b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh);
+                                   b->slab_dir_pk.as<uint32_t>(), w1, wv_thresh, NOQ, NOC, NOOQ, NOOC);
+        }
+        // the WIDE pass: windows past the cap above (clusters that chain along tandem copies: several hundred bases) went to the
+        // generic trace queue; they run through the same kernel once more with as much window as 160 KB of LDS holds planes for --
+        // one block per CU -- and only what is wider still is left for the lane-per-alignment kernel
+        if (max_w > wcap && b->opt.sw_pk != 2) {
+            const uint32_t pw_max = (uint32_t)((160 * 1024) / (64 * 4 * 2 * 4) / 2) - qw;             // plane words per window that fit
+            const uint32_t wcap2 = std::min<uint32_t>(max_w, pw_max * 32);
+            const uint64_t lds_pk2 = (uint64_t)(2 * ((wcap2 + 31) / 32) + 2 * qw) * 64 * 4 * 2 * 4;
+            const uint32_t w12 = wcap2 + 1;
+            const uint64_t per_wave2 = (uint64_t)w12 * ndg * 64 * 4;
+            const uint32_t wblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus), (2ull << 30) / (per_wave2 * 4)));
+            if ((rc = b->slab_dir_pk.ensure((uint64_t)wblocks * 4 * per_wave2)) || (rc = b->tqw.ensure(nc * 4 + 4))) return rc;
+            Counters *dc = b->ctr.as<Counters>();
+            ProfScope ps(b, "sw_trace_wide");
+            if (max_lq == 100) {
+                HIPCHK(hipFuncSetAttribute((const void *)k_sw_pk<100, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pk2));
+                hipLaunchKernelGGL((k_sw_pk<100, true>), dim3(wblocks), dim3(256), (size_t)lds_pk2, b->stream, io, (uint32_t)nc, wcap2,
+                                   b->slab_dir_pk.as<uint32_t>(), w12, 0u, (const uint32_t *)io.tq, (const unsigned int *)&dc->tq_count,
+                                   b->tqw.as<uint32_t>(), &dc->tqw_count);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void *)k_sw_pk<150, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pk2));
+                hipLaunchKernelGGL((k_sw_pk<150, true>), dim3(wblocks), dim3(256), (size_t)lds_pk2, b->stream, io, (uint32_t)nc, wcap2,
+                                   b->slab_dir_pk.as<uint32_t>(), w12, 0u, (const uint32_t *)io.tq, (const unsigned int *)&dc->tq_count,
+                                   b->tqw.as<uint32_t>(), &dc->tqw_count);
+            }
+            io.tq_in = b->tqw.as<uint32_t>(); io.tq_in_count = &dc->tqw_count;
         }
     } else if (fits16 && lds_bytes <= 160 * 1024 && !lds_off) {
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / lds_bytes)));
@@ -1321,7 +1350,8 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     twaves = std::max<uint64_t>(4, std::min<uint64_t>(twaves, (4ull << 30) / std::max<uint64_t>(per_wave, 1)) / 4 * 4);
     if ((rc = b->slab_bnd_t.ensure(twaves * maxW1 * 64 * 4)) || (rc = b->slab_dir.ensure(twaves * maxW1 * 64 * 4 * strips)))
         return rc;
-    ascii_for(io.tq, &b->ctr.as<Counters>()->tq_count, 0xffffffffu);
+    if (io.tq_in) ascii_for(io.tq_in, io.tq_in_count, 0xffffffffu);
+    else ascii_for(io.tq, &b->ctr.as<Counters>()->tq_count, 0xffffffffu);
     KLAUNCH(b, "sw_trace", (k_sw<SW_TRACE, false>), (uint32_t)(twaves / 4), 256, io, (uint32_t)nc, maxW1, strips,
             b->slab_bnd_t.as<uint32_t>(), (double *)nullptr, b->slab_dir.as<uint32_t>());
     const uint64_t fwaves = std::max<uint64_t>(4, std::min<uint64_t>(twaves, 1024) / 4 * 4);

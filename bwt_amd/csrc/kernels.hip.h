@@ -2051,6 +2051,8 @@ struct SwIO {
     uint32_t *tq2;             // traceback queue of the packed kernels (same read length, window <= cap)
     const uint32_t *qplanes, *wplanes;   // bit-planes over qbuf / rbuf (k_read_planes layout)
     uint32_t wave_upto;        // a DP queue of at most this many candidates is k_sw_wave's: the score kernels leave it alone
+    const uint32_t *tq_in;     // k_sw<SW_TRACE>: its queue and count when they are not tq / ctr->tq_count (what the wide pass of k_sw_pk left)
+    const unsigned int *tq_in_count;
     Counters *ctr;
 };
 
@@ -2074,13 +2076,13 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
     uint32_t *bnd = LDSB ? nullptr : slab_bnd + (uint64_t)wave * maxW1 * 64 + lane;                // [j*64]
     double *bndv = FP ? slab_bndv + (uint64_t)wave * maxW1 * 64 + lane : nullptr;
     uint32_t *dirs = DIRS ? slab_dir + (uint64_t)wave * max_strips * maxW1 * 64 + lane : nullptr;  // [(s*maxW1+j)*64]
-    const uint32_t n_total = MODE == SW_FP ? io.ctr->fp_count : MODE == SW_TRACE ? io.ctr->tq_count : io.dq ? io.ctr->dq_count : n_items;
+    const uint32_t n_total = MODE == SW_FP ? io.ctr->fp_count : MODE == SW_TRACE ? (io.tq_in ? *io.tq_in_count : io.ctr->tq_count) : io.dq ? io.ctr->dq_count : n_items;
     if (MODE == SW_SCORE && io.dq && n_total <= io.wave_upto) return;
 
     for (uint32_t g = wave; (uint64_t)g * 64 < n_total; g += nwaves) {
         const uint32_t item = g * 64 + lane;
         if (item >= n_total) continue;
-        const uint32_t c = MODE == SW_FP ? io.fpq[item] : MODE == SW_TRACE ? io.tq[item] : io.dq ? io.dq[item] : item;
+        const uint32_t c = MODE == SW_FP ? io.fpq[item] : MODE == SW_TRACE ? (io.tq_in ? io.tq_in[item] : io.tq[item]) : io.dq ? io.dq[item] : item;
         const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
         const int64_t wo = io.c_woff[c];
         if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
@@ -2719,9 +2721,16 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
 // TRACE = false: score pass over the DP queue (non-diagonal alignments go on to io.tq2).
 // TRACE = true : the same DP over io.tq2 that also keeps the 2-bit direction of every cell (8 rows of both
 //                alignments per dword, [column][row group][lane] in a per-wave HBM slab) and walks the traceback.
+// in_q / in_count (TRACE): another queue than tq2 -- the WIDE pass: the windows the first pass found wider than its cap (they went
+// to the generic trace queue io.tq) once more with a cap of up to ~1100 bases, i.e. as much window as LDS holds planes for; what is
+// wider still, or of another read length, goes to over_q / over_count instead of io.tq.  (The generic kernel is a lane per
+// alignment at ~18 instructions per cell, one wave per SIMD when a batch has a few ten thousand such windows: 5.3 ms for 56 k of
+// them on the repeat-rich batch; two per lane at ~4 per cell here.)
 template <int LQ, bool TRACE>
 __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32_t wcap, uint32_t *__restrict__ slab_dir,
-                                               uint32_t maxW1, uint32_t skip_upto) {
+                                               uint32_t maxW1, uint32_t skip_upto, const uint32_t *__restrict__ in_q,
+                                               const unsigned int *__restrict__ in_count, uint32_t *__restrict__ over_q,
+                                               unsigned int *__restrict__ over_count) {
     constexpr int QW = (LQ + 31) / 32, NG = (LQ + 15) / 16, NDG = (LQ + 7) / 8;   // NDG: direction dwords per column
     extern __shared__ uint32_t lds_sw[];
     const uint32_t lane = threadIdx.x & 63;
@@ -2731,8 +2740,8 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
     const uint32_t set_words = (2 * PW + 2 * QW) * 64;                      // one set = 64 candidates
     uint32_t *pl = lds_sw + (uint64_t)(threadIdx.x >> 6) * 2 * set_words;
 
-    const uint32_t *const queue = TRACE ? io.tq2 : io.dq;
-    if (TRACE) n_items = io.ctr->tq2_count; else if (io.dq) n_items = io.ctr->dq_count;
+    const uint32_t *const queue = in_q ? in_q : TRACE ? io.tq2 : io.dq;
+    if (in_q) n_items = *in_count; else if (TRACE) n_items = io.ctr->tq2_count; else if (io.dq) n_items = io.ctr->dq_count;
     if (n_items <= skip_upto) return;                            // (a short queue: k_sw_wave took it)
     uint32_t *const dirs = TRACE ? slab_dir + (uint64_t)wave * maxW1 * NDG * 64 + lane : nullptr;   // [(j*NDG + g)*64]
     for (uint32_t g = wave; (uint64_t)g * 128 < n_items; g += nwaves) {
@@ -2815,7 +2824,10 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (state[h] == 2) { io.c_status[cc[h]] = CS_WINDOW_OOR; io.c_ciglen[cc[h]] = 0; }
-            else if (state[h] == 3) { io.c_status[cc[h]] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = cc[h]; }   // generic trace kernel
+            else if (state[h] == 3) {                                  // generic trace kernel
+                io.c_status[cc[h]] = CS_PENDING;
+                if (over_q) over_q[atomicAdd(over_count, 1u)] = cc[h]; else io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = cc[h];
+            }
             else if (state[h] == 4) { io.c_status[cc[h]] = CS_NEED_FP; io.fpq[atomicAdd(&io.ctr->fp_count, 1u)] = cc[h]; }
         }
         const bool runA = state[0] == 0, runB = state[1] == 0;

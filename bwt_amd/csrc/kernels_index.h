@@ -154,7 +154,7 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned int why[6];       // ... by reason: [0] base outside ACGT, [1] table overflow, [4] > 64 seeds in a read, [5] > CL_STAGE clusters
     unsigned int band_in, band_left, band_next, pf_ov;   // (pf_ov: candidates the fused prefilter pass listed for the quad-per-candidate pass)   // k_sw_band, first tier: DP candidates it was given, those it passed on, its work counter
     unsigned int band2_in, band2_left, band2_next, band_direct;   // ... second tier (wider band); band_direct: candidates the first tier sent straight to the third
-    unsigned int band3_in, band3_left, band3_next, pad5_;   // ... third tier (64 diagonals); what it passes on goes to the full-rectangle kernels
+    unsigned int band3_in, band3_left, band3_next, tqw_count;   // (tqw_count: what the wide pass of k_sw_pk left for the generic trace kernel)   // ... third tier (64 diagonals); what it passes on goes to the full-rectangle kernels
     unsigned long long cig_total;                            // bytes of all CIGAR texts of the batch's hits (k_hits_count)
 };
 

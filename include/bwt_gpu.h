@@ -68,7 +68,7 @@ typedef struct {
     int32_t sw_band;            /* 0: no banded DP tiers (full rectangles only); 2: the 20- and 32-diagonal tiers only; else all three */
     int32_t sw_band_min;        /* DP queues up to this many candidates skip the banded tier (default 16384) */
     int32_t sw_lds;             /* 0: boundary rows in HBM slabs instead of LDS */
-    int32_t sw_pk;              /* 0: no packed-i16 DP kernels */
+    int32_t sw_pk;              /* 0: no packed-i16 DP kernels; 2: without their wide pass (windows past 254 bases go to the generic kernel) */
     int32_t sw_trace_all;       /* 0: score-only DP pass first, traceback for what needs it */
     int32_t pf_blocks_per_cu, sw_blocks_per_cu, sw_waves_per_cu;   /* occupancy caps (experiments) */
     int32_t debug;              /* 1: diagnostic lines on stderr (hand-back reasons of k_seed_fast) */

@@ -36,7 +36,7 @@ def check_against_oracle(out, reads, orc_fm, ref1):
 
 # every execution option of bwt_options (include/bwt_gpu.h) that selects between equivalent kernels, and the table's summary bitmap
 MODES = [{"seed_big": 1}, {"ktab_summary": 2}, {"ktab_summary": 0}, {"sw_band": 0}, {"sw_band": 2, "sw_band_min": 0}, {"sw_band_min": 0}, {"sw_band_min": 0, "sw_wave": 0},
-         {"seed_fuse": 0}, {"sw_prefilter": 0}, {"sw_pk": 0}, {"sw_lds": 0}, {"sw_trace_all": 0, "sw_wave": 0},
+         {"seed_fuse": 0}, {"sw_prefilter": 0}, {"sw_pk": 0}, {"sw_pk": 2}, {"sw_lds": 0}, {"sw_trace_all": 0, "sw_wave": 0},
          {"sw_wave": 0, "sw_prefilter": 0}, {"search_ilp": 2}, {"seed_fast": 0}, {"sw_fuse_cand": 0}]
 
 
@@ -398,11 +398,14 @@ def test_banded_dp_in_tandem_repeats(tandem_index, length):
         out = b.fetch_hits()
         assert check_against_oracle(out, reads, ofm, ref1) > 200
         assert c["n_banded"] > 100, c
-        b.set_options(sw_band_min=0, sw_band=0)
-        b.run(lib.STAGE_EXTEND)
-        out0 = b.fetch_hits()
-        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
-            assert np.array_equal(out[k], out0[k]), k
-        assert out["cigar"] == out0["cigar"]
+        assert int(np.max(out["win_len"])) > 254 + 40          # clusters that chain along a tract: windows past the packed kernels' first cap
+        # ... which the packed kernel's wide pass takes (sw_pk = 2: the generic lane-per-alignment kernel, as before); and no band
+        for opts in ({"sw_band_min": 0, "sw_pk": 2}, {"sw_band_min": 0, "sw_band": 0}, {"sw_band_min": 0, "sw_band": 0, "sw_pk": 2}):
+            b.set_options(**opts)
+            b.run(lib.STAGE_EXTEND)
+            out0 = b.fetch_hits()
+            for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+                assert np.array_equal(out[k], out0[k]), (opts, k)
+            assert out["cigar"] == out0["cigar"], opts
     finally:
         b.destroy()
