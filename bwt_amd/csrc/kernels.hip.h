@@ -3439,15 +3439,24 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
             HitExtra x; x.hit = (uint32_t)ho1; x.win_len = wl; x.cig_off = (uint32_t)co1; x.cig_len = clf;
             x_rec[xo1] = x;
             // the text sits right-aligned in its slot (slots are multiples of 32 bytes, 16-byte aligned): it is taken 16 bytes at a
-            // time from the slot's end by aligned loads and stored byte by byte (stores do not stall the lane; a byte loop of
-            // dependent load / store pairs took 2.9 ms for the 15 M extras of a repeat-rich batch)
+            // time from the slot's end by aligned loads (a byte loop of dependent load / store pairs took 2.9 ms for the 15 M extras
+            // of a repeat-rich batch) and stored in pieces of 8 / 4 / 2 / 1 bytes at its unaligned place -- byte by byte the
+            // kernel wrote 2.6 GB for 0.85 GB of records and text
             const uint8_t *slot_end = cig + (k + 1) * (uint64_t)cig_stride;
             for (uint32_t done = 0; done < clf; done += 16) {
                 const uint4 v = *(const uint4 *)(slot_end - done - 16);
-                const unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
+                unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
                 const uint32_t take = clf - done < 16 ? clf - done : 16;
-                uint8_t *dst = x_cig + co1 + (clf - done) - 16;                // byte i of the chunk goes to dst[i], i = 16 - take .. 15
-                for (uint32_t i = 16 - take; i < 16; i++) dst[i] = (uint8_t)((i < 8 ? lo : hi) >> (8 * (i & 7)));
+                // the chunk's last `take` bytes go to x_cig[co1 + clf - done - take ..): shifted down to byte 0 first
+                const uint32_t sft = 16 - take;
+                if (sft >= 8) { lo = hi >> (8 * (sft - 8)); hi = 0; }
+                else if (sft) { lo = (lo >> (8 * sft)) | (hi << (64 - 8 * sft)); hi >>= 8 * sft; }
+                uint8_t *p = x_cig + co1 + (clf - done - take);
+                if (take & 16) { __builtin_memcpy(p, &lo, 8); __builtin_memcpy(p + 8, &hi, 8); }
+                if (take & 8) { __builtin_memcpy(p, &lo, 8); p += 8; lo = hi; }
+                if (take & 4) { const uint32_t w4 = (uint32_t)lo; __builtin_memcpy(p, &w4, 4); p += 4; lo >>= 32; }
+                if (take & 2) { const uint16_t w2 = (uint16_t)lo; __builtin_memcpy(p, &w2, 2); p += 2; lo >>= 16; }
+                if (take & 1) *p = (uint8_t)lo;
             }
         }
     };
