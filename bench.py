@@ -3,7 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload grch38|chr1|config2|config2-align]
 
-One process per GPU (torch.distributed / RCCL for N > 1; the driver launches the ranks).  A "step"
+One process per GPU (torch.distributed / RCCL for N > 1).  Launched under torch.distributed.run (WORLD_SIZE set) a process is
+one rank; started plainly with --gpus N > 1 it starts the N ranks itself (fresh child processes, 127.0.0.1 rendezvous), relays
+rank 0's line and passes on a failing rank's exit code.  A "step"
 is one batch of synthetic reads through the hot path AT THE HOST BOUNDARY ("reads submitted /
 wall time from the first H2D copy to the last gathered hit"; the reference's own boundary is host strings
 in, casts out: src/master.erl:162-178 -> src/worker_bwt.erl:62-69): the packed reads of the batch sit in
@@ -292,6 +294,98 @@ class HostPipeline:
         self.pipe.close()
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT the HIP runtime (the launcher must not initialise a GPU: its children do):
+    the KFD topology nodes that have compute units, cut down by *_VISIBLE_DEVICES.  None when the topology cannot be read."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(base, d, "properties")).read().splitlines() if " " in line)
+        except OSError:
+            # (an unreadable node: a GPU of another container's cgroup)
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n, check_only):
+    """`python3 bench.py --gpus N` with no launcher around it: start N fresh ranks of this script (one process per GPU, as
+    src/master.erl:123,140-147 gives every worker the whole index and lets it pull its reads), relay rank 0's ONE JSON line, pass
+    on the first non-zero exit code and end the other ranks when one dies.  Children are new processes (subprocess: never
+    exec from a process that has touched the GPU -- this one has not, and does not)."""
+    import socket
+    import subprocess
+    if not check_only:
+        have = visible_gpus()
+        if have is not None and have < n:
+            print("bench.py: --gpus %d but only %d GPU%s visible on this node" % (n, have, "" if have == 1 else "s"), file=sys.stderr)
+            return 3
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if (r == 0 or check_only) else sys.stderr))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live and rc == 0:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0:
+                        rc = c if c > 0 else 1
+                        print("bench.py: rank %d ended with exit code %d; ending the other ranks" % (r, c), file=sys.stderr)
+                        break
+            if live and rc == 0:
+                time.sleep(0.05)
+    finally:
+        for r, p_ in enumerate(procs):                      # exactly the processes started here
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+                p_.wait()
+    outs = [p_.stdout.read().decode("utf8", "replace") if p_.stdout is not None else "" for p_ in procs]
+    if rc:
+        sys.stderr.write(outs[0])
+        return rc
+    if check_only:
+        seen = []
+        for o in outs:
+            for ln in o.splitlines():
+                if ln.startswith("{"):
+                    seen.append(json.loads(ln)["launch_check"])
+        ok = sorted(x["rank"] for x in seen) == list(range(n)) and all(x["world"] == n for x in seen)
+        print(json.dumps({"launch_check": {"ranks": seen, "ok": ok}}), flush=True)
+        return 0 if ok else 4
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        print("bench.py: rank 0 printed %d JSON lines, expected one" % len(lines), file=sys.stderr)
+        sys.stderr.write(outs[0])
+        return 5
+    print(lines[0], flush=True)
+    return 0
+
+
 def load_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -316,19 +410,32 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="slots of the host pipeline (0 = the default)")
     ap.add_argument("--ktable", default="", help="K,wide: suffix-interval table depth and whether its top level carries SA values (default: the "
                                                  "library's choice for the index, K=15 wide at GRCh38 scale: 71.6 GB); e.g. 15,0 = 11.5 GB, 0,0 = none")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse the start of the ranks only: every rank reports rank / world and exits before any GPU is touched")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="resident steps only (profiling: rocprofv3's tracing serialises the pipe's streams and inflates the event times; "
                          "`value` is then the resident rate and says so)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nobody launched the ranks: this process becomes the launcher (it never imports torch and never touches HIP)
+        sys.exit(launch_ranks(args.gpus, args.launch_check))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's world and --gpus must agree)" % (args.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
+    if args.launch_check:
+        # the launch rehearsal: say who this rank is and leave before anything initialises a GPU
+        print(json.dumps({"launch_check": {"rank": rank, "local_rank": local_rank, "world": world,
+                                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}}), flush=True)
+        sys.exit(0)
 
     # stdout carries ONE JSON line: whatever libraries print there on the way (RCCL's version banner at communicator set-up)
     # goes to stderr instead
@@ -342,6 +449,7 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dist = None
+    ranks_seen = [0]
     force_gather = os.environ.get("BWT_BENCH_FORCE_GATHER") == "1"    # rehearse the N>1 exchange step on one GPU
     if world > 1 or force_gather:
         import torch.distributed as dist
@@ -349,6 +457,14 @@ def main():
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # who is there, asked over RCCL itself (the first collective of the run; reported as config.ranks_seen)
+        me = torch.tensor([rank], dtype=torch.int64, device=torch.device("cuda", local_rank))
+        everyone = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(everyone, me)
+        ranks_seen = [int(x.item()) for x in everyone]
+        if ranks_seen != list(range(world)):
+            print("bench.py: RCCL all_gather of the ranks returned %r" % (ranks_seen,), file=sys.stderr)
+            sys.exit(6)
 
     from bwt_amd import lib, shard
     length = 100
@@ -591,7 +707,8 @@ def main():
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
                        "suffix_interval_table": {"K": ix.ktable[0], "top_level_carries_sa": ix.ktable[1]},
                        "repeat_spectrum": composition,
-                       "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world},
+                       "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world,
+                       "ranks_seen": ranks_seen},
             "roofline": roof,
             "rooflines": roofs,
             "dominant_kernel": dom,

@@ -686,6 +686,7 @@ int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_
     }
     if (chk[3] & 1u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: exception position behind the last base");
     if (chk[3] & 2u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: an exception byte is one of ACGT");
+    if (chk[3] & 4u) return fail(BWT_EINVAL, "bwt_batch_set_reads_packed: exceptions must be strictly ascending by position");
     const uint32_t maxlq = !n ? 0 : read_len ? read_len : chk[1], minlq = !n ? 0 : read_len ? read_len : chk[0];
     b->n = n; b->max_lq = maxlq; b->maxT = std::max<uint32_t>(1, maxlq / BWT_MIN_LEN);
     b->ulen = (n && minlq == maxlq) ? maxlq : 0;
@@ -1406,6 +1407,12 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
         return rc;
     if ((rc = fetch_counters(b))) return rc;                                   // sync
     HIPCHK(hipGetLastError());
+    // HitExtra.hit and HitExtra.cig_off are 32-bit: a table whose hit count or extras text passes 4 GiB would wrap silently
+    // (k_hits_write stores the low words of its 64-bit scan offsets).  n_cand is capped at 2^32 - 16, the text is not.
+    if (tot[0] > 0xffffffffull || tot[2] > 0xffffffffull) {
+        b->n_hits = 0; b->n_extra = 0; b->xcig_bytes = 0; b->cig_bytes = 0;
+        return fail(BWT_EOVERFLOW, "batch produced more than 2^32-1 hits or bytes of CIGAR text in its compact table: split it");
+    }
     b->n_hits = tot[0]; b->n_extra = tot[1]; b->xcig_bytes = tot[2]; b->cig_bytes = b->hctr.cig_total;
     return 0;
 }

@@ -3565,6 +3565,9 @@ __global__ __launch_bounds__(256) void k_unpack_exc(const uint64_t *__restrict__
         const uint32_t c = (uint32_t)(e >> 56);
         if (pos >= total) { atomicOr(err, 1u); continue; }
         if (c == 'A' || c == 'C' || c == 'G' || c == 'T') { atomicOr(err, 2u); continue; }
+        // the list is ascending by position (include/bwt_gpu.h): two records for one base would set both the N and the `other`
+        // plane bit and race on the byte
+        if (k && (exc[k - 1] & 0x00ffffffffffffffull) >= pos) { atomicOr(err, 4u); continue; }
         const uint64_t w = pos >> 5;
         const uint32_t bit = 1u << (pos & 31);
         atomicAnd(&planes[4 * w + RP_LO], ~bit); atomicAnd(&planes[4 * w + RP_HI], ~bit);

@@ -59,6 +59,16 @@ def _round16(x):
     return (int(x) + 15) // 16 * 16
 
 
+def _host_sync(device):
+    """After work.wait(): under RCCL that call only makes torch's CURRENT STREAM wait for the collective -- the host goes on.
+    The gatherers' buffers are written by the library on ITS OWN stream (bwt_batch_compact_to_device) and read by consumers
+    that may not be on torch's stream either, so a slot may only be handed back to the producer (or its recv views handed
+    out) once the HOST knows the collective is done: block on the stream that now carries the wait.  (gloo's wait() blocks the
+    host by itself; there is nothing to do for a CPU device.)"""
+    if torch.device(device).type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
+
+
 class TableGatherer:
     """Asynchronous, double-buffered gather of COMPACT HIT TABLES (include/bwt_gpu.h) to rank `dst`: everything the worker's cast
     {cigar, Name, {Score, Cigar}, Pos, RefSeq} needs (src/worker_bwt.erl:100-105) -- 16-byte hit records with global read ids,
@@ -143,6 +153,7 @@ class TableGatherer:
         s, work, counts = self.pending
         self.pending = None
         work.wait()
+        _host_sync(self.device)
         if self.rank != self.dst:
             return None
         return [self._sections(self.recv[s][r], counts[r]) for r in range(self.world)]
@@ -227,6 +238,7 @@ class HitGatherer:
         s, work, counts = self.pending
         self.pending = None
         work.wait()
+        _host_sync(self.device)
         if self.rank != self.dst:
             return None
         return [self.recv[s][r][: counts[r]] for r in range(self.world)]

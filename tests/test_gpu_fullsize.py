@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+from _fullsize import pipe_twice_against_digest, sprinkle_exceptions
 
 pytestmark = pytest.mark.gpu
 
@@ -37,39 +38,12 @@ def chr1_scale():
 @pytest.mark.parametrize("length,indel_p,name", [(100, 0.0, "configs[2]: 100 bp, 0/1/2 substitutions"),
                                                  (150, 0.2, "configs[4] reads: 150 bp, 0/1/2 substitutions + an indel of 1-5 bp with p = 0.2")])
 def test_full_size_index_against_oracle_digest(chr1_scale, length, indel_p, name):
-    from bwt_amd import lib
-    from oracle import orc
     bench, ix, ref, ofm, ref1 = chr1_scale
     bases, off = bench.synth_reads(ref, N_READS, length, seed=4000 + length, max_subs=2, indel_p=indel_p)
-    rng = np.random.default_rng(length)
-    dirty = rng.integers(0, N_READS, N_READS // 100)                           # a percent of the reads with an N / IUPAC base (exception list)
-    bases[dirty * length + rng.integers(0, length, len(dirty))] = np.frombuffer(b"NNNNRYKM", np.uint8)[rng.integers(0, 8, len(dirty))]
-    codes, exc = lib.pack_2bit(bases)
-    assert len(exc) > 1000
-    pipe = lib.Pipe(ix, depth=2)
-    pipe.set_options(sw_band_min=0)            # (a DP queue of a few ten thousand candidates would be left to the wave kernel otherwise)
-    try:
-        # two submissions of the same batch: a steady pipe, and the second result must equal the first
-        outs = []
-        for _ in range(2):
-            s, v = pipe.acquire_packed(len(bases), N_READS, len(exc))
-            v["codes"][:len(codes)] = codes; v["exc"][:len(exc)] = exc
-            pipe.submit_packed(s, N_READS, length, len(bases), len(exc))
-        for _ in range(2):
-            r = pipe.wait()
-            out = pipe.expand(r)
-            outs.append((out, r["counts"], len(r["extra"])))
-            pipe.release(r["slot"])
-    finally:
-        pipe.close()
-    (out, c, n_extra), (out2, _, _) = outs
-    for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
-        assert np.array_equal(out[k], out2[k]), k
-    assert out["cigar"] == out2["cigar"]
-    gpu = orc.hits_digest(out)
-    cpu = orc.batch_digest(ofm, ref1, bases, off.astype(np.uint32), os.cpu_count() or 1)
-    bad = np.nonzero(gpu != cpu)[0]
-    assert len(bad) == 0, (name, len(bad), bad[:10].tolist())
+    sprinkle_exceptions(bases, N_READS, length, seed=length)                  # a percent of the reads with an N / IUPAC base (exception list)
+    # (sw_band_min = 0: a DP queue of a few ten thousand candidates would be left to the wave kernel otherwise)
+    out, c, n_extra, n_exc = pipe_twice_against_digest(ix, ofm, ref1, bases, off, N_READS, length, options={"sw_band_min": 0})
+    assert n_exc > 1000
     # the run took the paths the bench takes: nearly every group stays in the fast seed kernel; 100 bp reads are settled by the
     # prefilter (plain hits, no extra record), the 150 bp reads with an indel go through the banded DP
     # (on a genome of this size about half of the reads end without a cluster: the reference's row ranges are shifted one row

@@ -400,7 +400,11 @@ def test_banded_dp_in_tandem_repeats(tandem_index, length):
         assert c["n_banded"] > 100, c
         assert int(np.max(out["win_len"])) > 254 + 40          # clusters that chain along a tract: windows past the packed kernels' first cap
         # ... which the packed kernel's wide pass takes (sw_pk = 2: the generic lane-per-alignment kernel, as before); and no band
-        for opts in ({"sw_band_min": 0, "sw_pk": 2}, {"sw_band_min": 0, "sw_band": 0}, {"sw_band_min": 0, "sw_band": 0, "sw_pk": 2}):
+        # sw_wave = 0: a DP queue this short would otherwise be taken whole by the wave-per-alignment kernel, and the packed
+        # kernel's passes -- the wide one above all -- would launch on empty queues: without it they get every item
+        for opts in ({"sw_band_min": 0, "sw_pk": 2}, {"sw_band_min": 0, "sw_band": 0}, {"sw_band_min": 0, "sw_band": 0, "sw_pk": 2},
+                     {"sw_band_min": 0, "sw_wave": 0}, {"sw_band_min": 0, "sw_wave": 0, "sw_band": 0}, {"sw_wave": 0, "sw_band": 0, "sw_pk": 2},
+                     {"sw_wave": 0, "sw_band": 0, "sw_trace_all": 0}):
             b.set_options(**opts)
             b.run(lib.STAGE_EXTEND)
             out0 = b.fetch_hits()

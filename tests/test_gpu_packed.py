@@ -121,6 +121,10 @@ def test_packed_upload_rejects_bad_input(gpu_index):
     with pytest.raises(lib.BwtError) as e:                            # ... behind the last base
         b.set_reads_packed(codes, np.array([400 | (ord("N") << 56)], np.uint64), 4, read_len=100)
     assert e.value.code == -22
+    for dup in ([7 | (ord("N") << 56), 7 | (ord("R") << 56)], [9 | (ord("N") << 56), 7 | (ord("N") << 56)]):
+        with pytest.raises(lib.BwtError) as e:                        # ... two records for one base / descending positions
+            b.set_reads_packed(codes, np.array(dup, np.uint64), 4, read_len=100)
+        assert e.value.code == -22 and "ascending" in str(e.value)
     with pytest.raises(lib.BwtError):                                 # n * read_len != total
         b.set_reads_packed(codes, exc, 4, read_len=99, total=400)
     with pytest.raises(lib.BwtError):                                 # ragged without offsets
