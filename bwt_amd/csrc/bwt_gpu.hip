@@ -4,6 +4,8 @@
 #include "etf_fm.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -893,7 +895,8 @@ struct MailGuard {
 // lookups, per-read totals) + k_search_pending (the LF steps the table left over) -- the per-read totals of the cluster
 // stage are then already in place (b->counts_done).  Else: k_subreads + k_search over every task, from n = 1.
 // raw: one task per "read", t_def already filled (bwt_find_seeds_batch).
-static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool lean = false) {
+// pre_zeroed: the caller's own kernel has already cleared r_K / r_pend / r_P (the small-batch path: a memset is a launch)
+static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool lean = false, bool pre_zeroed = false) {
     int rc;
     const uint64_t T = (uint64_t)n * maxT;
     b->counts_done = false; b->fused = false; b->rows_kept = true;
@@ -913,7 +916,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         const bool fuse = !raw && b->ix->d.ktw && maxT >= 8 && b->opt.seed_fuse != 0;
         if (fuse) {
             if ((rc = b->r_K.ensure((size_t)n * 4 + 4)) || (rc = b->r_cl.ensure((size_t)n * 8 * CL_STAGE + 16))) return rc;
-            HIPCHK(hipMemsetAsync(b->r_K.p, 0, (size_t)n * 4, b->stream));      // k_cluster_small only runs if reads are left for it
+            if (!pre_zeroed) HIPCHK(hipMemsetAsync(b->r_K.p, 0, (size_t)n * 4, b->stream));      // k_cluster_small only runs if reads are left for it
         }
         b->fused = fuse;
         b->rows_kept = !(fuse && lean);
@@ -953,8 +956,10 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
                     b->occ_seed_maxT = maxT | (big ? 0x100u : 0u) | (sum ? 0x200u : 0u);
                 }
                 const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)cus * per_cu));
-                HIPCHK(hipMemsetAsync(b->r_pend.p, 0, (size_t)n * 8, b->stream));
-                HIPCHK(hipMemsetAsync(b->r_P.p, 0, (size_t)n * 4, b->stream));
+                if (!pre_zeroed) {
+                    HIPCHK(hipMemsetAsync(b->r_pend.p, 0, (size_t)n * 8, b->stream));
+                    HIPCHK(hipMemsetAsync(b->r_P.p, 0, (size_t)n * 4, b->stream));
+                }
                 ProfScope ps(b, "fm_lookup");
                 {
 #define SF_LAUNCH(BIGV, SUMV) hipLaunchKernelGGL((k_seed_fast<BIGV, SUMV>), dim3(grid), dim3(256), lds, b->stream, b->ix->d, b->rplanes.as<uint32_t>(), n, maxT, b->ulen, \
@@ -971,8 +976,14 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
         else KLAUNCH(b, "fm_lookup", (k_seed_tasks<false, false>), resident(2, (const void *)k_seed_tasks<false, false>), 256, SEED_ARGS, (uint32_t *)nullptr, (uint32_t *)nullptr, b->ctr.as<Counters>(), 0, b->ulen, nolist, nocount);
         {
             ProfScope ps(b, "fm_search");
-            hipLaunchKernelGGL(k_search_pending, dim3(search_grid(b, T, false)), dim3(256), (size_t)4 * 64 * maxT * 2, b->stream, SEED_ARGS,
-                               b->ctr.as<Counters>());
+            // reads per wave chunk: 64 when the batch fills the resident grid with such chunks, fewer (a power of two) when it does
+            // not -- a wave works through its chunk's tasks 16 at a time, and a batch of a few hundred reads on four waves was
+            // 0.12 ms of dependent LF steps with the rest of the chip idle
+            const uint32_t sg = search_grid(b, 1ull << 28, false);                // (the resident grid: blocks, four waves each)
+            uint32_t rpc = 64;
+            while (rpc > 1 && (uint64_t)(rpc / 2) * sg * 4 >= n) rpc /= 2;
+            hipLaunchKernelGGL(k_search_pending, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(sg, cdiv(cdiv(n, rpc), 4)))), dim3(256), (size_t)4 * 64 * maxT * 2, b->stream, SEED_ARGS,
+                               b->ctr.as<Counters>(), rpc);
         }
 #undef SEED_ARGS
         b->counts_done = true;
@@ -1068,17 +1079,17 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         KLAUNCH(b, "cluster_wave2", k_cluster_wave<2>, cdiv((uint64_t)b->hctr.n_mid2 * 64, 256), 256, b->ix->d, b->hctr.n_mid2,
                 b->mid2q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
-                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>());
+                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
     if (b->hctr.n_mid4)
         KLAUNCH(b, "cluster_wave4", k_cluster_wave<4>, cdiv((uint64_t)b->hctr.n_mid4 * 64, 256), 256, b->ix->d, b->hctr.n_mid4,
                 b->mid4q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
-                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>());
+                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
     if (b->hctr.n_big)
         KLAUNCH(b, "cluster_big", k_cluster_big, b->hctr.n_big, 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                 b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
-                b->r_K.as<uint32_t>());
+                b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
     if (!all_clustered) {
         if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
         if ((rc = mail(b, &ncand, b->clus_off.as<uint64_t>() + n, 8))) return rc;
@@ -1202,7 +1213,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
 
     // a short DP queue (what a batch of clean reads leaves after the prefilter) goes to the wave-per-alignment kernel:
     // lane-per-alignment work would run a handful of waves for the full serial length of a DP
-    const uint32_t wv_dwords = (max_w >> 4) + 1, wv_w1 = max_w + 1;
+    const uint32_t wv_dwords = swv_dwords(max_w), wv_w1 = max_w + 1;
     const uint64_t wv_lds = ((uint64_t)wv_w1 + (uint64_t)max_lq * wv_dwords) * 4 * 4;            // 4 waves per block
     const uint32_t wv_thresh = (io.dq && wv_lds <= 60 * 1024 && b->opt.sw_wave != 0) ? 32768u : 0u;
     io.wave_upto = wv_thresh;
@@ -1253,7 +1264,8 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     if (wv_thresh) {
         ProfScope ps(b, "sw_wave");
         hipLaunchKernelGGL(k_sw_wave, dim3((uint32_t)std::min<uint64_t>(cdiv(std::min<uint64_t>(nc, wv_thresh), 4), (uint64_t)dev_cus * 4)),
-                           dim3(256), (size_t)wv_lds, b->stream, io, wv_thresh, wv_w1, wv_dwords, max_lq);
+                           dim3(256), (size_t)wv_lds, b->stream, io, wv_thresh, wv_w1, wv_dwords, max_lq, (const uint32_t *)nullptr,
+                           (const unsigned int *)nullptr, (uint32_t *)nullptr, (unsigned int *)nullptr);
     }
 
     // pass 1: bit-planes + 16-bit packed boundary row in LDS (k_sw_score); windows wider than the cap and
@@ -1461,6 +1473,7 @@ static int stage_extend(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, 
         HIPCHK(hipMemsetAsync(&dc->err_flags, 0, 8, b->stream));
         if ((rc = stage_hits(b, shift))) return rc;
         if (b->hctr.err_flags & 4) return fail(BWT_EHIP, "internal: candidate left pending by the extend stage");
+        if (b->hctr.err_flags & 16) return fail(BWT_EHIP, "internal: a DP slab was sized smaller than a candidate's window");
         if (!(b->hctr.err_flags & 2)) return 0;
         b->cig_stride *= 4;                                   // a CIGAR did not fit its slot: widen and redo
     }
@@ -1899,3 +1912,5 @@ extern "C" int bwt_sw_batch(int device, const uint8_t *q, const uint64_t *qoff, 
     }
     return 0;
 }
+
+#include "small_batch.hip.h"

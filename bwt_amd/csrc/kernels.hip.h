@@ -59,6 +59,33 @@ __device__ __forceinline__ void waveq_push(WaveQ &q, bool pred, uint32_t v, uint
 __device__ __forceinline__ void waveq_drain(WaveQ &q, uint32_t *__restrict__ gq, unsigned int *counter) {
     if (q.have) waveq_out(q, q.have, gq, counter);
 }
+// Work counters at the end of a kernel: a wave's (wave-uniform) sums go into block-shared accumulators and ONE thread of the
+// block adds them to the global counters.  Same-address global atomics run at ~88 per us on this part: a launch of a few hundred
+// short waves -- a batch of the reference's message size -- that ends with four atomics per wave spent more time on its counters
+// than on its work (k_seed_tasks 11 -> 23 us, k_search_pending 18 -> 58 us from 200 to 2000 reads).  Reached by EVERY thread of
+// the block, once per kernel.  sums[k] -> 64-bit counter g64[k] (or the 32-bit one g32[k] where g64[k] is null); maxes likewise.
+template <int NS, int NM>
+__device__ __forceinline__ void block_counters(const unsigned long long (&sums)[NS], unsigned long long *const (&g64)[NS],
+                                               unsigned int *const (&g32)[NS], const uint32_t (&maxes)[NM], unsigned int *const (&gmx)[NM]) {
+    __shared__ unsigned long long s_[NS];
+    __shared__ unsigned int m_[NM];
+    if (threadIdx.x < (uint32_t)NS) s_[threadIdx.x] = 0;
+    if (threadIdx.x < (uint32_t)NM) m_[threadIdx.x] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) if (sums[k]) atomicAdd(&s_[k], sums[k]);
+#pragma unroll
+        for (int k = 0; k < NM; k++) if (maxes[k]) atomicMax(&m_[k], maxes[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) if (s_[k]) { if (g64[k]) atomicAdd(g64[k], s_[k]); else atomicAdd(g32[k], (unsigned int)s_[k]); }
+#pragma unroll
+        for (int k = 0; k < NM; k++) if (m_[k]) atomicMax(gmx[k], m_[k]);
+    }
+}
 __device__ __forceinline__ bool is_acgt(uint32_t c) {
     uint32_t i = c - 'A';   // A=0 C=2 G=6 T=19
     return i < 20u && ((0x80045u >> i) & 1u);
@@ -1058,15 +1085,14 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         }
     }
     readq_drain(rq, bigq, mid2q, mid4q, ctr);
-    dmax = wave_max_u32(dmax);
-    if (lane == 0 && dmax) atomicMax(&ctr->max_D, dmax);
     if (__ballot(had_pend != 0) && lane == 0) ctr->n_pend = 1u;        // (a plain store: every writer writes the same)
-    unsigned long long l = wave_sum_u64(live), k = wave_sum_u64(looked), s = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
-    if (lane == 0 && (l | k | s | ns)) {
-        atomicAdd(&ctr->n_tasks, l);
-        atomicAdd(&ctr->kt_lookups, k);
-        atomicAdd(&ctr->sa_reads, s);
-        if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns);
+    {
+        const unsigned long long sums[4] = {wave_sum_u64(live), wave_sum_u64(looked), wave_sum_u64(Psum), wave_sum_u64(nsmall)};
+        unsigned long long *const g64[4] = {&ctr->n_tasks, &ctr->kt_lookups, &ctr->sa_reads, nullptr};
+        unsigned int *const g32[4] = {nullptr, nullptr, nullptr, &ctr->n_small};
+        const uint32_t mx[1] = {wave_max_u32(dmax)};
+        unsigned int *const gmx[1] = {&ctr->max_D};
+        block_counters(sums, g64, g32, mx, gmx);
     }
 }
 
@@ -1471,17 +1497,17 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         atomicAdd(&ctr->why[0], why & 255u); atomicAdd(&ctr->why[1], (why >> 8) & 255u); atomicAdd(&ctr->why[2], (why >> 16) & 255u);
         atomicAdd(&ctr->why[3], why >> 24); atomicAdd(&ctr->why[4], why2 & 0xffffu); atomicAdd(&ctr->why[5], why2 >> 16);
     }
-    dmaxl = wave_max_u32(dmaxl);
-    if (lane == 0 && dmaxl) atomicMax(&ctr->max_D, dmaxl);
-    const unsigned long long Psum = wave_sum_u64(Pacc);
-    if (lane == 0 && (live | Psum)) {
-        atomicAdd(&ctr->n_tasks, (unsigned long long)live);
-        atomicAdd(&ctr->kt_lookups, (unsigned long long)live);
-        atomicAdd(&ctr->sa_reads, Psum);
+    {
+        const unsigned long long sums[3] = {(unsigned long long)live, (unsigned long long)live, wave_sum_u64(Pacc)};
+        unsigned long long *const g64[3] = {&ctr->n_tasks, &ctr->kt_lookups, &ctr->sa_reads};
+        unsigned int *const g32[3] = {nullptr, nullptr, nullptr};
+        const uint32_t mx[1] = {wave_max_u32(dmaxl)};
+        unsigned int *const gmx[1] = {&ctr->max_D};
+        block_counters(sums, g64, g32, mx, gmx);
     }
 }
 
-// k_search_pending: the LF steps the table left over.  A wave scans 64 reads' r_pend words at a time and lists their
+// k_search_pending: the LF steps the table left over.  A wave scans rpc (64 for large batches) reads' r_pend words at a time and lists their
 // pending tasks in LDS ((read of the chunk) << 6 | slot); its 16 quads take the tasks 16 at a time -- QUAD PER TASK, from
 // the (Sp, Ep, n) k_seed_tasks stored, two 16-byte-per-lane block loads per step as in k_search -- and add what each
 // task found to its read's LDS accumulators; then one lane per read totals the read.  No global queue, no global atomics.
@@ -1493,7 +1519,8 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
                                                          const unsigned long long *__restrict__ r_pend,
                                                          uint32_t *__restrict__ r_P, uint32_t *__restrict__ r_qty,
                                                          uint32_t *__restrict__ bigq, uint32_t *__restrict__ mid2q,
-                                                         uint32_t *__restrict__ mid4q, Counters *ctr) {
+                                                         uint32_t *__restrict__ mid4q, Counters *ctr, uint32_t rpc) {
+    // rpc: reads per wave chunk (a power of two, 1..64): lanes 0 .. rpc-1 carry a read each
     if (ctr->n_pend == 0) return;                                 // no seed-kernel pass left a task behind: no need to look through r_pend
     extern __shared__ uint16_t pend_list_[];                      // 4 waves x 64 reads x maxT pending tasks (dynamic)
     __shared__ unsigned long long accP_[4][64];
@@ -1512,9 +1539,9 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t steps = 0, nsmall = 0;
     unsigned long long Psum = 0;
-    for (uint32_t chunk = wave; (uint64_t)chunk * 64 < n; chunk += nwaves) {
-        const uint32_t rl = chunk * 64 + lane;
-        const unsigned long long mine = rl < n ? r_pend[rl] : 0ull;
+    for (uint32_t chunk = wave; (uint64_t)chunk * rpc < n; chunk += nwaves) {
+        const uint32_t rl = chunk * rpc + lane;
+        const unsigned long long mine = (lane < rpc && rl < n) ? r_pend[rl] : 0ull;
         if (!__ballot(mine != 0)) continue;
         // task list: lane l's tasks at [excl_l, excl_l + popc(mine_l))
         uint32_t cntl = (uint32_t)__popcll(mine), incl = cntl;
@@ -1531,7 +1558,7 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
             const bool work = b0 + qi < total;
             const uint32_t ent = work ? list[b0 + qi] : 0u;
             const uint32_t rloc = ent >> 6, k = ent & 63u;
-            const uint32_t r = chunk * 64 + rloc;
+            const uint32_t r = chunk * rpc + rloc;
             LfTask t;
             t.task = (uint64_t)r * maxT + k; t.sp = 0; t.ep = 0; t.lo16 = 0; t.hi16 = 0; t.status = TS_NONE; t.n = 0; t.nlim = 0;
             t.check_at_limit = true; t.check = true; t.active = false;
@@ -1585,11 +1612,13 @@ __global__ __launch_bounds__(256) void k_search_pending(DevIndex ix, const uint3
         __builtin_amdgcn_wave_barrier();
     }
     readq_drain(rq, bigq, mid2q, mid4q, ctr);
-    unsigned long long s = wave_sum_u64(ql == 0 ? steps : 0), ps = wave_sum_u64(Psum), ns = wave_sum_u64(nsmall);
-    if (lane == 0 && (s | ps | ns)) {
-        atomicAdd(&ctr->lf_steps, s);
-        atomicAdd(&ctr->sa_reads, ps);
-        if (ns) atomicAdd(&ctr->n_small, (unsigned int)ns);
+    {
+        const unsigned long long sums[3] = {wave_sum_u64(ql == 0 ? steps : 0), wave_sum_u64(Psum), wave_sum_u64(nsmall)};
+        unsigned long long *const g64[3] = {&ctr->lf_steps, &ctr->sa_reads, nullptr};
+        unsigned int *const g32[3] = {nullptr, nullptr, &ctr->n_small};
+        const uint32_t mx[1] = {0u};
+        unsigned int *const gmx[1] = {&ctr->max_D};
+        block_counters(sums, g64, g32, mx, gmx);
     }
 }
 
@@ -1756,25 +1785,19 @@ __global__ __launch_bounds__(256) void k_cluster_small(DevIndex ix, uint32_t n, 
 // here).  Same algorithm as k_cluster_small with R elements per lane, element e = r*64 + lane: bitonic
 // strides >= 64 are register-to-register exchanges, smaller strides are lane shuffles; run starts and
 // emitters carry across the R chunks as wave-uniform scalars.
+// (the read's work as a device function: k_cluster_wave runs it on a queue entry, k_cluster_rest -- the small-batch path -- on all
+// three queues of reads with more than 64 seeds in one launch; mk = 2 * 64 R words of wave-private LDS)
 template <int R>
-__global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, const uint32_t *__restrict__ queue,
-                                                       uint32_t maxT, const uint32_t *__restrict__ t_def,
-                                                       const uint32_t *__restrict__ t_sp,
-                                                       const uint32_t *__restrict__ t_info,
-                                                       const uint32_t *__restrict__ t_cnt,
-                                                       const uint32_t *__restrict__ r_P,
-                                                       const uint32_t *__restrict__ r_qty,
-                                                       const uint64_t *__restrict__ seed_off,
-                                                       uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+__device__ __forceinline__ void cluster_wave_read(const DevIndex &ix, uint32_t r, uint32_t maxT, const uint32_t *__restrict__ t_def,
+                                                  const uint32_t *__restrict__ t_sp, const uint32_t *__restrict__ t_info,
+                                                  const uint32_t *__restrict__ t_cnt, const uint32_t *__restrict__ r_P,
+                                                  const uint32_t *__restrict__ r_qty, const uint64_t *__restrict__ seed_off,
+                                                  uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K, uint32_t *mk) {
     constexpr int N = 64 * R;
-    __shared__ uint32_t lds[4][2 * N];
-    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    if (w >= nq) return;
-    const uint32_t r = queue[w];
     const uint32_t P = r_P[r];
     const uint32_t qty = r_qty[r] & 0x7fffffffu;
-    uint32_t *mk = lds[threadIdx.x >> 6], *srt = mk + N;
+    uint32_t *srt = mk + N;
     uint32_t cnt = 0, sp = 0, nadd = 0;
     if (lane < maxT) {
         const uint64_t t = (uint64_t)r * maxT + lane;
@@ -1878,21 +1901,35 @@ __global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, 
     }
     if (lane == 0) r_K[r] = above;
 }
+template <int R>
+__global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, const uint32_t *__restrict__ queue,
+                                                       uint32_t maxT, const uint32_t *__restrict__ t_def,
+                                                       const uint32_t *__restrict__ t_sp,
+                                                       const uint32_t *__restrict__ t_info,
+                                                       const uint32_t *__restrict__ t_cnt,
+                                                       const uint32_t *__restrict__ r_P,
+                                                       const uint32_t *__restrict__ r_qty,
+                                                       const uint64_t *__restrict__ seed_off,
+                                                       uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
+                                                       const unsigned int *__restrict__ nq_dev) {
+    // nq_dev != null: the queue length is read on the device (nq = the most the queue can hold)
+    __shared__ uint32_t lds[4][2 * 64 * R];
+    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (nq_dev) nq = *nq_dev;
+    if (w >= nq) return;
+    cluster_wave_read<R>(ix, queue[w], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds[threadIdx.x >> 6]);
+}
 
 // k_cluster_big: workgroup per read (P > 64): gather into the read's slice of `pos`, sort it
 // (ascending-only bitonic network: virtual +inf padding past P), cluster sequentially.
 #define BIG_LDS 4096
-__global__ __launch_bounds__(256) void k_cluster_big(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ bigq,
-                                                      const uint32_t *__restrict__ t_def,
-                                                      const uint32_t *__restrict__ t_sp,
-                                                      const uint32_t *__restrict__ t_info,
-                                                      const uint32_t *__restrict__ t_cnt,
-                                                      const uint32_t *__restrict__ r_P,
-                                                      const uint32_t *__restrict__ r_qty,
-                                                      const uint64_t *__restrict__ seed_off,
-                                                      uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
-    __shared__ uint32_t sh[BIG_LDS];
-    const uint32_t r = bigq[blockIdx.x];
+// (one read, by a whole block; sh = BIG_LDS words of block-shared LDS.  Every thread of the block calls it.)
+__device__ __forceinline__ void cluster_big_read(const DevIndex &ix, uint32_t r, uint32_t maxT, const uint32_t *__restrict__ t_def,
+                                                 const uint32_t *__restrict__ t_sp, const uint32_t *__restrict__ t_info,
+                                                 const uint32_t *__restrict__ t_cnt, const uint32_t *__restrict__ r_P,
+                                                 const uint32_t *__restrict__ r_qty, const uint64_t *__restrict__ seed_off,
+                                                 uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K, uint32_t *sh) {
+    __syncthreads();                                      // (sh is reused from one read to the next)
     const uint32_t P = r_P[r];
     uint32_t *reg = pos + seed_off[r];
     uint32_t o = 0;
@@ -1944,6 +1981,44 @@ __global__ __launch_bounds__(256) void k_cluster_big(DevIndex ix, uint32_t maxT,
         }
         r_K[r] = K;
     }
+}
+__global__ __launch_bounds__(256) void k_cluster_big(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ bigq,
+                                                      const uint32_t *__restrict__ t_def,
+                                                      const uint32_t *__restrict__ t_sp,
+                                                      const uint32_t *__restrict__ t_info,
+                                                      const uint32_t *__restrict__ t_cnt,
+                                                      const uint32_t *__restrict__ r_P,
+                                                      const uint32_t *__restrict__ r_qty,
+                                                      const uint64_t *__restrict__ seed_off,
+                                                      uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
+                                                      const unsigned int *__restrict__ nq_dev) {
+    __shared__ uint32_t sh[BIG_LDS];
+    // nq_dev != null: grid-stride over a queue whose length is read on the device
+    for (uint32_t bi = blockIdx.x; bi < (nq_dev ? *nq_dev : gridDim.x); bi += gridDim.x)
+        cluster_big_read(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, sh);
+}
+// the three queues of reads with more than 64 seeds in ONE launch (the small-batch path: queue lengths read on the device, a
+// launch saved twice): waves take the entries of the 65..128 and 129..256 queues, then blocks those of the workgroup-per-read one
+__global__ __launch_bounds__(256) void k_cluster_rest(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ mid2q, const uint32_t *__restrict__ mid4q,
+                                                       const uint32_t *__restrict__ bigq, const Counters *__restrict__ ctr,
+                                                       const uint32_t *__restrict__ t_def, const uint32_t *__restrict__ t_sp,
+                                                       const uint32_t *__restrict__ t_info, const uint32_t *__restrict__ t_cnt,
+                                                       const uint32_t *__restrict__ r_P, const uint32_t *__restrict__ r_qty,
+                                                       const uint64_t *__restrict__ seed_off, uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+    __shared__ uint32_t lds[BIG_LDS];                      // 4 waves x 2 x 256 words for the wave kernels = 2048; BIG_LDS for the block one
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n2 = ctr->n_mid2, n4 = ctr->n_mid4, nb = ctr->n_big;
+    uint32_t *mine = lds + (threadIdx.x >> 6) * 512;
+    for (uint32_t w = wave; w < n2; w += nwaves) {
+        cluster_wave_read<2>(ix, mid2q[w], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, mine);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (uint32_t w = wave; w < n4; w += nwaves) {
+        cluster_wave_read<4>(ix, mid4q[w], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, mine);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (uint32_t bi = blockIdx.x; bi < nb; bi += gridDim.x)
+        cluster_big_read(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2061,17 +2136,22 @@ __device__ __forceinline__ void cig_emit(uint8_t *slot, int &p, int &len, uint32
     len++; if (--p >= 0) slot[p] = (uint8_t)op;
     do { len++; if (--p >= 0) slot[p] = (uint8_t)('0' + n % 10); n /= 10; } while (n);
 }
+// ... by every lane of a wave that walks a traceback together (same p / len in all of them), the bytes by the lane `wr` picks
+__device__ __forceinline__ void cig_emit_if(bool wr, uint8_t *slot, int &p, int &len, uint32_t n, char op) {
+    len++; if (--p >= 0 && wr) slot[p] = (uint8_t)op;
+    do { len++; if (--p >= 0 && wr) slot[p] = (uint8_t)('0' + n % 10); n /= 10; } while (n);
+}
 
+// (the kernel's work as a device function of (wave, nwaves): k_sw is the plain launch, k_sw_tail -- the small-batch path -- runs the
+// traced and the fp64 instance side by side in one launch)
 template <int MODE, bool LDSB>
-__global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t maxW1, uint32_t max_strips,
-                                            uint32_t *__restrict__ slab_bnd, double *__restrict__ slab_bndv,
-                                            uint32_t *__restrict__ slab_dir) {
+__device__ __forceinline__ void sw_lanes(const SwIO &io, uint32_t n_items, uint32_t maxW1, uint32_t max_strips,
+                                         uint32_t *__restrict__ slab_bnd, double *__restrict__ slab_bndv,
+                                         uint32_t *__restrict__ slab_dir, const uint32_t wave, const uint32_t nwaves) {
     constexpr bool FP = MODE == SW_FP;
     constexpr bool DIRS = MODE != SW_SCORE;
     extern __shared__ uint16_t lds_bnd[];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     uint16_t *bl = LDSB ? lds_bnd + (uint64_t)(threadIdx.x >> 6) * maxW1 * 64 + lane : nullptr;   // [j*64]
     uint32_t *bnd = LDSB ? nullptr : slab_bnd + (uint64_t)wave * maxW1 * 64 + lane;                // [j*64]
     double *bndv = FP ? slab_bndv + (uint64_t)wave * maxW1 * 64 + lane : nullptr;
@@ -2087,6 +2167,13 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
         const int64_t wo = io.c_woff[c];
         if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
             io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0;
+            continue;
+        }
+        if (w + 1 > maxW1 || (lq + SW_R - 1) / SW_R > max_strips) {
+            // wider than the slabs were sized for: never in a run sized by the batch's own maxima; the small-batch path sizes by
+            // fixed capacities and redoes such a batch through the general path (err_flags bit 16)
+            io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0;
+            atomicOr(&io.ctr->err_flags, 16ull);
             continue;
         }
         const uint8_t *q = io.qbuf + io.c_qoff[c];
@@ -2246,6 +2333,21 @@ __global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t 
         io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
     }
 }
+template <int MODE, bool LDSB>
+__global__ __launch_bounds__(256) void k_sw(SwIO io, uint32_t n_items, uint32_t maxW1, uint32_t max_strips,
+                                            uint32_t *__restrict__ slab_bnd, double *__restrict__ slab_bndv,
+                                            uint32_t *__restrict__ slab_dir) {
+    sw_lanes<MODE, LDSB>(io, n_items, maxW1, max_strips, slab_bnd, slab_bndv, slab_dir,
+                         (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), (gridDim.x * blockDim.x) >> 6);
+}
+// blockIdx.y = 0: the traced integer instance on the trace queue (io.tq_in when set), 1: the fp64 instance on the fp queue
+__global__ __launch_bounds__(256) void k_sw_tail(SwIO io, uint32_t n_items, uint32_t maxW1, uint32_t max_strips,
+                                                 uint32_t *__restrict__ bnd_t, uint32_t *__restrict__ dir_t,
+                                                 uint32_t *__restrict__ bnd_fp, double *__restrict__ bndv_fp, uint32_t *__restrict__ dir_fp) {
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (blockIdx.y == 0) sw_lanes<SW_TRACE, false>(io, n_items, maxW1, max_strips, bnd_t, nullptr, dir_t, wave, nwaves);
+    else sw_lanes<SW_FP, false>(io, n_items, maxW1, max_strips, bnd_fp, bndv_fp, dir_fp, wave, nwaves);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_sw_prefilter: QUAD per candidate, on the bit-planes of reads and Ref1 only.
@@ -2311,6 +2413,7 @@ struct CandSrc {
     uint32_t *ovq; unsigned int *ov_count;
     const uint32_t *list; const unsigned int *list_count;
     uint32_t ulen;                               // > 0: every read has this length (no offset loads)
+    uint32_t kcap;                               // FROM_READS: candidates of a read the fused pass tests itself (0 = PF_KCAP; the small-batch path: all)
 };
 // A wave of the fused pass takes 16 reads and loops to the LARGEST cluster count among them: on a repeat-rich genome one read in
 // twelve has a dozen or more clusters, three waves in four hold such a read, and the other fifteen quads idle through its loop
@@ -2380,9 +2483,10 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
                 maxlq = lq_r > maxlq ? lq_r : maxlq;
             }
         }
-        if (FROM_READS && kmax > PF_KCAP) {
+        const uint32_t kcap = src.kcap ? src.kcap : PF_KCAP;
+        if (FROM_READS && kmax > kcap) {
             // the candidates past the first PF_KCAP of every read of this pass: descriptors and list entries, four per quad step
-            for (uint32_t kb = PF_KCAP; kb < kmax; kb += 4) {
+            for (uint32_t kb = kcap; kb < kmax; kb += 4) {
                 const uint32_t kc = kb + (uint32_t)ql;
                 const bool have = kc < K_r;
                 const uint32_t c = (uint32_t)(co_r + kc);
@@ -2395,8 +2499,8 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
                 }
                 waveq_push(qov, have, c, src.ovq, src.ov_count);
             }
-            kmax = PF_KCAP;
-            K_r = K_r < PF_KCAP ? K_r : PF_KCAP;
+            kmax = kcap;
+            K_r = K_r < kcap ? K_r : kcap;
         }
         for (uint32_t kc = 0; kc < kmax; kc++) {                              // (one pass unless FROM_READS)
             const uint32_t c = FROM_READS ? (uint32_t)(co_r + kc) : src.list ? (item < n_items ? src.list[item] : 0u) : item;
@@ -2535,12 +2639,12 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
     waveq_drain(qdp, io.dq, &io.ctr->dq_count);
     if (FROM_READS) {
         waveq_drain(qov, src.ovq, src.ov_count);
-        cells = wave_sum_u64(cells); wbytes = wave_sum_u64(wbytes);
-        maxw = wave_max_u32(maxw); maxlq = wave_max_u32(maxlq);
-        if ((threadIdx.x & 63) == 0 && maxlq) {
-            atomicAdd(&io.ctr->sw_cells, cells); atomicAdd(&io.ctr->window_bytes, wbytes);
-            atomicMax(&io.ctr->max_w, maxw); atomicMax(&io.ctr->max_lq, maxlq);
-        }
+        const unsigned long long sums[2] = {wave_sum_u64(cells), wave_sum_u64(wbytes)};
+        unsigned long long *const g64[2] = {&io.ctr->sw_cells, &io.ctr->window_bytes};
+        unsigned int *const g32[2] = {nullptr, nullptr};
+        const uint32_t mx[2] = {wave_max_u32(maxw), wave_max_u32(maxlq)};
+        unsigned int *const gmx[2] = {&io.ctr->max_w, &io.ctr->max_lq};
+        block_counters(sums, g64, g32, mx, gmx);
     }
 }
 
@@ -3237,30 +3341,39 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
 // k_sw_wave: a WAVE per alignment, for DP queues too short to fill the chip with lane-per-alignment work (after the
 // prefilter a batch of clean reads leaves a few hundred candidates: the packed kernels then run a handful of waves for
 // the full serial length of a DP, ~0.5 ms).  Same cells as k_sw (packed 4V + code, ties up_left > up > left, gap cost by
-// the neighbour's stored direction), evaluated along anti-diagonals: lane t owns query row i0 + t of a 64-row strip and
-// at step k the cell of column k - t; the value of the row above and the window base arrive from lane t - 1, the
-// boundary row between strips and the 2-bit directions (16 columns per word) live in LDS.  Traceback by lane 0.
+// the neighbour's stored direction), evaluated along anti-diagonals: lane t owns query rows i0 + 2t and i0 + 2t + 1 of a 128-row
+// strip and at step k their cells of column k - t; the value of the row above and the window base arrive from lane t - 1, the
+// boundary row between strips and the 2-bit directions (16 steps per word) live in LDS.  Traceback by lane 0.
 // Runs only when the DP queue holds at most `thresh` candidates (k_sw_pk takes the longer queues); the queue holds clean
 // ACGT candidates only (k_sw_prefilter filled it).
-__global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint32_t maxW1, uint32_t dwords, uint32_t max_lq) {
+// words of 2-bit directions a query row keeps in k_sw_wave (16 steps per word; a row's cells are filed by STEP, see the kernel)
+__host__ __device__ __forceinline__ uint32_t swv_dwords(uint32_t max_w) { return ((max_w + 63u) >> 4) + 1u; }
+// q_in / q_count: the queue when it is not the DP queue (null: io.dq, ctr->dq_count); q_over / q_over_count: where candidates wider
+// than this launch's LDS go (null: io.tq, ctr->tq_count) -- the small-batch path runs the kernel twice, tight LDS first, then with
+// all the LDS a block can have on what that pass found too wide, before anything is left to the lane-per-alignment kernel
+__global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint32_t maxW1, uint32_t dwords, uint32_t max_lq,
+                                                  const uint32_t *__restrict__ q_in, const unsigned int *__restrict__ q_count,
+                                                  uint32_t *__restrict__ q_over, unsigned int *__restrict__ q_over_count) {
     extern __shared__ uint32_t lds_wv[];
-    const uint32_t n_total = io.ctr->dq_count;
+    const uint32_t n_total = q_in ? *q_count : io.ctr->dq_count;
+    if (!q_in) q_in = io.dq;
+    if (!q_over) { q_over = io.tq; q_over_count = &io.ctr->tq_count; }
     if (n_total == 0 || n_total > thresh) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t *bl = lds_wv + (size_t)(threadIdx.x >> 6) * (maxW1 + (size_t)max_lq * dwords);    // boundary row [j]
-    uint32_t *dirs = bl + maxW1;                                                                  // [row][j >> 4]
+    uint32_t *dirs = bl + maxW1;                                                                  // [row][step >> 4]
     for (uint32_t item = wave; item < n_total; item += nwaves) {
-        const uint32_t c = io.dq[item];
+        const uint32_t c = q_in[item];
         const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
         const int64_t wo = io.c_woff[c];
         if (wo < 0 || (uint64_t)wo + w > io.rbuf_len || w == 0 || lq == 0) {
             if (lane == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
             continue;
         }
-        if (w + 1 > maxW1 || lq > max_lq) {                      // (sized by the batch maxima: not expected) -> generic trace kernel
-            if (lane == 0) { io.c_status[c] = CS_PENDING; io.tq[atomicAdd(&io.ctr->tq_count, 1u)] = c; }
+        if (w + 1 > maxW1 || lq > max_lq) {                      // wider than this launch's LDS was sized for -> the next kernel's queue
+            if (lane == 0) { io.c_status[c] = CS_PENDING; q_over[atomicAdd(q_over_count, 1u)] = c; }
             continue;
         }
         const uint8_t *q = io.qbuf + io.c_qoff[c];
@@ -3269,75 +3382,122 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
         __builtin_amdgcn_wave_barrier();
         int best = -(int)(lq + 1) * 4 + DIR_UP;                               // V(Lq, 0)
         uint32_t bestj = 0;
-        const uint32_t ns = (lq + 63) / 64;
+        // Strips of 128 query rows, TWO ROWS PER LANE (lane t: rows i0 + 2t and i0 + 2t + 1), swept along anti-diagonals of lane
+        // pairs: at step k lane t fills column k - t of its upper row and then of its lower one -- the lower cell's `up` is the
+        // cell just made, its diagonal the upper row's previous cell, both in registers.  A 100-base read is ONE strip of
+        // W + 49 steps (two strips of 64 rows: 2 W + 98), and the per-step overhead -- the hand-down of the lane above's value
+        // and base, the next window base and boundary value for lane 0, the loop -- is paid once per two cells.
+        // Per step a lane needs two values of the lane above it -- that lane's lower cell of the step before (the row above at my
+        // column) and the window base it worked on -- and lane 0 needs the next window base and the next value of the boundary
+        // row.  All of it stays in registers: window bases and boundary values are fetched 64 at a time, one per lane, and
+        // handed to lane 0 by v_readlane; the shift down the wave is a DPP move (wave_shr:1, lane 0 keeps the `old` operand).
+        // The step itself is branch-free: a lane outside its rows' columns computes cells nobody keeps.  A row's 2-bit
+        // directions are filed by STEP (word k >> 4, bits 2 (k & 15); column j of lane t at step j + t), so that every
+        // lane stores its words at the same steps -- a scalar branch, not a per-lane one.
+        const uint32_t ns = (lq + 127) / 128;
         for (uint32_t s = 0; s < ns; s++) {
-            const uint32_t i0 = s * 64, i = i0 + lane;                         // 0-based query row of this lane
-            const bool rowok = i < lq;
-            const uint32_t qc = rowok ? q[i] : 0xffu;
-            int h = -(int)(i + 2) * 4 + DIR_UP;                                // column 0 of my row
-            // value of the row above at the column before mine (the diagonal input): column 0 of that row
-            int d = lane == 0 ? (s == 0 ? (int)DIR_UNDEF : -(int)(i0 + 1) * 4 + DIR_UP) : -(int)(i + 1) * 4 + DIR_UP;
-            uint32_t rc = 0, dirw = 0;
-            uint32_t wch = lane < w ? rw[lane] : 0u;                            // window bases 64 at a time, one per lane
-            for (uint32_t k = 1; k <= w + 63; k++) {
-                // lane 0 takes the next window base, the others inherit the base and the value of the lane above
-                const uint32_t kb = k - 1;
-                if (kb && (kb & 63u) == 0) wch = kb + lane < w ? rw[kb + lane] : 0u;
-                const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)wch, (int)(kb & 63u));
-                const uint32_t rc_up = (uint32_t)__shfl_up((int)rc, 1, 64);
-                int u = __shfl_up(h, 1, 64);
-                rc = lane == 0 ? nb : rc_up;
-                const uint32_t j = k - lane;                                    // my column at this step
-                if (lane == 0) u = (int)bl[k <= w ? k : 0];
-                const bool on = rowok && j >= 1 && j <= w;
-                if (on) {
-                    const int sig = (qc == rc) ? 7 : -5;                        // 4*sigma - 1
-                    const int cd = (d | 3) + sig;                               // 4(Vul+sigma) + up_left
-                    const int cl = h + (int)(int8_t)(0xF5F6F7FCu >> ((h & 3) * 8));     // {-4,-9,-10,-11}
-                    const int cu = u + (int)(int8_t)(0xF6F7FCF9u >> ((u & 3) * 8));     // {-7,-4,-9,-10}
-                    int hn = cd > cl ? cd : cl;
-                    hn = hn > cu ? hn : cu;
-                    dirw |= (uint32_t)(hn & 3) << (2 * (j & 15u));
-                    if ((j & 15u) == 15u || j == w) { dirs[(size_t)i * dwords + (j >> 4)] = dirw; dirw = 0; }
-                    h = hn;
-                    if (lane == 63) bl[j] = (uint32_t)hn;                       // boundary row for the next strip
-                    if (i == lq - 1 && (hn >> 2) > (best >> 2)) { best = hn; bestj = j; }   // leftmost maximum of the last row
+            const uint32_t i0 = s * 128, ia = i0 + 2 * lane, ib = ia + 1;       // 0-based query rows of this lane
+            const bool oka = ia < lq, okb = ib < lq;
+            const uint32_t qa = oka ? q[ia] : 0xffu, qb = okb ? q[ib] : 0xfeu;
+            int ha = -(int)(ia + 2) * 4 + DIR_UP, hb = -(int)(ib + 2) * 4 + DIR_UP;   // column 0 of my rows
+            // value of the row above my upper row at the column before mine (its diagonal input): column 0 of that row
+            int da = lane == 0 ? (s == 0 ? (int)DIR_UNDEF : -(int)(i0 + 1) * 4 + DIR_UP) : -(int)(ia + 1) * 4 + DIR_UP;
+            uint32_t rc = 0, dwa = 0, dwb = 0;
+            const uint32_t nrow = lq - i0 < 128u ? lq - i0 : 128u;              // rows of this strip
+            const uint32_t nlane = (nrow + 1) >> 1;                             // lanes that carry one
+            const uint32_t ksteps = w + nlane - 1;                              // its last lane reaches column w at this step
+            const bool has_next = s + 1 < ns, last_strip = !has_next;
+            const uint32_t wla = oka ? w : 0u, wlb = okb ? w : 0u;              // j - 1 < wl  <=>  the row exists and 1 <= j <= w
+            const bool last_is_b = ((lq - 1 - i0) & 1u) != 0;                   // (wave-uniform; only looked at in the last strip)
+            const bool lastlane = lane == ((lq - 1 - i0) >> 1);
+            uint32_t *drow_a = dirs + (size_t)(oka ? ia : 0u) * dwords, *drow_b = dirs + (size_t)(okb ? ib : 0u) * dwords;
+            // (steps in chunks of 64: the chunk's window bases and boundary values are loaded -- and waited for -- once, in front of
+            // an inner loop that reads nothing from memory)
+            for (uint32_t kb0 = 0; kb0 < ksteps; kb0 += 64) {
+                const uint32_t wch = kb0 + lane < w ? rw[kb0 + lane] : 0u;          // window bases of columns kb0 + 1.., one per lane
+                const int bch = (int)bl[kb0 + 1 + lane <= w ? kb0 + 1 + lane : 0];  // boundary row (the strip above) at those columns
+                const uint32_t kend = kb0 + 64 < ksteps ? kb0 + 64 : ksteps;
+                for (uint32_t k = kb0 + 1; k <= kend; k++) {
+                    const int sel = (int)(k - 1 - kb0);
+                    const int nb = __builtin_amdgcn_readlane((int)wch, sel);
+                    const int ub = __builtin_amdgcn_readlane(bch, sel);
+                    const int ua = __builtin_amdgcn_update_dpp(ub, hb, 0x138, 0xF, 0xF, false);          // wave_shr:1; lane 0: the boundary row
+                    rc = (uint32_t)__builtin_amdgcn_update_dpp(nb, (int)rc, 0x138, 0xF, 0xF, false);     // ... lane 0: the next window base
+                    const uint32_t j = k - lane;                                // my column at this step
+                    const bool ona = j - 1u < wla, onb = j - 1u < wlb;
+                    // upper row: diagonal da (row above, column j - 1), left ha, up ua
+                    const int cda = (da | 3) + ((qa == rc) ? 7 : -5);           // 4(Vul + sigma) + up_left
+                    const int cla = ha + __builtin_amdgcn_sbfe((int)0xF5F6F7FCu, (uint32_t)(ha & 3) * 8u, 8u);   // {-4,-9,-10,-11}
+                    const int cua = ua + __builtin_amdgcn_sbfe((int)0xF6F7FCF9u, (uint32_t)(ua & 3) * 8u, 8u);   // {-7,-4,-9,-10}
+                    int hna = cda > cla ? cda : cla;
+                    hna = hna > cua ? hna : cua;
+                    // lower row: diagonal = the upper row's cell of column j - 1 (ha as it still is), left hb, up = the cell just made
+                    const int cdb = (ha | 3) + ((qb == rc) ? 7 : -5);
+                    const int clb = hb + __builtin_amdgcn_sbfe((int)0xF5F6F7FCu, (uint32_t)(hb & 3) * 8u, 8u);
+                    const int cub = hna + __builtin_amdgcn_sbfe((int)0xF6F7FCF9u, (uint32_t)(hna & 3) * 8u, 8u);
+                    int hnb = cdb > clb ? cdb : clb;
+                    hnb = hnb > cub ? hnb : cub;
+                    const uint32_t sh2 = 2u * (k & 15u);
+                    dwa |= ona ? (uint32_t)(hna & 3) << sh2 : 0u;
+                    dwb |= onb ? (uint32_t)(hnb & 3) << sh2 : 0u;
+                    ha = ona ? hna : ha;
+                    hb = onb ? hnb : hb;
+                    if (has_next) { if (lane == 63 && onb) bl[j] = (uint32_t)hnb; }   // boundary row for the next strip (its 128th row)
+                    if (last_strip) {                                           // leftmost maximum of the last row
+                        const int hl = last_is_b ? hnb : hna;
+                        const bool take = (last_is_b ? onb : ona) && lastlane && (hl >> 2) > (best >> 2);
+                        best = take ? hl : best; bestj = take ? j : bestj;
+                    }
+                    if ((k & 15u) == 15u || k == ksteps) {
+                        if (oka) drow_a[k >> 4] = dwa;
+                        if (okb) drow_b[k >> 4] = dwb;
+                        dwa = 0; dwb = 0;
+                    }
+                    da = ua;                                                    // the row above at my column: next step's diagonal
                 }
-                d = u;                                                          // the row above at my column: next step's diagonal
             }
             __builtin_amdgcn_wave_barrier();
         }
-        const int ll = (int)((lq - 1) & 63u);                                   // lane that owns the last row
+        const int ll = (int)(((lq - 1) & 127u) >> 1);                           // lane that owns the last row
         best = __builtin_amdgcn_readlane(best, ll);
         bestj = (uint32_t)__builtin_amdgcn_readlane((int)bestj, ll);
-        if (lane == 0) {
+        {
             // sw.erl:69 after the last row: no_match iff RowMax < -2*(Lq div 2) + 2*Lq
             const int thr = -2 * (int)(lq / 2) + 2 * (int)lq;
             const int score = best >> 2;
-            if (score < thr) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; }
+            if (score < thr) { if (lane == 0) { io.c_status[c] = CS_NO_MATCH; io.c_ciglen[c] = 0; } }
             else {
                 uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
                 int p = (int)io.cig_stride, len = 0;
-                // traceback (sw.erl:116-160): from the leftmost maximum of the last row up to row 0
+                // traceback (sw.erl:116-160): from the leftmost maximum of the last row up to row 0.  By the whole wave: lane l looks
+                // at the cell l steps up the diagonal from (ti, tj), a ballot says how far the run of up_left reaches, and the walk
+                // jumps it in one go -- a lane following one stored direction after the other paid an LDS round trip per cell, some
+                // 200 in a row.  (All lanes keep the same ti / tj / run state; lane 0 alone writes the text.)
                 uint32_t ti = lq, tj = bestj;
                 int runop = -1; uint32_t runlen = 0;
-                for (;;) {
-                    int code = -1;
-                    if (ti > 0) {
-                        if (tj == 0) code = DIR_UP;
-                        else code = (int)((dirs[(size_t)(ti - 1) * dwords + (tj >> 4)] >> (2 * (tj & 15u))) & 3u);
-                    }
-                    if (code == runop) { runlen++; }
+                auto flush = [&]() { if (runop >= 0) cig_emit_if(lane == 0, slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D'); };
+                auto step = [&](int op, uint32_t cnt) { if (op == runop) runlen += cnt; else { flush(); runop = op; runlen = cnt; } };
+                while (ti > 0) {
+                    if (tj == 0) { step(DIR_UP, ti); ti = 0; break; }                  // column 0: up all the way (sw.erl:73-77)
+                    const bool in = lane < ti && lane < tj;
+                    const uint32_t r = in ? ti - 1 - lane : 0u, cc = in ? tj - lane : 1u;
+                    const uint32_t kk = cc + ((r & 127u) >> 1);                         // the step at which row r reached column cc
+                    const uint32_t code = in ? (dirs[(size_t)r * dwords + (kk >> 4)] >> (2 * (kk & 15u))) & 3u : 0xffu;
+                    const unsigned long long ul = __ballot(code == DIR_UL);
+                    const uint32_t nul = (uint32_t)__builtin_ctzll(~ul | (1ull << 63)) ;   // (a run of 64 stops at 63: the next round goes on)
+                    if (nul) { step(DIR_UL, nul); ti -= nul; tj -= nul; }
                     else {
-                        if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
-                        runop = code; runlen = 1;
+                        const int c0 = __builtin_amdgcn_readfirstlane((int)code);       // up or left
+                        step(c0, 1u);
+                        if (c0 == DIR_UP) ti--; else tj--;
                     }
-                    if (code < 0) break;
-                    if (code == DIR_UL) { ti--; tj--; } else if (code == DIR_UP) ti--; else tj--;
                 }
-                io.c_score[c] = score;
-                io.c_ciglen[c] = (uint32_t)len;
-                io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                flush();
+                if (lane == 0) {
+                    io.c_score[c] = score;
+                    io.c_ciglen[c] = (uint32_t)len;
+                    io.c_status[c] = len > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -3353,6 +3513,16 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
 // from the record.  The per-hit arrays of bwt_align_batch (window offset / length, CIGAR offsets, all texts) are expanded from
 // it on demand (k_hits_expand) -- a batch whose results leave as compact tables never writes them.
 #define HITS_FAT 128u          // candidates of a read from which on the wave takes the read together (k_hits_count, k_hits_write)
+// one candidate of a read into the read's totals (the fold of src/worker_bwt.erl:84-97: no_match drops out, the rest is a hit)
+__device__ __forceinline__ void hit_count_one(int32_t cs, const uint32_t *__restrict__ c_ciglen, uint64_t k, uint32_t &nh, uint32_t &nx,
+                                              uint32_t &xcb, unsigned long long &cbr, int32_t &st, Counters *ctr) {
+    if (cs == CS_OK) {
+        const uint32_t clf = c_ciglen[k];
+        nh++; cbr += clf & ~CIG_DIAG;
+        if (!(clf & CIG_DIAG)) { nx++; xcb += clf; }
+    } else if (cs == CS_WINDOW_OOR) st = -2;
+    else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
+}
 __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *__restrict__ clus_off,
                                                      const int32_t *__restrict__ c_status,
                                                      const uint32_t *__restrict__ c_ciglen,
@@ -3375,15 +3545,7 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
         const uint64_t a = valid ? clus_off[r] : 0ull, b = valid ? clus_off[r + 1] : 0ull;
         if (b > a) st = 0;
         const bool fat = b - a > HITS_FAT;
-        auto one = [&](uint64_t k) {
-            const int32_t cs = c_status[k];
-            if (cs == CS_OK) {
-                const uint32_t clf = c_ciglen[k];
-                nh++; cbr += clf & ~CIG_DIAG;
-                if (!(clf & CIG_DIAG)) { nx++; xcb += clf; }
-            } else if (cs == CS_WINDOW_OOR) st = -2;
-            else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);
-        };
+        auto one = [&](uint64_t k) { hit_count_one(c_status[k], c_ciglen, k, nh, nx, xcb, cbr, st, ctr); };
         if (!fat) for (uint64_t k = a; k < b; k++) one(k);
         for (unsigned long long fm = __ballot(fat); fm; fm &= fm - 1ull) {
             const int src = __ffsll((long long)fm) - 1;
@@ -3413,6 +3575,39 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
 struct HitRec { uint32_t read; int32_t score; int64_t pos; };   // the 16-byte record gathered over RCCL
 struct HitExtra { uint32_t hit, win_len, cig_off, cig_len; };   // bwt_hit_extra
 
+// one hit: its record, and for a hit that is not plain its extra record and text
+__device__ __forceinline__ void hit_put(uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf, int32_t shift,
+                                    const int32_t *__restrict__ c_score, const uint32_t *__restrict__ c_S, const uint8_t *__restrict__ cig,
+                                    uint32_t cig_stride, HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec, uint8_t *__restrict__ x_cig) {
+    HitRec hr; hr.read = rd; hr.score = c_score[k];
+    hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
+    h_rec[ho1] = hr;
+    if (!(clf & CIG_DIAG)) {
+        HitExtra x; x.hit = (uint32_t)ho1; x.win_len = wl; x.cig_off = (uint32_t)co1; x.cig_len = clf;
+        x_rec[xo1] = x;
+        // the text sits right-aligned in its slot (slots are multiples of 32 bytes, 16-byte aligned): it is taken 16 bytes at a
+        // time from the slot's end by aligned loads (a byte loop of dependent load / store pairs took 2.9 ms for the 15 M extras
+        // of a repeat-rich batch) and stored in pieces of 8 / 4 / 2 / 1 bytes at its unaligned place -- byte by byte the
+        // kernel wrote 2.6 GB for 0.85 GB of records and text
+        const uint8_t *slot_end = cig + (k + 1) * (uint64_t)cig_stride;
+        for (uint32_t done = 0; done < clf; done += 16) {
+            const uint4 v = *(const uint4 *)(slot_end - done - 16);
+            unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
+            const uint32_t take = clf - done < 16 ? clf - done : 16;
+            // the chunk's last `take` bytes go to x_cig[co1 + clf - done - take ..): shifted down to byte 0 first
+            const uint32_t sft = 16 - take;
+            if (sft >= 8) { lo = hi >> (8 * (sft - 8)); hi = 0; }
+            else if (sft) { lo = (lo >> (8 * sft)) | (hi << (64 - 8 * sft)); hi >>= 8 * sft; }
+            uint8_t *p = x_cig + co1 + (clf - done - take);
+            if (take & 16) { __builtin_memcpy(p, &lo, 8); __builtin_memcpy(p + 8, &hi, 8); }
+            if (take & 8) { __builtin_memcpy(p, &lo, 8); p += 8; lo = hi; }
+            if (take & 4) { const uint32_t w4 = (uint32_t)lo; __builtin_memcpy(p, &w4, 4); p += 4; lo >>= 32; }
+            if (take & 2) { const uint16_t w2 = (uint16_t)lo; __builtin_memcpy(p, &w2, 2); p += 2; lo >>= 16; }
+            if (take & 1) *p = (uint8_t)lo;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, const uint64_t *__restrict__ clus_off,
                                                      const uint64_t *__restrict__ hit_off, const uint64_t *__restrict__ x_off,
                                                      const uint64_t *__restrict__ xcb_off,
@@ -3430,35 +3625,8 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
     uint64_t ho = live0 ? hit_off[r] : 0ull;
     const bool live = live0 && ho != hit_off[r + 1];
     uint64_t xo = live ? x_off[r] : 0ull, co = live ? xcb_off[r] : 0ull;
-    // one hit: its record, and for a hit that is not plain its extra record and text
     auto put = [&](uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf) {
-        HitRec hr; hr.read = rd; hr.score = c_score[k];
-        hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
-        h_rec[ho1] = hr;
-        if (!(clf & CIG_DIAG)) {
-            HitExtra x; x.hit = (uint32_t)ho1; x.win_len = wl; x.cig_off = (uint32_t)co1; x.cig_len = clf;
-            x_rec[xo1] = x;
-            // the text sits right-aligned in its slot (slots are multiples of 32 bytes, 16-byte aligned): it is taken 16 bytes at a
-            // time from the slot's end by aligned loads (a byte loop of dependent load / store pairs took 2.9 ms for the 15 M extras
-            // of a repeat-rich batch) and stored in pieces of 8 / 4 / 2 / 1 bytes at its unaligned place -- byte by byte the
-            // kernel wrote 2.6 GB for 0.85 GB of records and text
-            const uint8_t *slot_end = cig + (k + 1) * (uint64_t)cig_stride;
-            for (uint32_t done = 0; done < clf; done += 16) {
-                const uint4 v = *(const uint4 *)(slot_end - done - 16);
-                unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
-                const uint32_t take = clf - done < 16 ? clf - done : 16;
-                // the chunk's last `take` bytes go to x_cig[co1 + clf - done - take ..): shifted down to byte 0 first
-                const uint32_t sft = 16 - take;
-                if (sft >= 8) { lo = hi >> (8 * (sft - 8)); hi = 0; }
-                else if (sft) { lo = (lo >> (8 * sft)) | (hi << (64 - 8 * sft)); hi >>= 8 * sft; }
-                uint8_t *p = x_cig + co1 + (clf - done - take);
-                if (take & 16) { __builtin_memcpy(p, &lo, 8); __builtin_memcpy(p + 8, &hi, 8); }
-                if (take & 8) { __builtin_memcpy(p, &lo, 8); p += 8; lo = hi; }
-                if (take & 4) { const uint32_t w4 = (uint32_t)lo; __builtin_memcpy(p, &w4, 4); p += 4; lo >>= 32; }
-                if (take & 2) { const uint16_t w2 = (uint16_t)lo; __builtin_memcpy(p, &w2, 2); p += 2; lo >>= 16; }
-                if (take & 1) *p = (uint8_t)lo;
-            }
-        }
+        hit_put(rd, k, ho1, xo1, co1, wl, clf, shift, c_score, c_S, cig, cig_stride, h_rec, x_rec, x_cig);
     };
     const bool fat = live && b - a > HITS_FAT;
     if (live && !fat)

@@ -96,34 +96,44 @@ __device__ __forceinline__ uint32_t rp_gather16(uint32_t f0, uint32_t f1, uint32
     const uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
     return lo | (hi << 8);
 }
+// the 16 bases of segment s of a stream of `total` bases as four words (past the end: 'A' = all planes 0)
+__device__ __forceinline__ void rp_load16(const uint8_t *__restrict__ bases, uint64_t total, uint64_t s, uint32_t (&x)[4]) {
+    const uint64_t p0 = s * 16;
+    x[0] = x[1] = x[2] = x[3] = 0x41414141u;
+    if (p0 + 16 <= total) {
+        const uint4 v = *(const uint4 *)(bases + p0);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else if (p0 < total) {
+        for (uint32_t i = 0; p0 + i < total; i++)
+            x[i >> 2] = (x[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)bases[p0 + i] << (8 * (i & 3)));
+    }
+}
+// ... -> the four plane words of the 32 bases an (even, odd) lane pair holds; valid in the even lane.  Whole waves.
+__device__ __forceinline__ uint4 rp_pair_word(const uint32_t (&x)[4]) {
+    uint32_t fl[4], fh[4], fn[4], fo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rp_word(x[k], fl[k], fh[k], fn[k], fo[k]);
+    uint32_t out[4];
+    out[RP_LO] = rp_gather16(fl[0], fl[1], fl[2], fl[3]);
+    out[RP_HI] = rp_gather16(fh[0], fh[1], fh[2], fh[3]);
+    out[RP_N] = rp_gather16(fn[0], fn[1], fn[2], fn[3]);
+    out[RP_O] = rp_gather16(fo[0], fo[1], fo[2], fo[3]);
+    // the odd lane's 16 bits complete the even lane's word
+    uint4 w;
+    w.x = out[0] | ((uint32_t)__shfl_xor((int)out[0], 1, 64) << 16);
+    w.y = out[1] | ((uint32_t)__shfl_xor((int)out[1], 1, 64) << 16);
+    w.z = out[2] | ((uint32_t)__shfl_xor((int)out[2], 1, 64) << 16);
+    w.w = out[3] | ((uint32_t)__shfl_xor((int)out[3], 1, 64) << 16);
+    return w;
+}
 static __global__ __launch_bounds__(256) __attribute__((unused)) void k_read_planes(const uint8_t *__restrict__ bases, uint64_t total,
                                                       uint32_t *__restrict__ planes) {
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t nseg = (((total + 15) >> 4) + 1) & ~1ull;      // 16-base segments, lane pairs finish whole words
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += nthreads) {
-        const uint64_t p0 = s * 16;
-        uint32_t x[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};       // past the end: 'A' = all planes 0
-        if (p0 + 16 <= total) {
-            const uint4 v = *(const uint4 *)(bases + p0);
-            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-        } else if (p0 < total) {
-            for (uint32_t i = 0; p0 + i < total; i++)
-                x[i >> 2] = (x[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)bases[p0 + i] << (8 * (i & 3)));
-        }
-        uint32_t fl[4], fh[4], fn[4], fo[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) rp_word(x[k], fl[k], fh[k], fn[k], fo[k]);
-        uint32_t out[4];
-        out[RP_LO] = rp_gather16(fl[0], fl[1], fl[2], fl[3]);
-        out[RP_HI] = rp_gather16(fh[0], fh[1], fh[2], fh[3]);
-        out[RP_N] = rp_gather16(fn[0], fn[1], fn[2], fn[3]);
-        out[RP_O] = rp_gather16(fo[0], fo[1], fo[2], fo[3]);
-        // the odd lane's 16 bits complete the even lane's word
-        uint4 w;
-        w.x = out[0] | ((uint32_t)__shfl_xor((int)out[0], 1, 64) << 16);
-        w.y = out[1] | ((uint32_t)__shfl_xor((int)out[1], 1, 64) << 16);
-        w.z = out[2] | ((uint32_t)__shfl_xor((int)out[2], 1, 64) << 16);
-        w.w = out[3] | ((uint32_t)__shfl_xor((int)out[3], 1, 64) << 16);
+        uint32_t x[4];
+        rp_load16(bases, total, s, x);
+        const uint4 w = rp_pair_word(x);
         if (!(s & 1)) ((uint4 *)planes)[s >> 1] = w;
     }
 }

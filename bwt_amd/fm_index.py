@@ -30,6 +30,10 @@ class FM:
         (self.Pc, self.Pg, self.Pt, self.Last), self.shift = index.meta()
 
     def close(self):
+        sb = getattr(self, "_small_batch", None)          # (worker_bwt's small-batch handle holds device buffers on this index)
+        if sb is not None:
+            sb.close()
+            self._small_batch = None
         self.index.close()
 
     def save_native(self, chrom, j):

@@ -26,6 +26,7 @@ EXPORTS = [
     "bwt_batch_set_reads_packed", "bwt_batch_fetch_hits_compact", "bwt_hits_expand", "bwt_pipe_set_options", "bwt_pipe_profile",
     "bwt_pipe_kernel_times", "bwt_pipe_acquire_packed", "bwt_pipe_submit_packed", "bwt_pipe_submit_ascii", "bwt_pipe_batch",
     "bwt_batch_compact_to_device",
+    "bwt_small_create", "bwt_small_destroy", "bwt_small_set_options", "bwt_small_align", "bwt_small_profile", "bwt_small_kernel_times",
 ]
 
 
@@ -106,6 +107,15 @@ class PipeResult(C.Structure):
                 ("ms_download", C.c_double), ("ms_waiting", C.c_double)]
 
 
+class SmallResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("path", C.c_uint32), ("n_hits", C.c_uint64), ("n_extra", C.c_uint64), ("cigar_bytes", C.c_uint64),
+                ("read_status", C.c_void_p), ("hits", C.c_void_p), ("extra", C.c_void_p), ("cigar", C.c_void_p),
+                ("n_candidates", C.c_uint64), ("n_dp", C.c_uint64), ("n_float", C.c_uint64), ("overflow_flags", C.c_uint64),
+                ("us_copy_in", C.c_double), ("us_enqueue", C.c_double), ("us_wait", C.c_double), ("us_total", C.c_double)]
+
+
+SMALL_MAX_READS = 4096
+
 _lib = None
 
 
@@ -125,6 +135,7 @@ def load():
     lib.bwt_fastq_close.restype = None
     lib.bwt_batch_destroy.restype = None
     lib.bwt_pipe_destroy.restype = None
+    lib.bwt_small_destroy.restype = None
     lib.bwt_constants.restype = None
     lib.bwt_options_init.restype = None
     lib.bwt_packed_words.restype = C.c_uint64
@@ -687,3 +698,72 @@ class Pipe:
 
     def release(self, slot):
         _chk(load().bwt_pipe_release(self.h, C.c_uint32(slot)))
+
+
+class SmallBatch:
+    """bwt_small: one call per batch of the reference's message size (<= SMALL_MAX_READS reads): pinned staging, no host round trip
+    between the kernels, the compact hit table straight into pinned memory.  Larger or odd batches, and batches that overflow one of
+    its fixed capacities, go through the general path inside the same call (path 0 / 2); results are identical either way."""
+
+    def __init__(self, index):
+        self.index = index
+        self.h = C.c_void_p()
+        _chk(load().bwt_small_create(index.h, C.byref(self.h)))
+        self.last = None
+        self.fallbacks = 0
+        self.paths = {0: 0, 1: 0, 2: 0}
+
+    def close(self):
+        if self.h:
+            load().bwt_small_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_options(self, **kw):
+        o = make_options(**kw)
+        _chk(load().bwt_small_set_options(self.h, C.byref(o)))
+
+    def align_raw(self, bases, off):
+        """the C call alone (arrays must be contiguous u8 / u64 already) -> SmallResult"""
+        r = SmallResult()
+        _chk(load().bwt_small_align(self.h, _p(bases), _p(off), C.c_uint32(len(off) - 1), C.byref(r)))
+        self.last = r
+        self.paths[int(r.path)] += 1
+        if r.path == 2:
+            self.fallbacks += 1
+        return r
+
+    def align(self, bases, off, expand=True):
+        """-> the compact table (views into the handle's buffers, valid until the next call), or with expand the per-hit arrays of
+        Index.align_batch"""
+        bases = np.ascontiguousarray(bases, np.uint8); off = np.ascontiguousarray(off, np.uint64)
+        r = self.align_raw(bases, off)
+        n, nh, nx = int(r.n_reads), int(r.n_hits), int(r.n_extra)
+        comp = dict(read_status=_view(r.read_status, n, np.int8), hits=_view(r.hits, nh, HIT_REC), extra=_view(r.extra, nx, HIT_EXTRA),
+                    cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8), path=int(r.path), overflow_flags=int(r.overflow_flags),
+                    counts=dict(n_clusters=int(r.n_candidates), n_dp=int(r.n_dp), n_float=int(r.n_float), n_hits=nh))
+        if not expand:
+            return comp
+        out = hits_expand(n, 0, off - off[0], self.index.meta()[1], comp["hits"], comp["extra"], comp["cigar"])
+        out["read_status"] = comp["read_status"].astype(np.int32)
+        out["path"] = comp["path"]; out["counts"] = comp["counts"]; out["overflow_flags"] = comp["overflow_flags"]
+        return out
+
+    def stage_us(self):
+        r = self.last
+        return dict(copy_in=r.us_copy_in, enqueue=r.us_enqueue, wait=r.us_wait, total=r.us_total)
+
+    def profile(self, enable=True):
+        _chk(load().bwt_small_profile(self.h, 1 if enable else 0))
+
+    def kernel_times(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * 64)(); ln = (C.c_uint64 * 64)()
+        k = _chk(load().bwt_small_kernel_times(self.h, names, 4096, ms, ln, 64))
+        parts = names.raw.split(b"\0")[:k]
+        return {parts[i].decode(): dict(ms=float(ms[i]), launches=int(ln[i])) for i in range(k)}

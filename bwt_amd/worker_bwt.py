@@ -19,12 +19,22 @@ class WorkerCrash(Exception):
     (the documented divergence of SURVEY 8b)."""
 
 
+def _small(fm):
+    """the index's small-batch handle (bwt_small: pinned staging, one synchronisation per call), made on first use"""
+    sb = getattr(fm, "_small_batch", None)
+    if sb is None:
+        sb = fm._small_batch = lib.SmallBatch(fm.index)
+    return sb
+
+
 def align_batch(fm, qseq_list):
     """qseq_list: [(Name, Seq)].  -> per read None (sga = []), WorkerCrash, or the `Cigars` list
-    [((Score,Cigar), Pos, RefSeq)] in the reference's list order."""
+    [((Score,Cigar), Pos, RefSeq)] in the reference's list order.  One bwt_small_align call: a QseqList (200 reads,
+    src/master.erl:59) or a whole workload message (10 of them) is the size that entry point is for; anything it does not take
+    runs through the general path inside the same call."""
     reads = [bytes(s) for _, s in qseq_list]
     bases, off = lib.pack_reads(reads)
-    out = fm.index.align_batch(bases, off)
+    out = _small(fm).align(bases, off)
     refseqs = fm.index.ref1_gather(out["win_off"], out["win_len"])         # RefSeq of every hit in one call
     res = []
     for i, (name, _) in enumerate(qseq_list):
@@ -56,7 +66,10 @@ def running(fm, qseq_list):
     """One QseqList of the workload -> list of casts in the order the reference sends them.
     Seeds is built by prepending in the foldl (worker_bwt.erl:74-80), so reads are answered in
     REVERSE batch order."""
-    per_read = align_batch(fm, qseq_list)
+    return _casts(qseq_list, align_batch(fm, qseq_list))
+
+
+def _casts(qseq_list, per_read):
     casts = []
     for (name, _), cig in reversed(list(zip(qseq_list, per_read))):
         if cig is None:
@@ -70,4 +83,19 @@ def running(fm, qseq_list):
         else:
             (score_cigar, pos, refseq) = top
             casts.append(("cigar", name.decode() if isinstance(name, bytes) else name, score_cigar, pos, refseq))
+    return casts
+
+
+
+def workload(fm, qseq_lists):
+    """A whole {workload, [QseqList, ...]} message (src/worker_bwt.erl:62-69) in ONE device call: the reads of all its lists go up
+    together, and the casts come out exactly as the reference sends them -- list by list in message order
+    (worker_loop(running, [QseqList | WorkloadRest], ...), :73,112), inside a list in reverse read order (:74-80)."""
+    flat = [item for ql in qseq_lists for item in ql]
+    per_read = align_batch(fm, flat) if flat else []
+    casts = []
+    at = 0
+    for ql in qseq_lists:
+        casts.extend(_casts(ql, per_read[at:at + len(ql)]))
+        at += len(ql)
     return casts

@@ -1,7 +1,7 @@
 %% Loader of the NIF shim c_src/bwt_nif.c (libbwtgpu, include/bwt_gpu.h).
 %% Written from scratch for this repository; not compiled here (no Erlang in the authoring container).
 -module(bwt_nif).
--export([constants/0, index_open/3, index_meta/1, align_batch/2]).
+-export([constants/0, index_open/3, index_meta/1, align_batch/2, align_workload/2]).
 -on_load(init/0).
 
 -include("bwt.hrl").   %% the reference's own include/bwt.hrl
@@ -18,3 +18,4 @@ constants() -> erlang:nif_error(nif_not_loaded).
 index_open(_Fm, _Ref, _Device) -> erlang:nif_error(nif_not_loaded).
 index_meta(_Index) -> erlang:nif_error(nif_not_loaded).
 align_batch(_Index, _QseqList) -> erlang:nif_error(nif_not_loaded).
+align_workload(_Index, _Workload) -> erlang:nif_error(nif_not_loaded).

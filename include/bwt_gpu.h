@@ -398,6 +398,40 @@ int bwt_pipe_wait(bwt_pipe *p, bwt_pipe_result *res);
 int bwt_pipe_release(bwt_pipe *p, uint32_t slot);
 bwt_batch *bwt_pipe_batch(bwt_pipe *p, uint32_t slot);
 
+/* ------------------------------------------------------------------ small batches: the reference's own message size
+ * The master hands a worker 10 lists of 200 reads per message (src/master.erl:59) and worker_bwt runs its `running` clause once
+ * per list (src/worker_bwt.erl:16,62-69,73-112).  A call of that size is all fixed cost on the general path (about forty launches,
+ * six synchronisations, pageable copies, two-call sizing: 0.7-0.9 ms for 200-2000 reads).  bwt_small_align runs the SAME kernels
+ * with what surrounds them removed: the reads go through pinned memory that the first kernel reads directly, no size comes back
+ * to the host in mid-run (fixed capacities; queue lengths are read on the device), the compact hit table is written into
+ * pinned memory by the last kernel, and one synchronisation ends the call.
+ *   n <= BWT_SMALL_MAX_READS reads of up to ~200 bases, <= 1 M bases in all; a batch it does not take, or one that overflows a
+ *   fixed capacity (more than 32768 candidates, 2^20 seeds left to the cluster kernels, a window wider than 2048 bases, a CIGAR
+ *   longer than its slot), is run through the general path by the same call -- the results are identical either way and
+ *   res->path says which ran: 1 = small path, 2 = small path overflowed and the general path redid it, 0 = general path.
+ * The result is the compact hit table (format above; bwt_hits_expand gives the per-hit arrays); its pointers stay valid until the
+ * next call on the handle.  One call at a time per handle; several handles may share an index. */
+#define BWT_SMALL_MAX_READS 4096u
+typedef struct bwt_small bwt_small;
+typedef struct {
+    uint32_t n_reads, path;
+    uint64_t n_hits, n_extra, cigar_bytes;
+    const int8_t *read_status;       /* n_reads   (values as bwt_align_batch) */
+    const bwt_hit_rec *hits;         /* n_hits, ascending by read */
+    const bwt_hit_extra *extra;      /* n_extra, ascending by hit */
+    const char *cigar;               /* cigar_bytes: the text of the extras */
+    uint64_t n_candidates, n_dp, n_float;   /* {S,D} candidates, those that ran a DP kernel, those that took the fp64 one */
+    uint64_t overflow_flags;         /* path 2: why the small path gave up (2 a CIGAR longer than its slot, 16 a fixed capacity, ...) */
+    double us_copy_in, us_enqueue, us_wait, us_total;   /* host clock since the call began: reads in pinned memory, kernels queued, results back, done */
+} bwt_small_result;
+int bwt_small_create(bwt_index *idx, bwt_small **out);
+void bwt_small_destroy(bwt_small *s);
+int bwt_small_set_options(bwt_small *s, const bwt_options *opt);
+int bwt_small_align(bwt_small *s, const uint8_t *bases, const uint64_t *off, uint32_t n, bwt_small_result *res);
+/* per-kernel device time of the handle's runs (as bwt_batch_profile / bwt_batch_kernel_times) */
+int bwt_small_profile(bwt_small *s, int enable);
+int bwt_small_kernel_times(bwt_small *s, char *names, uint32_t names_cap, double *ms, uint64_t *launches, uint32_t cap);
+
 /* ------------------------------------------------------------------ the whole job for one FASTQ file
  * What the reference's master and one worker do (src/master.erl:162-178 workload production, src/worker_bwt.erl:73-112 the
  * running clause incl. the final pick by lists:sort/2 with the comparator R1 > R2, src/master.erl:149-155 the result sink):

@@ -61,6 +61,12 @@ for n in (200, 2000, 4096, 20000):
             sb.align_raw(bases, off)
         rec["small_path_ms_c_call_only"] = (time.perf_counter() - t0) / (reps * 4) * 1e3
         rec["small_path_stage_us"] = sb.stage_us()
+        sb.profile(True)
+        for _ in range(reps):
+            sb.align_raw(bases, off)
+        rec["small_path_device_us_per_call"] = {k_: round(v["ms"] / reps * 1e3, 2) for k_, v in sorted(sb.kernel_times().items())}
+        rec["small_path_launches_per_call"] = sum(v["launches"] for v in sb.kernel_times().values()) / reps
+        sb.profile(False)
         got = sb.align(bases, off)
         same = all(np.array_equal(got[k_], ref_out[k_]) for k_ in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off")) and got["cigar"] == ref_out["cigar"]
         rec["small_path_equals_general_path"] = bool(same)

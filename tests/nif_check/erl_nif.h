@@ -51,10 +51,11 @@ ErlNifMutex *enif_mutex_create(char *name);
 void enif_mutex_destroy(ErlNifMutex *);
 void enif_mutex_lock(ErlNifMutex *);
 void enif_mutex_unlock(ErlNifMutex *);
+typedef struct { const char *name; int nfuncs; ErlNifFunc *funcs; int (*load)(ErlNifEnv *, void **, ERL_NIF_TERM); } ErlNifEntry;
+const ErlNifEntry *nif_init(void);
 #define ERL_NIF_INIT(NAME, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD)                                                   \
-    struct bwt_nif_entry { const char *name; int nfuncs; ErlNifFunc *funcs; int (*load)(ErlNifEnv *, void **, ERL_NIF_TERM); }; \
-    const struct bwt_nif_entry *nif_init(void) {                                                                   \
-        static const struct bwt_nif_entry e = {#NAME, sizeof(FUNCS) / sizeof(FUNCS[0]), FUNCS, LOAD};              \
+    const ErlNifEntry *nif_init(void) {                                                                            \
+        static const ErlNifEntry e = {#NAME, sizeof(FUNCS) / sizeof(FUNCS[0]), FUNCS, LOAD};                       \
         (void)(RELOAD); (void)(UPGRADE); (void)(UNLOAD);                                                           \
         return &e;                                                                                                 \
     }

@@ -23,10 +23,12 @@ def test_shim_calls_only_exported_symbols():
     assert called and called <= set(lib.EXPORTS), called - set(lib.EXPORTS)
 
 
-def test_shim_serialises_its_resident_batch():
-    """every use of the handle's batch sits between enif_mutex_lock and enif_mutex_unlock"""
+def test_shim_serialises_its_small_batch_handle():
+    """every use of the handle's bwt_small (not re-entrant) sits between enif_mutex_lock and enif_mutex_unlock"""
     src = open(os.path.join(ROOT, "c_src", "bwt_nif.c")).read()
-    body = src[src.index("static ERL_NIF_TERM nif_align_batch"):]
+    body = src[src.index("static int align_staged"):src.index("static ERL_NIF_TERM nif_align_batch")]
     lock, unlock = body.index("enif_mutex_lock(r->lock)"), body.index("enif_mutex_unlock(r->lock)")
-    uses = [m.start() for m in re.finditer(r"r->batch", body)]
+    uses = [m.start() for m in re.finditer(r"r->small|\bsr\.", body)]        # the handle, and the result pointers it owns
     assert uses and all(lock < u < unlock for u in uses)
+    rest = src[src.index("static ERL_NIF_TERM nif_align_batch"):]
+    assert "r->small" not in rest
