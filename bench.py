@@ -643,7 +643,9 @@ def main():
         # (k_seed_fast hands single reads back to the general kernel)
         back = min(1.0, counts.get("n_handed_back", 0) / max(counts["n_reads"], 1)) if fast else 1.0
         back2 = back
-        narrow = counts["n_reads"] * sum(1 for k in range(length // 8) if 8 <= length - 8 * k < kdepth) if kdepth else 0
+        # (lookups below the top level are 8-byte entries unless that level is one of the widened ones: 64 bytes then, like the top)
+        widened = set(ix.ktable_wide_levels) if kwide else set()
+        narrow = counts["n_reads"] * sum(1 for k in range(length // 8) if 8 <= length - 8 * k < kdepth and (length - 8 * k) not in widened) if kdepth else 0
         wide_l = max(0, counts["n_lookups"] - narrow) if kwide else 0
         narrow_l = counts["n_lookups"] - wide_l
         # seed stage, both kernels: Lq per read in, one table entry per task (64 B / 8 B), 16 B per read (r_pend, r_P, r_qty) + 4 B (r_K)
@@ -705,7 +707,7 @@ def main():
                         else "search stage only, reads resident in HBM (BASELINE configs[1] times the kernel alone)",
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": length,
                        "index_rows": ix.meta()[0][3], "index_bytes": ix.device_bytes(),
-                       "suffix_interval_table": {"K": ix.ktable[0], "top_level_carries_sa": ix.ktable[1]},
+                       "suffix_interval_table": {"K": ix.ktable[0], "top_level_carries_sa": ix.ktable[1], "lower_levels_kept_wide": ix.ktable_wide_levels},
                        "repeat_spectrum": composition,
                        "parallelism": "reads sharded x%d (contiguous slabs), index replicated, RCCL hit gather" % world,
                        "ranks_seen": ranks_seen},

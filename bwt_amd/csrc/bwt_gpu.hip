@@ -92,6 +92,8 @@ extern "C" int bwt_index_set_ktable_ex(bwt_index *ix, int K, int wide, int summa
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->d.ktab = nullptr; ix->d.ktw = nullptr; ix->d.kt_k = 0; ix->d.ktsum = nullptr; ix->d.ktsum_levels = 0;
+    for (int k = 0; k < 8; k++) ix->d.ktw_off[k] = KTW_NONE;
+    ix->ktw_bytes = 0;
     ix->ktab.release(); ix->ktw.release(); ix->ktsum.release();
     if (K == 0) return 0;
     const uint64_t wide_bytes = 64ull << (2 * K);
@@ -99,24 +101,66 @@ extern "C" int bwt_index_set_ktable_ex(bwt_index *ix, int K, int wide, int summa
         {
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
-            wide = K == BWT_MAX_LEN && free_b >= wide_bytes + (32ull << 30);
+            wide = (K == BWT_MAX_LEN && free_b >= wide_bytes + (32ull << 30)) ? 2 : 0;
         }
     }
-    int rc = ix->ktab.exact((wide ? kt_level_off(K) : kt_entries(K)) * 8);
-    if (rc) return rc;
-    if (wide && (rc = ix->ktw.exact(wide_bytes))) { ix->ktab.release(); return rc; }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
+    // the 8-byte levels first (every level but a wide top one); then, wide == 2, which of the LOWER levels are worth keeping as
+    // 64-byte entries as well: those where at least a quarter of the keys give a task that ends there a seed list -- on a
+    // chromosome-sized index the 12-mers (the last sub-read of a 100-bp read: its ~14 seeds were a dozen random SA reads per
+    // read, more lines than the eleven top-level lookups together), on a genome-sized one the 14-mers (150-bp reads) -- and
+    // that fit next to a 32 GB reserve
+    int rc = ix->ktab.exact((wide ? kt_level_off(K) : kt_entries(K)) * 8);
+    if (rc) return rc;
     for (int m = KT_MIN; m <= K; m++) {
+        if (wide && m == K) break;
         const uint64_t quads = 1ull << (2 * m);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((quads * 4 + 255) / 256, (uint64_t)cus * 8);
-        hipLaunchKernelGGL(kt_build, dim3(grid), dim3(256), 0, ix->stream, ix->d, ix->ktab.as<uint64_t>(), m,
-                           (wide && m == K) ? ix->ktw.as<uint4>() : (uint4 *)nullptr);
+        hipLaunchKernelGGL(kt_build, dim3(grid), dim3(256), 0, ix->stream, ix->d, ix->ktab.as<uint64_t>(), m, (uint4 *)nullptr);
+    }
+    uint64_t off_entries[8];
+    for (int k = 0; k < 8; k++) off_entries[k] = KTW_NONE;
+    uint64_t total_entries = wide ? (1ull << (2 * K)) : 0;
+    if (wide == 2 && K == BWT_MAX_LEN) {
+        DevBuf cnt;
+        if ((rc = cnt.ensure(16 * 8))) { ix->ktab.release(); return rc; }
+        HIPCHK(hipMemsetAsync(cnt.p, 0, 16 * 8, ix->stream));
+        for (int m = KT_MIN + 1; m < K; m++)
+            hipLaunchKernelGGL(kt_count_seeded, dim3((uint32_t)std::min<uint64_t>(((1ull << (2 * m)) + 255) / 256, (uint64_t)cus * 8)), dim3(256), 0, ix->stream,
+                               (const uint64_t *)ix->ktab.as<uint64_t>(), m, cnt.as<unsigned long long>());
+        unsigned long long hc[16] = {0};
+        hipError_t e = hipMemcpyAsync(hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        cnt.release();
+        if (e != hipSuccess) { ix->ktab.release(); return fail(BWT_EHIP, std::string("suffix-interval table: ") + hipGetErrorString(e)); }
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = free_b > wide_bytes + (32ull << 30) ? free_b - wide_bytes - (32ull << 30) : 0;
+        for (int m = K - 1; m > KT_MIN; m--) {
+            const uint64_t keys = 1ull << (2 * m);
+            if (hc[m] * 4 >= keys && keys * 64 <= budget && total_entries + keys < 0xfffffff0ull) {
+                off_entries[m - 8] = total_entries; total_entries += keys; budget -= keys * 64;
+            }
+        }
+    }
+    if (wide) {
+        off_entries[K - 8] = 0;
+        if ((rc = ix->ktw.exact(total_entries * 64))) { ix->ktab.release(); return rc; }
+        ix->ktw_bytes = total_entries * 64;
+        const uint64_t quads = 1ull << (2 * K);
+        hipLaunchKernelGGL(kt_build, dim3((uint32_t)std::min<uint64_t>((quads * 4 + 255) / 256, (uint64_t)cus * 8)), dim3(256), 0, ix->stream, ix->d,
+                           ix->ktab.as<uint64_t>(), K, ix->ktw.as<uint4>());
+        for (int m = KT_MIN; m < K; m++)
+            if (off_entries[m - 8] != KTW_NONE)
+                hipLaunchKernelGGL(kt_widen, dim3((uint32_t)std::min<uint64_t>(((1ull << (2 * m)) * 4 + 255) / 256, (uint64_t)cus * 8)), dim3(256), 0, ix->stream, ix->d,
+                                   (const uint64_t *)ix->ktab.as<uint64_t>(), m, ix->ktw.as<uint4>() + off_entries[m - 8] * 4);
     }
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipGetLastError());
     ix->d.ktab = ix->ktab.as<uint64_t>(); ix->d.kt_k = K;
     ix->d.ktw = wide ? ix->ktw.as<uint4>() : nullptr;
+    if (wide) for (int k = 0; k < 8; k++) ix->d.ktw_off[k] = (uint32_t)off_entries[k];
     // Summary of the 8-byte levels (one bit per 64 entries: "not all plain too-many-seeds entries"): on a large genome every
     // 12-mer occurs far more than MAX_RANGE times, and the lookup of a read's short last sub-read is answered by a cached
     // bit instead of a random table line.  Used per level only where fewer than a quarter of the bits are set.
@@ -144,7 +188,13 @@ extern "C" int bwt_index_set_ktable_ex(bwt_index *ix, int K, int wide, int summa
     }
     return 0;
 }
-extern "C" int bwt_index_ktable(const bwt_index *ix) { return ix ? (ix->d.kt_k | (ix->d.ktw ? 16 : 0)) : 0; }
+extern "C" int bwt_index_ktable(const bwt_index *ix) {
+    if (!ix) return 0;
+    int v = ix->d.kt_k | (ix->d.ktw ? 16 : 0);
+    if (ix->d.ktw)
+        for (int m = KT_MIN; m < ix->d.kt_k; m++) if (ix->d.ktw_off[m - 8] != KTW_NONE) v |= 1 << (m - 8 + 8);     // bit 8 + (m - 8): level m widened
+    return v;
+}
 
 static int index_build(const FmHost &fm, const uint8_t *ref, uint64_t ref_len, int device, bwt_index **out) {
     const uint32_t n = (uint32_t)fm.L.size();
@@ -278,7 +328,7 @@ extern "C" int bwt_index_meta(const bwt_index *ix, uint32_t out[5]) {
 extern "C" int bwt_index_device_bytes(const bwt_index *ix, uint64_t out[4]) {
     if (!ix || !out) return fail(BWT_EINVAL, "bwt_index_device_bytes: null argument");
     out[0] = (uint64_t)ix->d.nblk * 64; out[1] = (uint64_t)ix->Last * 4; out[2] = ix->ref1_len + ix->d.rpw * 4;
-    out[3] = ix->d.kt_k ? (ix->d.ktw ? kt_level_off(ix->d.kt_k) * 8 + (64ull << (2 * ix->d.kt_k)) : kt_entries(ix->d.kt_k) * 8) : 0;
+    out[3] = ix->d.kt_k ? (ix->d.ktw ? kt_level_off(ix->d.kt_k) * 8 + ix->ktw_bytes : kt_entries(ix->d.kt_k) * 8) : 0;
     return 0;
 }
 
@@ -945,7 +995,7 @@ static int launch_search(bwt_batch *b, uint32_t n, uint32_t maxT, bool raw, bool
                 const size_t lds = sf_lds_bytes(maxT, big);
                 // the summary bit is looked at only when the index has one for the level of this batch's short last sub-read
                 const int mn = (int)(b->ulen % BWT_MIN_LEN) + BWT_MIN_LEN;
-                const bool sum = b->ix->d.ktsum && mn < BWT_MAX_LEN && ((b->ix->d.ktsum_levels >> mn) & 1u);
+                const bool sum = b->ix->d.ktsum && mn < BWT_MAX_LEN && ((b->ix->d.ktsum_levels >> mn) & 1u) && b->ix->d.ktw_off[mn - 8] == KTW_NONE;
                 const void *kern = big ? (sum ? (const void *)k_seed_fast<true, true> : (const void *)k_seed_fast<true, false>)
                                        : (sum ? (const void *)k_seed_fast<false, true> : (const void *)k_seed_fast<false, false>);
                 int &per_cu = b->occ_seed[3];

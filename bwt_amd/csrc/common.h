@@ -55,6 +55,7 @@ struct bwt_index {
     uint32_t Pc = 0, Pg = 0, Pt = 0, Last = 0;
     int32_t shift = 0;
     uint64_t ref1_len = 0;
+    uint64_t ktw_bytes = 0;           // the table's 64-byte levels (the top one + the widened lower ones)
     bwt_options opt;                  // defaults of the batches made on this index (bwt_index_set_options); -1 = library's choice
     bwt_index() { bwt_options_init(&opt); }
     hipStream_t stream = nullptr;     // index-level work only (table build, RefSeq gathers); every batch has its own stream

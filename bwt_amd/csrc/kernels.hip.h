@@ -663,6 +663,42 @@ __global__ __launch_bounds__(256) void kt_build(DevIndex ix, uint64_t *__restric
     }
 }
 
+// kt_widen: level m (below the top) once more as 64-byte entries {Sp, width | n << 28, 14 SA values}, from its 8-byte entries
+// (quad per key, lane q writes quarter q).  kt_count_seeded: how many keys of level m give a task that ENDS there a seed list
+// (the whole m-mer occurs at most MAX_RANGE + 1 times, or the search stopped short of it with >= 8 bases matched): the levels
+// where that is common are the ones worth widening (bwt_index_set_ktable_ex).
+__global__ __launch_bounds__(256) void kt_widen(DevIndex ix, const uint64_t *__restrict__ tab, int m, uint4 *__restrict__ wide) {
+    const int ql = (int)(threadIdx.x & 3);
+    const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2, nkeys = 1ull << (2 * m);
+    for (uint64_t key = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; key < nkeys; key += nquads) {
+        const uint64_t ent = tab[kt_level_off(m) + key];
+        const uint32_t sp = (uint32_t)ent, wd = (uint32_t)(ent >> 32) & KT_OVF;
+        const uint32_t cnt = wd == KT_OVF ? 0u : wd + 1u;
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int wi = 4 * ql + c;
+            uint32_t v = 0;
+            if (wi == 0) v = (uint32_t)ent;
+            else if (wi == 1) v = (uint32_t)(ent >> 32);
+            else if ((uint32_t)(wi - 2) < cnt) v = ix.sa[sp - 1 + (uint32_t)(wi - 2)];
+            w[c] = v;
+        }
+        wide[key * 4 + (uint64_t)ql] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+__global__ __launch_bounds__(256) void kt_count_seeded(const uint64_t *__restrict__ tab, int m, unsigned long long *__restrict__ out) {
+    const uint64_t nkeys = 1ull << (2 * m), base = kt_level_off(m);
+    unsigned long long mine = 0;
+    for (uint64_t key = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys; key += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t ent = tab[base + key];
+        const uint32_t wd = (uint32_t)(ent >> 32) & KT_OVF, nn = (uint32_t)(ent >> 60);
+        mine += (wd != KT_OVF && nn >= BWT_MIN_LEN && ((int)nn < m || wd <= BWT_MAX_RANGE)) ? 1u : 0u;
+    }
+    mine = wave_sum_u64(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out + m, mine);
+}
+
 // k_kt_summary: level m of the 8-byte table, one bit per 64 entries (DevIndex::ktsum): set unless all 64 entries are plain
 // "too many seeds" entries (n = m steps done, MAX_RANGE < width, not the overflow mark).  A wave per 64 entries, grid-stride;
 // nset[m] counts the set bits (how sparse the level is decides whether checking the bit first pays).
@@ -869,12 +905,14 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
         // the table read.  Wide top level under FUSE: the four lanes of a quad fetch the quad's four 64-byte entries one
         // after the other, lane q taking quarter q -- one L2 request per entry instead of four (the L2 request rate, not
         // HBM, is what a lane-per-entry fetch of all four quarters runs into); Q[t] = my quarter of the entry of lane t.
-        const bool askw = m == K && m > 0 && ix.ktw != nullptr;
+        const uint32_t woff = m > 0 ? ktw_level_off(ix, m) : KTW_NONE;     // the level asked is kept as 64-byte entries (the top one, or a widened lower one)
+        const bool askw = woff != KTW_NONE;
+        const uint64_t wkey = key + woff;
         uint64_t ent = 0;
         uint4 Q[4];
         if (FUSE) {
             const int ql = (int)(lane & 3);
-            const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32), aw = askw ? 1u : 0u;
+            const uint32_t klo = (uint32_t)wkey, khi = (uint32_t)(wkey >> 32), aw = askw ? 1u : 0u;
 #define KT_QLOAD(T)                                                                                                    \
             {                                                                                                          \
                 const uint64_t kt = (uint64_t)quad_bcast<T>(klo) | ((uint64_t)quad_bcast<T>(khi) << 32);                \
@@ -888,7 +926,7 @@ __global__ __launch_bounds__(256) void k_seed_tasks(DevIndex ix, const uint32_t 
             const uint32_t ex = ql == 0 ? x0 : ql == 1 ? x1 : ql == 2 ? x2 : x3, ey = ql == 0 ? y0 : ql == 1 ? y1 : ql == 2 ? y2 : y3;
             if (askw) { ent = (uint64_t)ex | ((uint64_t)ey << 32); inl = true; }
         } else if (askw) {
-            const uint4 q0 = ix.ktw[key * 4];
+            const uint4 q0 = ix.ktw[wkey * 4];
             ent = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
         }
         if (m > 0 && !askw) ent = ix.ktab[kt_level_off(m) + key];
@@ -1161,7 +1199,8 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
     const int m = e < BWT_MAX_LEN ? e : BWT_MAX_LEN;
     const uint32_t kmask = (1u << m) - 1u, ksh = 16u - (uint32_t)m;
     const uint32_t inread = e >= 16 ? 0xffffu : ((0xffffu << (16 - e)) & 0xffffu);
-    const bool wide = m == BWT_MAX_LEN;
+    const uint32_t woff = m >= KT_MIN ? ktw_level_off(ix, m) : KTW_NONE;    // my level as 64-byte entries: the top one (always, here) or a widened lower one
+    const bool wide = woff != KTW_NONE;
     const uint64_t loff = kt_level_off(m > KT_MIN ? m : KT_MIN);
     const bool usesum = SUM && !wide && m >= KT_MIN && ix.ktsum != nullptr && ((ix.ktsum_levels >> m) & 1u);   // check the summary bit before the 8-byte entry
     const uint32_t shsk = BWT_MIN_LEN * slot;
@@ -1206,10 +1245,11 @@ void k_seed_fast(DevIndex ix, const uint32_t *__restrict__ planes, uint32_t n, u
         if (SUM && act2 && usesum) sword = ix.ktsum[nidx >> 11];
         // lane q of a quad takes quarter q of the quad's four entries (one L2 request per entry)
         const uint32_t aw = act2 && wide ? 1u : 0u;
-        { const uint32_t kt = quad_bcast<0>(key); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        { const uint32_t kt = quad_bcast<1>(key); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        { const uint32_t kt = quad_bcast<2>(key); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
-        { const uint32_t kt = quad_bcast<3>(key); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        const uint32_t wk = key + woff;                                 // (all widened levels together hold fewer than 2^32 entries)
+        { const uint32_t kt = quad_bcast<0>(wk); if (quad_bcast<0>(aw)) Q0 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<1>(wk); if (quad_bcast<1>(aw)) Q1 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<2>(wk); if (quad_bcast<2>(aw)) Q2 = ix.ktw[(uint64_t)kt * 4 + ql]; }
+        { const uint32_t kt = quad_bcast<3>(wk); if (quad_bcast<3>(aw)) Q3 = ix.ktw[(uint64_t)kt * 4 + ql]; }
         // summary bit clear: the entry is a plain "too many seeds" one -- known without its table line.  (The load stays a bare
         // conditional load: giving nent a value on the other path would merge right behind the load, i.e. wait for it here.)
         if (SUM) {

@@ -47,12 +47,26 @@ struct DevIndex {
     const uint64_t *ktab;  // suffix-interval table, levels 8..kt_k (kernels.hip.h: kt_build); null when kt_k == 0
     const uint4 *ktw;      // level kt_k as 64-byte entries that also carry the first 14 SA values, or null (then ktab holds it)
     int kt_k;
+    // LOWER levels kept as 64-byte entries as well (behind the top level in ktw; round 4): ktw_off[m - 8] = where level m starts in
+    // ktw, in entries, or KTW_NONE.  A read's short last sub-read (12 bases of a 100-bp read, 14 of a 150-bp one) ends at such a
+    // level; on an index where that level's k-mers mostly have a seed list -- 4^12 k-mers over 2.3e8 positions: 14 occurrences
+    // each -- its seeds come with the table line instead of by a dozen random SA reads.  ktw_off[7] (the top level) is 0.
+    uint32_t ktw_off[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     // one bit per 64 entries of the 8-byte levels of ktab: clear = all 64 are plain "too many seeds" entries (the search ran its
     // full length and the interval is wider than MAX_RANGE), so a lookup that finds the bit clear knows its answer without the
     // table line.  ktsum_levels: bit m set = level m is sparse enough for the check to pay (kernels.hip.h: k_kt_summary).
     const uint32_t *ktsum = nullptr;
     uint32_t ktsum_levels = 0;
 };
+
+#define KTW_NONE 0xffffffffu
+// where level m (8..15) starts in ktw, or KTW_NONE (chained selects: a per-lane index into the kernel-argument array goes through scratch)
+__device__ __forceinline__ uint32_t ktw_level_off(const DevIndex &ix, int m) {
+    uint32_t o = KTW_NONE;
+    o = m == 9 ? ix.ktw_off[1] : o; o = m == 10 ? ix.ktw_off[2] : o; o = m == 11 ? ix.ktw_off[3] : o; o = m == 12 ? ix.ktw_off[4] : o;
+    o = m == 13 ? ix.ktw_off[5] : o; o = m == 14 ? ix.ktw_off[6] : o; o = m == 15 ? ix.ktw_off[7] : o; o = m == 8 ? ix.ktw_off[0] : o;
+    return ix.ktw ? o : KTW_NONE;
+}
 
 // byte-stream bit-planes (reads, Ref1) ---------------------------------------------------------------
 __device__ __forceinline__ int base_code(uint32_t c) {  // A C G T -> 0..3, anything else -> -1

@@ -303,7 +303,8 @@ class Index:
 
     def set_ktable(self, k, wide=-1, summary=1):
         """Suffix-interval table: depth k (0 = none, 8..15, negative = the library's default for this index), whether its
-        top level carries SA values (1 / 0 / negative = default) and the summary bitmap (0 none, 1 where it pays, 2 everywhere)."""
+        top level carries SA values (1; 2 = and the lower levels where that pays; 0; negative = default) and the summary bitmap
+        (0 none, 1 where it pays, 2 everywhere)."""
         _chk(load().bwt_index_set_ktable_ex(self.h, int(k), int(wide), int(summary)))
 
     def set_options(self, **kw):
@@ -316,6 +317,12 @@ class Index:
         """(K, wide)"""
         v = int(load().bwt_index_ktable(self.h))
         return v & 15, bool(v & 16)
+
+    @property
+    def ktable_wide_levels(self):
+        """levels below the top one that are kept as 64-byte entries as well (set_ktable(15, 2) / the default on a large index)"""
+        v = int(load().bwt_index_ktable(self.h))
+        return [m for m in range(9, 15) if (v >> m) & 1]
 
     def ref1(self, off, length):
         out = np.empty(length, np.uint8)

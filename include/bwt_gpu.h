@@ -100,11 +100,14 @@ int bwt_index_device_bytes(const bwt_index *idx, uint64_t out[4]);
  * K: 0 = none (every task searched step by step), 8..15, <0 = default (by index size).
  * wide: 1 = the top level as 64-byte entries that also hold the first 14 SA values of the range, so that
  *   a task ending there needs no SA read and the seed kernel can cluster the read itself (64 * 4^K bytes:
- *   68.7 GB at K = 15); 0 = 8-byte entries throughout; <0 = default (on when K = 15 and it leaves
+ *   68.7 GB at K = 15); 2 = K = 15 only: also the LOWER levels where at least a quarter of the k-mers give a
+ *   task that ends there a seed list (a read's short last sub-read ends below the top: 12 bases of a 100-bp
+ *   read, 14 of a 150-bp one -- 1.1 GB for the 12-mers of a chromosome-sized index, 17 GB for the 14-mers of a
+ *   genome-sized one); 0 = 8-byte entries throughout; <0 = default (2 when K = 15 and the top level leaves
  *   >= 32 GB of HBM free).
  * Not to be called while a batch on this index is running. */
 int bwt_index_set_ktable(bwt_index *idx, int K, int wide);
-/* current K (0 = none), + 16 when the top level is wide */
+/* current K (0 = none), + 16 when the top level is wide, + 1 << m for every lower level m (9..14) that is kept wide as well */
 int bwt_index_ktable(const bwt_index *idx);
 /* the same with the summary bitmap of the 8-byte levels chosen explicitly: summary 0 = none, 1 = where it pays (the
  * default), 2 = on every level (tests) */

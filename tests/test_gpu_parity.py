@@ -351,7 +351,7 @@ def test_repeat_genome_all_cluster_paths():
     bases, off = lib.pack_reads(reads)
     exp = [orc.align_read(ofm, ref1, q) for q in reads]
     assert max(len(e) for e in exp if e) >= 6
-    for mode in ((0, 0), (12, 0), (15, 0), (15, 1)):
+    for mode in ((0, 0), (12, 0), (15, 0), (15, 1), (15, 2)):
         ix.set_ktable(*mode)
         out = ix.align_batch(bases, off)
         for i, q in enumerate(reads):
@@ -408,7 +408,7 @@ def test_table_modes_agree_at_scale():
                  synth_reads(ref, nreads // 4, length, seed + 20, n_frac=0.3, iupac_frac=0.05))
         bases, off = lib.pack_reads(reads)
         base = None
-        for mode in ((0, 0), (13, 0), (12, 1), (15, 0), (15, 1)):
+        for mode in ((0, 0), (13, 0), (12, 1), (15, 0), (15, 1), (15, 2)):
             ix.set_ktable(*mode)
             out = ix.align_batch(bases, off)
             if base is None:
@@ -444,7 +444,7 @@ def test_table_modes_agree_on_repeats():
             synth_reads(ref, 10_000, length, 6 + length, indel_frac=0.5, n_frac=0.1)
         bases, off = lib.pack_reads(reads)
         base = None
-        for mode in ((0, 0), (12, 0), (15, 0), (15, 1)):
+        for mode in ((0, 0), (12, 0), (15, 0), (15, 1), (15, 2)):
             ix.set_ktable(*mode)
             out = ix.align_batch(bases, off)
             if base is None:

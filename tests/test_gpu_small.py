@@ -123,7 +123,7 @@ def repeat_index():
     ix.close()
 
 
-@pytest.mark.parametrize("K,wide", [(15, 1), (15, 0), (12, 0), (0, 0)])
+@pytest.mark.parametrize("K,wide", [(15, 2), (15, 1), (15, 0), (12, 0), (0, 0)])
 def test_every_table_shape(repeat_index, K, wide):
     """K = 15 wide: k_seed_fast + in-kernel clustering; 15 narrow / 12: table + SA gathers (+ LF steps); 0: LF steps only"""
     from bwt_amd import lib
@@ -206,3 +206,33 @@ def test_worker_mirror_takes_a_whole_workload_message(gpu_index, ref_bytes):
     assert fm._small_batch.paths[1] >= 11 and fm._small_batch.paths[2] == 0
     fm._small_batch.close()
     fm._small_batch = None                                         # (the index belongs to the session fixture: not closed here)
+
+
+def test_widened_lower_levels_every_read_length(repeat_index):
+    """set_ktable(15, 2): the lower levels of the suffix-interval table where k-mers mostly have a seed list are kept as 64-byte
+    entries too, so that a read's short last sub-read (8 + Lq mod 8 bases) gets its seeds with its table line.  Read lengths whose
+    last sub-read ends at every level 9..15, against the table-less search (K = 0: the mode the oracle tests pin) and the oracle,
+    through both the general and the small-batch path."""
+    from bwt_amd import lib
+    ix, ref, seg, ofm, ref1 = repeat_index
+    ix.set_ktable(15, 2)
+    try:
+        levels = ix.ktable_wide_levels
+        assert ix.ktable == (15, True) and len(levels) >= 2, levels          # (1.5 M positions: the 10- and 11-mers mostly occur once or twice)
+        batches = {}
+        for length in (81, 82, 83, 84, 85, 86, 87, 88, 100, 150):
+            reads = mixed_reads(ref, 400, seed=length, length=length) + [seg[i:i + length] for i in range(0, 300 - length, 11)]
+            bases, off = lib.pack_reads(reads)
+            out = ix.align_batch(bases, off)
+            sb = lib.SmallBatch(ix)
+            got = sb.align(bases, off)
+            assert got["path"] == 1
+            sb.close()
+            same_tables(got, out)
+            batches[length] = (reads, bases, off, out)
+        assert oracle_check(batches[83][3], batches[83][0], ofm, ref1) > 300 and oracle_check(batches[100][3], batches[100][0], ofm, ref1) > 300
+        ix.set_ktable(0, 0)
+        for length, (reads, bases, off, out) in batches.items():
+            same_tables(ix.align_batch(bases, off), out)
+    finally:
+        ix.set_ktable(-1, -1)
