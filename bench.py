@@ -240,6 +240,7 @@ class HostPipeline:
         self.held = None
         self.done_at = []
         self.stage_ms, self.stage_n = {}, 0
+        self.ascii_sets, self.ascii_filled = None, {}
 
     def submit_next(self):
         total = self.n * self.length
@@ -248,6 +249,16 @@ class HostPipeline:
         if got is None:
             return False
         s, v = got
+        if self.ascii_sets is not None:
+            # the ASCII form: the slot's staging buffer holds the reads as text (filled once, where a FASTQ reader would write every
+            # batch); every submit PACKS them into the pinned buffers in the slot's thread, inside whatever is being timed
+            if s not in self.ascii_filled:
+                k = s % len(self.ascii_sets)
+                v["ascii"][:total] = self.ascii_sets[k]
+                self.ascii_filled[s] = k
+            self.filled[s] = self.ascii_filled[s]
+            self.pipe.submit_ascii(s, self.n, self.length)
+            return True
         if s not in self.filled:
             k = s % len(self.sets)
             codes, exc = self.sets[k]
@@ -267,7 +278,7 @@ class HostPipeline:
             r = self.pipe.wait()
             counts = r["counts"]
             hits += int(counts["n_hits"])
-            self.last_sizes = (len(r["hits"]), len(r["extra"]), len(r["cigar"]))
+            self.last_sizes = (len(r["hits"]), len(r["extra"]), len(r["cigar"]), len(r["narrow_off"]))
             for kk, vv in r["stage_ms"].items():
                 self.stage_ms[kk] = self.stage_ms.get(kk, 0.0) + vv
             self.stage_n += 1
@@ -386,6 +397,36 @@ def launch_ranks(n, check_only):
     return 0
 
 
+def repeat_rich_record(args):
+    """`python bench.py --workload grch38-repeats` as a child process -> the part of its line that goes into `repeat_rich`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "grch38-repeats", "--steps", str(max(4, args.steps // 2)),
+           "--warmup", str(min(args.warmup, 2)), "--cpu-budget", "5"]
+    if args.genome_len:
+        cmd += ["--genome-len", str(args.genome_len)]
+    if args.reads:
+        cmd += ["--reads", str(args.reads)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {"error": "the repeat-rich run did not finish within 420 s"}
+    lines = [ln for ln in r.stdout.decode("utf8", "replace").splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": "the repeat-rich run ended with exit code %d and %d JSON lines" % (r.returncode, len(lines))}
+    d = json.loads(lines[0])
+    cb = d.get("cpu_baseline", {})
+    return {"workload": d["config"]["workload"], "repeat_spectrum": d["config"]["repeat_spectrum"], "value": d["value"], "unit": d["unit"],
+            "ms_per_step": d["ms_per_step"], "steps": d["steps"], "value_is": d["value_is"],
+            "resident": {"reads_per_s": d["resident"]["reads_per_s"], "ms_per_step": d["resident"]["ms_per_step"]},
+            "dominant_kernel": d["dominant_kernel"], "kernels_ms_per_step": d["resident"]["kernels_ms_per_step"],
+            "counts_per_step": {k: d["counts_per_step"][k] for k in ("n_clusters", "n_dp", "n_banded", "n_hits", "n_handed_back", "n_float")},
+            "host_boundary": {k: d["host_boundary"][k] for k in ("bytes_up_per_read", "bytes_down_per_read", "steady_state_ms_per_batch")},
+            "parity_sample": cb.get("parity_sample"), "parity_aggregate": cb.get("parity_aggregate"),
+            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}, "wall_s": time.perf_counter() - t0}
+
+
 def load_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -410,6 +451,10 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="slots of the host pipeline (0 = the default)")
     ap.add_argument("--ktable", default="", help="K,wide: suffix-interval table depth and whether its top level carries SA values (default: the "
                                                  "library's choice for the index, K=15 wide at GRCh38 scale: 71.6 GB); e.g. 15,0 = 11.5 GB, 0,0 = none")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-repeat-rich", action="store_true",
+                    help="the default run (workload grch38, one GPU) also times the repeat-rich genome -- in a child process, after this one has "
+                         "released the GPU -- and reports it as `repeat_rich` in the same line; this switches that off")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse the start of the ranks only: every rank reports rank / world and exits before any GPU is touched")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -537,7 +582,9 @@ def main():
         # RCCL hit gather (the path's one exchange step): the batch's compact table, device to device into the send buffer (read
         # ids made global on the way), then one asynchronous gather to rank 0 that overlaps the next batches' work
         c = r["counts"]
-        prev, (h, x, t) = gatherer.begin(len(r["hits"]), len(r["extra"]), len(r["cigar"]))
+        # (the exchange carries 16-byte records: the slot's table is widened on the device by bwt_batch_compact_to_device; a read with a
+        # narrow record is one more record there)
+        prev, (h, x, t) = gatherer.begin(len(r["hits"]) + len(r["narrow_off"]), len(r["extra"]), len(r["cigar"]))
         note(prev)
         slot_batch = lib.Batch(ix, handle=pipe.batch_handle(r["slot"]))
         slot_batch.compact_to_device(h.data_ptr(), h.shape[0], x.data_ptr(), x.shape[0], t.data_ptr(), t.shape[0], lo)
@@ -566,7 +613,7 @@ def main():
         # (with the exchange step a fourth slot: the copy into the gather's send buffer is a small kernel that has to wait for CUs
         # while another slot's persistent seed kernel runs, and the slot it belongs to cannot be released before it is done)
         depth = args.depth or (4 if gather else 3)
-        hp = HostPipeline(ix, packed_sets, n_reads, length, depth=depth, options=opts, on_result=exchange if gather else None)
+        hp = HostPipeline(ix, packed_sets, n_reads, length, depth=depth, options=dict({"hits_narrow": 1}, **opts), on_result=exchange if gather else None)
         hp.run(depth)                                       # untimed set-up: every slot's device and pinned buffers at their final sizes
         hp.run(args.warmup)
         drain()
@@ -584,6 +631,24 @@ def main():
         add_times(hp.pipe.kernel_times())
         last_set, last_hits = hp.take_last()
         hp.pipe.profile(False)
+        # the same pipe fed ASCII: every batch is packed to two bits per base by the slot's thread inside the timed region (ADVICE r3:
+        # `value` re-uploads buffers that were packed once; a feeder that packs every batch cannot outrun its packer).  Reported beside
+        # `value`, never as it.
+        with_pack = None
+        if not gather:
+            hp.ascii_sets = [b_ for b_, _ in read_sets]
+            hp.filled = {}
+            hp.keep_last = False
+            hp.run(depth)                                   # (staging buffers filled, untimed)
+            k_ = max(3, min(args.steps, 8))
+            sync()
+            t0p = time.perf_counter()
+            hp.run(k_)
+            sync()
+            dtp = time.perf_counter() - t0p
+            with_pack = {"reads_per_s": n_reads * world * k_ / dtp, "ms_per_batch": dtp / k_ * 1e3, "batches": k_,
+                         "what": "ASCII reads in host memory -> packed by the slot's thread (bwt_pipe_submit_ascii) -> the same pipeline"}
+            hp.ascii_sets = None
         if gather and rank == 0:
             counts["gathered_hits"], counts["gathered_extras"] = gathered
     else:
@@ -719,13 +784,16 @@ def main():
         }
         if hp is not None:
             up = sum(len(c_) * 4 + len(e_) * 8 for c_, e_ in packed_sets) / len(packed_sets)
-            down = hp.last_sizes[0] * 16 + hp.last_sizes[1] * 16 + hp.last_sizes[2] + n_reads
+            down = hp.last_sizes[0] * 16 + hp.last_sizes[1] * 16 + hp.last_sizes[2] + n_reads + hp.last_sizes[3] * 6
             line["host_boundary"] = {"bytes_up_per_read": up / n_reads, "bytes_down_per_read": down / n_reads,
                                      "steady_state_ms_per_batch": steady * 1e3, "steady_state_reads_per_s": n_reads * world / steady,
                                      "host_pack_reads_per_s": 2 * n_reads / t_pack,
+                                     "with_host_packing_in_the_timed_region": with_pack,
                                      "extras_per_batch": hp.last_sizes[1],
                                      "slot_thread_ms_per_batch": {kk: vv / max(1, hp.stage_n) for kk, vv in hp.stage_ms.items()},
-                                     "what": "2-bit codes + exception list up, 16-byte hit records + 1 status byte per read + extras down"}
+                                     "narrow_reads_per_batch": hp.last_sizes[3],
+                                     "what": "2-bit codes + exception list up; down: 1 status byte per read, 6 bytes (window offset u32 + score i16) for a read "
+                                             "whose answer is one plain hit, 16-byte records + extras for every other hit"}
             line["resident"] = {"reads_per_s": n_reads * world * args.steps / dt_res, "ms_per_step": dt_res / args.steps * 1e3,
                                 "what": "the same steps with the reads already in HBM and the hit tables left there (rounds 1-2 `value`)",
                                 "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(kt_res.items())}}
@@ -744,16 +812,23 @@ def main():
                               "dp_cells_per_s": counts["sw_cells"] * counts["n_dp"] / max(counts["n_clusters"], 1) / t_dp if t_dp else None}
         if not args.no_cpu_baseline and world == 1:
             cb_bases, cb_off = read_sets[last_set]
-            line["cpu_baseline"] = cpu_baseline(ix, ref, cb_bases, cb_off, length, 0 if stages == lib.STAGE_SEARCH else 1, hits=last_hits)
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+            line["cpu_baseline"] = cpu_baseline(ix, ref, cb_bases, cb_off, length, 0 if stages == lib.STAGE_SEARCH else 1, budget_s=args.cpu_budget, hits=last_hits)
     if hp is not None:
         hp.close()
     for b_ in batches:
         b_.destroy()
     ix.close()
+    if rank == 0:
+        if wl == "grch38" and world == 1 and not args.no_repeat_rich and not args.no_pipeline:
+            # The i.i.d. contig is the best case for every shortcut of the path (one cluster per read, the prefilter settles 99.99 % of
+            # the candidates): the same measurement on the REPEAT-RICH genome (41 % planted repeats, see synth_genome_repeats) belongs
+            # beside it.  A child process of this script, started now that this one has given the GPU back; its line is folded in.
+            del ref, bases, bases2, read_sets, packed_sets
+            line["repeat_rich"] = repeat_rich_record(args)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -430,6 +430,13 @@ struct bwt_batch {
     DevBuf h_rec, h_woff, h_wlen, h_cigoff, h_cig, pairs;
     DevBuf r_nx, r_xcb, x_off, xcb_off, x_rec, x_cig, h_xidx, h_len;    // compact table: extras of the hits that are not plain
     bool expanded = false;             // h_woff / h_wlen / h_cigoff / h_cig hold the expansion of the current compact table
+    // the NARROW form of the table (bwt_options.hits_narrow): reads whose answer is one plain hit are out of h_rec; their window offset
+    // and score sit in n_woff / n_score (in read order), r_status says 2 for them.  Entry points that hand out the 16-byte form
+    // widen the table first (ensure_v1: k_hits_widen into the w_* buffers, which then take the places of h_rec / x_rec / hit_off /
+    // r_status).
+    bool narrow = false;
+    uint64_t n_narrow = 0;
+    DevBuf r_nn, nn_off, n_woff, n_score, w_rec, w_xrec, w_hoff, w_status;
     // counters
     DevBuf ctr;
     Counters hctr{};
@@ -507,22 +514,24 @@ static int dev_scan(bwt_batch *b, const uint32_t *in, uint64_t *out, uint64_t n)
 
 // three scans of the same length (the hit, extra and CIGAR-byte offsets of a batch): one set of launches
 static int dev_scan3(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
-                     uint64_t *out2, uint64_t n) {
+                     uint64_t *out2, uint64_t n, const uint32_t *in3, uint64_t *out3) {
+    // (in3 / out3: a fourth array in the same launches, or null)
     if (n <= SCAN_TILE) {
         int rc = dev_scan(b, in0, out0, n);
         if (!rc) rc = dev_scan(b, in1, out1, n);
-        return rc ? rc : dev_scan(b, in2, out2, n);
+        if (!rc) rc = dev_scan(b, in2, out2, n);
+        return rc || !in3 ? rc : dev_scan(b, in3, out3, n);
     }
-    const uint32_t nb = std::max<uint32_t>(1, cdiv(n, SCAN_TILE));
-    int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8 * 3);
+    const uint32_t nb = std::max<uint32_t>(1, cdiv(n, SCAN_TILE)), na = in3 ? 4u : 3u;
+    int rc = b->scan_tmp.ensure(((size_t)nb + 1) * 8 * 4);
     if (rc) return rc;
     ScanPair p;
-    p.in[0] = in0; p.in[1] = in1; p.in[2] = in2; p.out[0] = out0; p.out[1] = out1; p.out[2] = out2;
-    p.bsum[0] = b->scan_tmp.as<uint64_t>(); p.bsum[1] = p.bsum[0] + nb + 1; p.bsum[2] = p.bsum[1] + nb + 1;
+    p.in[0] = in0; p.in[1] = in1; p.in[2] = in2; p.in[3] = in3; p.out[0] = out0; p.out[1] = out1; p.out[2] = out2; p.out[3] = out3;
+    p.bsum[0] = b->scan_tmp.as<uint64_t>(); p.bsum[1] = p.bsum[0] + nb + 1; p.bsum[2] = p.bsum[1] + nb + 1; p.bsum[3] = p.bsum[2] + nb + 1;
     ProfScope ps(b, "scan");
-    hipLaunchKernelGGL(k_scan1_pair, dim3(nb, 3), dim3(SCAN_BLOCK), 0, b->stream, p, n);
-    hipLaunchKernelGGL(k_scan2_pair, dim3(1, 3), dim3(SCAN_BLOCK), 0, b->stream, p, nb);
-    hipLaunchKernelGGL(k_scan3_pair, dim3(nb, 3), dim3(SCAN_BLOCK), 0, b->stream, p, n, nb);
+    hipLaunchKernelGGL(k_scan1_pair, dim3(nb, na), dim3(SCAN_BLOCK), 0, b->stream, p, n);
+    hipLaunchKernelGGL(k_scan2_pair, dim3(1, na), dim3(SCAN_BLOCK), 0, b->stream, p, nb);
+    hipLaunchKernelGGL(k_scan3_pair, dim3(nb, na), dim3(SCAN_BLOCK), 0, b->stream, p, n, nb);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -577,7 +586,8 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->cigb_off, &b->pos, &b->scan_tmp, &b->c_read, &b->c_S, &b->c_D, &b->c_qoff, &b->c_qlen,
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->tqw, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
-                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs};
+                     &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs,
+                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -767,6 +777,7 @@ static int ascii_all(bwt_batch *b) {
 }
 
 static int ensure_expanded(bwt_batch *b);
+static int ensure_v1(bwt_batch *b);
 
 // ------------------------------------------------------------------------------------------------
 // Reverse strand and pairing: what the reference does not have (src/fastq.erl:43-50 is an unused helper).
@@ -867,10 +878,11 @@ extern "C" int bwt_batch_pair_hits(bwt_batch *b, uint32_t n_pairs, int32_t min_i
     if ((uint64_t)n_pairs * 4 != b->n) return fail(BWT_EINVAL, "bwt_batch_pair_hits: the batch must hold both strands of 2 * n_pairs interleaved mates");
     if (min_insert < 0 || max_insert < min_insert) return fail(BWT_EINVAL, "bwt_batch_pair_hits: bad insert range");
     if (!pairs && n_pairs) return fail(BWT_EINVAL, "bwt_batch_pair_hits: null argument");
-    if (b->n_hits > 0xfffffffeull) return fail(BWT_EINVAL, "bwt_batch_pair_hits: more than 2^32 - 2 hits");
-    if (!n_pairs) return 0;
     HIPCHK(hipSetDevice(b->device));
     int rc;
+    if ((rc = ensure_v1(b))) return rc;
+    if (b->n_hits > 0xfffffffeull) return fail(BWT_EINVAL, "bwt_batch_pair_hits: more than 2^32 - 2 hits");
+    if (!n_pairs) return 0;
     if ((rc = ensure_expanded(b)) || (rc = b->pairs.ensure((size_t)n_pairs * sizeof(PairRec)))) return rc;
     if ((rc = b->h_len.ensure((b->n_hits + 1) * 4))) return rc;              // (h_len is free again once the expansion is done: the spans go there)
     if (b->n_hits)
@@ -1429,7 +1441,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
 }
 
 static int dev_scan3(bwt_batch *b, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
-                     uint64_t *out2, uint64_t n);
+                     uint64_t *out2, uint64_t n, const uint32_t *in3, uint64_t *out3);
 
 static int stage_hits(bwt_batch *b, int32_t shift) {
     const uint32_t n = b->n;
@@ -1439,6 +1451,13 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
     if ((rc = b->r_nhit.ensure((size_t)n * 4 + 4)) || (rc = b->r_nx.ensure((size_t)n * 4 + 4)) || (rc = b->r_xcb.ensure((size_t)n * 4 + 4)) ||
         (rc = b->r_status.ensure((size_t)n + 4)) || (rc = b->hit_off.ensure(((size_t)n + 1) * 8)) ||
         (rc = b->x_off.ensure(((size_t)n + 1) * 8)) || (rc = b->xcb_off.ensure(((size_t)n + 1) * 8)))
+        return rc;
+    b->narrow = false; b->n_narrow = 0;
+    // the narrow form: on request, and only where a score fits 16 bits (2 Lq <= 32766; a window offset always fits 32: an index has
+    // fewer than 2^32 - 70000 rows)
+    const bool nar = n && b->ix && b->opt.hits_narrow == 1 && b->max_lq <= 16383;
+    if (nar && ((rc = b->r_nn.ensure((size_t)n * 4 + 4)) || (rc = b->nn_off.ensure(((size_t)n + 1) * 8)) ||
+                (rc = b->n_woff.ensure((size_t)n * 4 + 16)) || (rc = b->n_score.ensure((size_t)n * 2 + 16))))
         return rc;
     if (n == 0) {                                   // empty batch: empty, but well-formed, hit tables
         b->n_hits = 0; b->cig_bytes = 0; b->n_extra = 0; b->xcig_bytes = 0;
@@ -1450,9 +1469,10 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
     HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->cig_total, 0, 8, b->stream));     // (a retry with wider CIGAR slots counts again)
     KLAUNCH(b, "hits_count", k_hits_count, std::min<uint32_t>(cdiv(n, 256), 2048), 256, n, b->clus_off.as<uint64_t>(), b->c_status.as<int32_t>(),
             b->c_ciglen.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->r_nhit.as<uint32_t>(), b->r_nx.as<uint32_t>(), b->r_xcb.as<uint32_t>(),
-            b->r_status.as<int8_t>(), b->ctr.as<Counters>());
+            b->r_status.as<int8_t>(), b->ctr.as<Counters>(), nar ? b->r_nn.as<uint32_t>() : (uint32_t *)nullptr);
     if ((rc = dev_scan3(b, b->r_nhit.as<uint32_t>(), b->hit_off.as<uint64_t>(), b->r_nx.as<uint32_t>(), b->x_off.as<uint64_t>(),
-                        b->r_xcb.as<uint32_t>(), b->xcb_off.as<uint64_t>(), n)))
+                        b->r_xcb.as<uint32_t>(), b->xcb_off.as<uint64_t>(), n, nar ? (const uint32_t *)b->r_nn.as<uint32_t>() : nullptr,
+                        nar ? b->nn_off.as<uint64_t>() : nullptr)))
         return rc;
     // the hit tables are sized by their bounds (a hit per candidate, a full text slot per hit), so that nothing has to come
     // back to the host before k_hits_write: the totals are read once, together with the counters, when everything is queued
@@ -1462,10 +1482,11 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
     KLAUNCH(b, "hits_write", k_hits_write, cdiv(n, 256), 256, n, shift, b->clus_off.as<uint64_t>(),
             b->hit_off.as<uint64_t>(), b->x_off.as<uint64_t>(), b->xcb_off.as<uint64_t>(), b->r_status.as<int8_t>(), b->c_status.as<int32_t>(),
             b->c_score.as<int32_t>(), b->c_ciglen.as<uint32_t>(), b->c_S.as<uint32_t>(), b->c_wlen.as<uint32_t>(),
-            b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->x_rec.as<HitExtra>(), b->x_cig.as<uint8_t>());
-    uint64_t tot[3] = {0, 0, 0};
+            b->cig.as<uint8_t>(), b->cig_stride, b->h_rec.as<HitRec>(), b->x_rec.as<HitExtra>(), b->x_cig.as<uint8_t>(),
+            nar ? (const uint64_t *)b->nn_off.as<uint64_t>() : nullptr, b->n_woff.as<uint32_t>(), b->n_score.as<int16_t>());
+    uint64_t tot[4] = {0, 0, 0, 0};
     if ((rc = mail(b, &tot[0], b->hit_off.as<uint64_t>() + n, 8)) || (rc = mail(b, &tot[1], b->x_off.as<uint64_t>() + n, 8)) ||
-        (rc = mail(b, &tot[2], b->xcb_off.as<uint64_t>() + n, 8)))
+        (rc = mail(b, &tot[2], b->xcb_off.as<uint64_t>() + n, 8)) || (nar && (rc = mail(b, &tot[3], b->nn_off.as<uint64_t>() + n, 8))))
         return rc;
     if ((rc = fetch_counters(b))) return rc;                                   // sync
     HIPCHK(hipGetLastError());
@@ -1475,7 +1496,35 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
         b->n_hits = 0; b->n_extra = 0; b->xcig_bytes = 0; b->cig_bytes = 0;
         return fail(BWT_EOVERFLOW, "batch produced more than 2^32-1 hits or bytes of CIGAR text in its compact table: split it");
     }
+    if (tot[0] + tot[3] > 0xffffffffull) {
+        b->n_hits = 0; b->n_extra = 0; b->xcig_bytes = 0; b->cig_bytes = 0;
+        return fail(BWT_EOVERFLOW, "batch produced more than 2^32-1 hits: split it");
+    }
     b->n_hits = tot[0]; b->n_extra = tot[1]; b->xcig_bytes = tot[2]; b->cig_bytes = b->hctr.cig_total;
+    b->narrow = nar; b->n_narrow = tot[3];
+    return 0;
+}
+
+// a table made in the narrow form back into the 16-byte form, in place of it (entry points that hand out records)
+static int ensure_v1(bwt_batch *b) {
+    if (!b->narrow) return 0;
+    const uint32_t n = b->n;
+    const uint64_t nh = b->n_hits + b->n_narrow;
+    int rc;
+    if ((rc = b->w_rec.ensure((nh + 1) * 16)) || (rc = b->w_xrec.ensure((b->n_extra + 1) * 16)) || (rc = b->w_hoff.ensure(((size_t)n + 1) * 8)) ||
+        (rc = b->w_status.ensure((size_t)n + 4)))
+        return rc;
+    const int32_t shift = b->ix ? b->ix->shift : 0;
+    KLAUNCH(b, "hits_widen", k_hits_widen, (uint32_t)std::min<uint64_t>(cdiv((uint64_t)n + 1, 256), 8192), 256, n, shift, (const int8_t *)b->r_status.as<int8_t>(),
+            (const uint64_t *)b->hit_off.as<uint64_t>(), (const uint64_t *)b->nn_off.as<uint64_t>(), (const HitRec *)b->h_rec.as<HitRec>(),
+            (const uint32_t *)b->n_woff.as<uint32_t>(), (const int16_t *)b->n_score.as<int16_t>(), b->w_rec.as<HitRec>(), b->w_hoff.as<uint64_t>(),
+            b->w_status.as<int8_t>());
+    if (b->n_extra)
+        KLAUNCH(b, "hits_widen", k_extras_widen, (uint32_t)std::min<uint64_t>(cdiv(b->n_extra, 256), 8192), 256, b->n_extra, (const HitExtra *)b->x_rec.as<HitExtra>(),
+                (const HitRec *)b->h_rec.as<HitRec>(), (const uint64_t *)b->nn_off.as<uint64_t>(), b->w_xrec.as<HitExtra>());
+    HIPCHK(hipGetLastError());
+    std::swap(b->h_rec, b->w_rec); std::swap(b->x_rec, b->w_xrec); std::swap(b->hit_off, b->w_hoff); std::swap(b->r_status, b->w_status);
+    b->n_hits = nh; b->n_narrow = 0; b->narrow = false; b->expanded = false;
     return 0;
 }
 
@@ -1483,8 +1532,9 @@ static int stage_hits(bwt_batch *b, int32_t shift) {
 // asks for them
 static int ensure_expanded(bwt_batch *b) {
     if (b->expanded) return 0;
-    const uint64_t nh = b->n_hits;
     int rc;
+    if ((rc = ensure_v1(b))) return rc;
+    const uint64_t nh = b->n_hits;
     if ((rc = b->h_woff.ensure((nh + 1) * 8)) || (rc = b->h_wlen.ensure((nh + 1) * 4)) || (rc = b->h_cigoff.ensure((nh + 2) * 8)) ||
         (rc = b->h_cig.ensure(b->cig_bytes + 16)) || (rc = b->h_xidx.ensure((nh + 1) * 4)) || (rc = b->h_len.ensure((nh + 1) * 4)))
         return rc;
@@ -1560,7 +1610,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     if (counts) {
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;
-        counts->n_hits = b->n_hits; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
+        counts->n_hits = b->n_hits + b->n_narrow; counts->cigar_bytes = b->cig_bytes; counts->window_bytes = b->hctr.window_bytes;
         counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
         // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
         if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
@@ -1643,8 +1693,9 @@ extern "C" int bwt_batch_fetch_hits(bwt_batch *b, int32_t *read_status, uint64_t
                                     uint64_t cig_cap, uint64_t needed[2]) {
     if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits: extend stage not run");
     HIPCHK(hipSetDevice(b->device));
-    if (needed) { needed[0] = b->n_hits; needed[1] = b->cig_bytes; }
     int rc;
+    if ((rc = ensure_v1(b))) return rc;
+    if (needed) { needed[0] = b->n_hits; needed[1] = b->cig_bytes; }
     if ((rc = fetch_status32(b, read_status)) || (rc = d2h(b, hit_off, b->hit_off, (size_t)b->n + 1))) return rc;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->n_hits > hit_cap || b->cig_bytes > cig_cap) return fail(BWT_ENOSPC, "hit / cigar capacity too small");
@@ -1665,6 +1716,7 @@ extern "C" int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint
     static_assert(sizeof(bwt_hit_rec) == sizeof(HitRec), "bwt_hit_rec is the device record");
     if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits_raw: extend stage not run");
     HIPCHK(hipSetDevice(b->device));
+    { int rc0 = ensure_v1(b); if (rc0) return rc0; }
     if (needed) { needed[0] = b->n_hits; needed[1] = b->cig_bytes; }
     if ((hits || win_off || win_len || cig_off) && b->n_hits > hit_cap) return fail(BWT_ENOSPC, "hit capacity too small");
     if (cigar && b->cig_bytes > cig_cap) return fail(BWT_ENOSPC, "cigar capacity too small");
@@ -1685,6 +1737,7 @@ extern "C" int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, b
     static_assert(sizeof(bwt_hit_extra) == sizeof(HitExtra), "bwt_hit_extra is the device record");
     if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits_compact: extend stage not run");
     HIPCHK(hipSetDevice(b->device));
+    { int rc0 = ensure_v1(b); if (rc0) return rc0; }
     if (needed) { needed[0] = b->n_hits; needed[1] = b->n_extra; needed[2] = b->xcig_bytes; }
     if ((hits && b->n_hits > hit_cap) || (extra && b->n_extra > extra_cap) || (cigar && b->xcig_bytes > cig_cap))
         return fail(BWT_ENOSPC, "hit / extra / cigar capacity too small");
@@ -1697,9 +1750,30 @@ extern "C" int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, b
     return 0;
 }
 
+// the table as the device made it under bwt_options.hits_narrow (a batch run without the option, or one whose reads are too long
+// for 16-bit scores, simply has no narrow reads: everything is in the record stream)
+extern "C" int bwt_batch_fetch_hits_narrow(bwt_batch *b, int8_t *read_status, uint32_t *narrow_off, int16_t *narrow_score, bwt_hit_rec *hits,
+                                           bwt_hit_extra *extra, char *cigar, uint64_t narrow_cap, uint64_t hit_cap, uint64_t extra_cap, uint64_t cig_cap,
+                                           uint64_t needed[4]) {
+    if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_fetch_hits_narrow: extend stage not run");
+    HIPCHK(hipSetDevice(b->device));
+    if (needed) { needed[0] = b->n_narrow; needed[1] = b->n_hits; needed[2] = b->n_extra; needed[3] = b->xcig_bytes; }
+    if (((narrow_off || narrow_score) && b->n_narrow > narrow_cap) || (hits && b->n_hits > hit_cap) || (extra && b->n_extra > extra_cap) ||
+        (cigar && b->xcig_bytes > cig_cap))
+        return fail(BWT_ENOSPC, "narrow / hit / extra / cigar capacity too small");
+    if (!read_status && !narrow_off && !narrow_score && !hits && !extra && !cigar) return (b->n_narrow || b->n_hits || b->n_extra || b->xcig_bytes) ? BWT_ENOSPC : 0;
+    int rc;
+    if ((rc = d2h(b, read_status, b->r_status, b->n)) || (rc = d2h(b, narrow_off, b->n_woff, b->n_narrow)) || (rc = d2h(b, narrow_score, b->n_score, b->n_narrow)) ||
+        (rc = d2h(b, (HitRec *)hits, b->h_rec, b->n_hits)) || (rc = d2h(b, (HitExtra *)extra, b->x_rec, b->n_extra)) || (rc = d2h(b, cigar, b->x_cig, b->xcig_bytes)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
 extern "C" int bwt_batch_hits_to_device(bwt_batch *b, void *dev_dst, uint64_t cap_hits) {
     if (!b || !(b->done & BWT_STAGE_EXTEND) || !dev_dst) return fail(BWT_EINVAL, "bwt_batch_hits_to_device: not ready");
     HIPCHK(hipSetDevice(b->device));
+    { int rc0 = ensure_v1(b); if (rc0) return rc0; }
     if (b->n_hits > cap_hits) return fail(BWT_ENOSPC, "hit capacity too small");
     if (b->n_hits) HIPCHK(hipMemcpyAsync(dev_dst, b->h_rec.p, b->n_hits * 16, hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1716,6 +1790,7 @@ __global__ __launch_bounds__(256) static void k_hits_global(const HitRec *__rest
 extern "C" int bwt_batch_hits_to_device_global(bwt_batch *b, void *dev_dst, uint64_t cap_hits, uint32_t read_base) {
     if (!b || !(b->done & BWT_STAGE_EXTEND) || !dev_dst) return fail(BWT_EINVAL, "bwt_batch_hits_to_device_global: not ready");
     HIPCHK(hipSetDevice(b->device));
+    { int rc0 = ensure_v1(b); if (rc0) return rc0; }
     if (b->n_hits > cap_hits) return fail(BWT_ENOSPC, "hit capacity too small");
     if (b->n_hits)
         hipLaunchKernelGGL(k_hits_global, dim3((uint32_t)std::min<uint64_t>(cdiv(b->n_hits, 256), 4096)), dim3(256), 0, b->stream,
@@ -1730,8 +1805,9 @@ extern "C" int bwt_batch_hits_to_device_global(bwt_batch *b, void *dev_dst, uint
 extern "C" int bwt_batch_compact_to_device(bwt_batch *b, void *dst_hits, uint64_t cap_hits, void *dst_extra, uint64_t cap_extra,
                                            void *dst_cigar, uint64_t cap_cigar, uint32_t read_base) {
     if (!b || !(b->done & BWT_STAGE_EXTEND)) return fail(BWT_EINVAL, "bwt_batch_compact_to_device: extend stage not run");
-    if ((!dst_hits && b->n_hits) || (!dst_extra && b->n_extra) || (!dst_cigar && b->xcig_bytes)) return fail(BWT_EINVAL, "bwt_batch_compact_to_device: null destination");
     HIPCHK(hipSetDevice(b->device));
+    { int rc0 = ensure_v1(b); if (rc0) return rc0; }
+    if ((!dst_hits && b->n_hits) || (!dst_extra && b->n_extra) || (!dst_cigar && b->xcig_bytes)) return fail(BWT_EINVAL, "bwt_batch_compact_to_device: null destination");
     if (b->n_hits > cap_hits || b->n_extra > cap_extra || b->xcig_bytes > cap_cigar) return fail(BWT_ENOSPC, "bwt_batch_compact_to_device: capacity too small");
     if (b->n_hits)
         hipLaunchKernelGGL(k_hits_global, dim3((uint32_t)std::min<uint64_t>(cdiv(b->n_hits, 256), 4096)), dim3(256), 0, b->stream,

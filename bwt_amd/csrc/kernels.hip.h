@@ -330,7 +330,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(uint64_t *bsum, uint32_t n
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
                                                        const uint64_t *__restrict__ bsum, uint64_t n, uint32_t nb) { scan3_body(in, out, bsum, n, nb); }
 // two arrays of the same length in one set of launches (blockIdx.y picks the array): half the launches of two scans
-struct ScanPair { const uint32_t *in[3]; uint64_t *out[3]; uint64_t *bsum[3]; };
+struct ScanPair { const uint32_t *in[4]; uint64_t *out[4]; uint64_t *bsum[4]; };
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan1_pair(ScanPair p, uint64_t n) { scan1_body(p.in[blockIdx.y], p.bsum[blockIdx.y], n); }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2_pair(ScanPair p, uint32_t nb) { scan2_body(p.bsum[blockIdx.y], nb); }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3_pair(ScanPair p, uint64_t n, uint32_t nb) {
@@ -3568,7 +3568,11 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
                                                      const uint32_t *__restrict__ c_ciglen,
                                                      const uint32_t *__restrict__ r_qty,
                                                      uint32_t *__restrict__ r_nhit, uint32_t *__restrict__ r_nx,
-                                                     uint32_t *__restrict__ r_xcb, int8_t *__restrict__ r_status, Counters *ctr) {
+                                                     uint32_t *__restrict__ r_xcb, int8_t *__restrict__ r_status, Counters *ctr,
+                                                     uint32_t *__restrict__ r_nn) {
+    // r_nn != null: the NARROW form of the table (include/bwt_gpu.h, bwt_batch_fetch_hits_narrow): a read whose answer is exactly one
+    // plain hit takes no record in the hit stream -- r_nn[r] = 1, status 2 -- and k_hits_write files its window offset and score
+    // in the narrow arrays instead (6 bytes where a record is 16)
     // grid-stride over a capped grid: one atomic per wave for the whole launch (same-address atomics are rated at ~88 per us:
     // one per wave of a 12.5 M-read batch would be 2 ms of them).  Lane per read -- but a read with more than HITS_FAT candidates
     // (low-complexity reads have tens of thousands) is taken by the whole wave, 64 candidates at a time: as one lane's loop it was
@@ -3606,7 +3610,9 @@ __global__ __launch_bounds__(256) void k_hits_count(uint32_t n, const uint64_t *
         }
         if (st == -2) { nh = 0; nx = 0; xcb = 0; cbr = 0; }
         cb += cbr;
-        if (valid) { r_nhit[r] = nh; r_nx[r] = nx; r_xcb[r] = xcb; r_status[r] = (int8_t)st; }
+        const bool nar = r_nn != nullptr && st == 0 && nh == 1 && nx == 0;
+        if (nar) { nh = 0; st = 2; }
+        if (valid) { r_nhit[r] = nh; r_nx[r] = nx; r_xcb[r] = xcb; r_status[r] = (int8_t)st; if (r_nn) r_nn[r] = nar ? 1u : 0u; }
     }
     cb = wave_sum_u64(cb);
     if (lane == 0 && cb) atomicAdd(&ctr->cig_total, cb);
@@ -3658,8 +3664,15 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
                                                      const uint32_t *__restrict__ c_S, const uint32_t *__restrict__ c_wlen,
                                                      const uint8_t *__restrict__ cig, uint32_t cig_stride,
                                                      HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec,
-                                                     uint8_t *__restrict__ x_cig) {
+                                                     uint8_t *__restrict__ x_cig, const uint64_t *__restrict__ nn_off,
+                                                     uint32_t *__restrict__ n_woff, int16_t *__restrict__ n_score) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    if (nn_off && r < n && r_status[r] == 2) {
+        // the narrow form: this read's one plain hit as {window offset into Ref1 (= Pos - Shift + 200, src/worker_bwt.erl:86-94), score}
+        const uint64_t o = nn_off[r];
+        for (uint64_t k = clus_off[r]; k < clus_off[r + 1]; k++)
+            if (c_status[k] == CS_OK) { n_woff[o] = c_S[k] - c_wlen[k] + BWT_REF_EXT; n_score[o] = (int16_t)c_score[k]; break; }
+    }
     const bool live0 = r < n && r_status[r] == 0;
     const uint64_t a = live0 ? clus_off[r] : 0ull, b = live0 ? clus_off[r + 1] : 0ull;
     uint64_t ho = live0 ? hit_off[r] : 0ull;
@@ -3697,6 +3710,35 @@ __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, c
             fho += (uint64_t)__popcll(mok); fxo += (uint64_t)__popcll(mex);
             fco += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
+    }
+}
+
+// ---- the narrow form back into the 16-byte form (on demand: a caller of the per-hit / compact / device-to-device entry points on a
+// batch whose table was made narrow).  Lane per read: its records move up by the number of narrow reads before it, a narrow read's
+// record is rebuilt; lane per extra: the hit it names moves likewise.
+__global__ __launch_bounds__(256) void k_hits_widen(uint32_t n, int32_t shift, const int8_t *__restrict__ st_in, const uint64_t *__restrict__ hit_off,
+                                                     const uint64_t *__restrict__ nn_off, const HitRec *__restrict__ h_in,
+                                                     const uint32_t *__restrict__ n_woff, const int16_t *__restrict__ n_score,
+                                                     HitRec *__restrict__ h_out, uint64_t *__restrict__ hit_off_out, int8_t *__restrict__ st_out) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += gridDim.x * blockDim.x) {
+        const uint64_t o = hit_off[r] + nn_off[r];
+        hit_off_out[r] = o;
+        if (r == n) break;
+        const int8_t st = st_in[r];
+        st_out[r] = st == 2 ? 0 : st;
+        if (st == 2) {
+            HitRec h; h.read = r; h.score = n_score[nn_off[r]]; h.pos = (int64_t)n_woff[nn_off[r]] - BWT_REF_EXT + shift;
+            h_out[o] = h;
+        } else
+            for (uint64_t k = hit_off[r]; k < hit_off[r + 1]; k++) h_out[o + (k - hit_off[r])] = h_in[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_extras_widen(uint64_t nx, const HitExtra *__restrict__ x_in, const HitRec *__restrict__ h_in,
+                                                       const uint64_t *__restrict__ nn_off, HitExtra *__restrict__ x_out) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nx; k += (uint64_t)gridDim.x * blockDim.x) {
+        HitExtra x = x_in[k];
+        x.hit += (uint32_t)nn_off[h_in[x.hit].read];
+        x_out[k] = x;
     }
 }
 

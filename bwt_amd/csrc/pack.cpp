@@ -89,44 +89,73 @@ extern "C" int bwt_pack_reads(const uint8_t *bases, uint64_t total, uint32_t *co
 // The same expansion as k_hits_expand, on the host, for a compact table that has left the device (pipe results, gathered tables).
 // Every index and offset of the table is checked against its array: a table from elsewhere (another rank, a file) cannot make this
 // read or write out of bounds.
+// (one decoder for both forms of the table: the narrow form's reads with status 2 take their hit from the narrow arrays, in read
+// order; without them -- read_status null or no 2 in it -- this is the compact table's expansion)
+extern "C" int bwt_hits_expand_narrow(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const int8_t *read_status,
+                                      const uint32_t *narrow_off, const int16_t *narrow_score, uint64_t n_narrow, const bwt_hit_rec *hits, uint64_t n_hits,
+                                      const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t xcigar_len, uint64_t *hit_off,
+                                      int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar,
+                                      uint64_t cig_cap, uint64_t *cig_needed) {
+    enum { REF_EXT = 200 };                                   // ?REF_EXTENSION_LEN, src/worker_bwt.erl:17 (bwt_constants().ref_extension_len)
+    if ((!hits && n_hits) || (!extra && n_extra) || (!xcigar && xcigar_len) || (!read_len && !off && (n_hits || n_narrow)) ||
+        (n_narrow && (!read_status || !narrow_off || !narrow_score)))
+        return bwt_fail(BWT_EINVAL, "bwt_hits_expand: null argument");
+    auto lq_of = [&](uint32_t r) { return read_len ? read_len : (uint32_t)(off[r + 1] - off[r]); };
+    auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; };
+    auto plain_text = [&](uint64_t co, uint32_t cl, uint32_t lq) {
+        cigar[co + cl - 1] = 'M';
+        uint32_t v = lq;
+        for (uint32_t x = cl - 1; x-- > 0;) { cigar[co + x] = (char)('0' + v % 10); v /= 10; }
+    };
+    uint64_t xi = 0, co = 0, g = 0, k = 0, h = 0;             // g: next record of hits[], k: next narrow record, h: next output hit
+    for (uint32_t r = 0; r < n; r++) {
+        if (g < n_hits && hits[g].read < r) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: hits must be ascending by read");
+        if (hit_off) hit_off[r] = h;
+        if (n_narrow && read_status[r] == 2) {
+            if (k >= n_narrow) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: more reads with status 2 than narrow records");
+            if (g < n_hits && hits[g].read == r) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: a read with a narrow record also has records in hits[]");
+            const uint32_t lq = lq_of(r), cl = digits(lq) + 1;
+            if (score) score[h] = narrow_score[k];
+            if (pos) pos[h] = (int64_t)narrow_off[k] - REF_EXT + shift;
+            if (win_off) win_off[h] = narrow_off[k];
+            if (win_len) win_len[h] = (int32_t)lq;
+            if (cig_off) cig_off[h] = co;
+            if (cigar && co + cl <= cig_cap) plain_text(co, cl, lq);
+            co += cl; k++; h++;
+            continue;
+        }
+        for (; g < n_hits && hits[g].read == r; g++, h++) {
+            const bwt_hit_rec &hr = hits[g];
+            const bool ex = xi < n_extra && extra[xi].hit == g;
+            if (ex && ((uint64_t)extra[xi].cig_off + extra[xi].cig_len > xcigar_len))
+                return bwt_fail(BWT_EINVAL, "bwt_hits_expand: an extra's text lies outside the text buffer");
+            const uint32_t lq = lq_of(hr.read), cl = ex ? extra[xi].cig_len : digits(lq) + 1;
+            if (score) score[h] = hr.score;
+            if (pos) pos[h] = hr.pos;
+            if (win_off) win_off[h] = hr.pos - shift + REF_EXT;
+            if (win_len) win_len[h] = (int32_t)(ex ? extra[xi].win_len : lq);
+            if (cig_off) cig_off[h] = co;
+            if (cigar && co + cl <= cig_cap) {
+                if (ex) memcpy(cigar + co, xcigar + extra[xi].cig_off, cl);
+                else plain_text(co, cl, lq);
+            }
+            co += cl;
+            if (ex) xi++;
+        }
+    }
+    if (g != n_hits) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: hits must be ascending by read and name reads of the batch");
+    if (k != n_narrow) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: fewer reads with status 2 than narrow records");
+    if (xi != n_extra) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: extras must be ascending by hit and name existing hits");
+    if (hit_off) hit_off[n] = h;
+    if (cig_off) cig_off[h] = co;
+    if (cig_needed) *cig_needed = co;
+    if (cigar && co > cig_cap) return bwt_fail(BWT_ENOSPC, "cigar capacity too small");
+    return 0;
+}
 extern "C" int bwt_hits_expand(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const bwt_hit_rec *hits, uint64_t n_hits,
                                const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t xcigar_len, uint64_t *hit_off,
                                int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar,
                                uint64_t cig_cap, uint64_t *cig_needed) {
-    enum { REF_EXT = 200 };                                   // ?REF_EXTENSION_LEN, src/worker_bwt.erl:17 (bwt_constants().ref_extension_len)
-    if ((!hits && n_hits) || (!extra && n_extra) || (!xcigar && xcigar_len) || (!read_len && !off && n_hits))
-        return bwt_fail(BWT_EINVAL, "bwt_hits_expand: null argument");
-    auto lq_of = [&](uint32_t r) { return read_len ? read_len : (uint32_t)(off[r + 1] - off[r]); };
-    auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; };
-    uint64_t xi = 0, co = 0, r_next = 0;
-    for (uint64_t h = 0; h < n_hits; h++) {
-        const bwt_hit_rec &hr = hits[h];
-        if (hr.read >= n || (h && hr.read < hits[h - 1].read)) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: hits must be ascending by read");
-        if (hit_off) while (r_next <= hr.read) hit_off[r_next++] = h;
-        const bool ex = xi < n_extra && extra[xi].hit == h;
-        if (ex && ((uint64_t)extra[xi].cig_off + extra[xi].cig_len > xcigar_len))
-            return bwt_fail(BWT_EINVAL, "bwt_hits_expand: an extra's text lies outside the text buffer");
-        const uint32_t lq = lq_of(hr.read), cl = ex ? extra[xi].cig_len : digits(lq) + 1;
-        if (score) score[h] = hr.score;
-        if (pos) pos[h] = hr.pos;
-        if (win_off) win_off[h] = hr.pos - shift + REF_EXT;
-        if (win_len) win_len[h] = (int32_t)(ex ? extra[xi].win_len : lq);
-        if (cig_off) cig_off[h] = co;
-        if (cigar && co + cl <= cig_cap) {
-            if (ex) memcpy(cigar + co, xcigar + extra[xi].cig_off, cl);
-            else {
-                cigar[co + cl - 1] = 'M';
-                uint32_t v = lq;
-                for (uint32_t x = cl - 1; x-- > 0;) { cigar[co + x] = (char)('0' + v % 10); v /= 10; }
-            }
-        }
-        co += cl;
-        if (ex) xi++;
-    }
-    if (xi != n_extra) return bwt_fail(BWT_EINVAL, "bwt_hits_expand: extras must be ascending by hit and name existing hits");
-    if (hit_off) while (r_next <= n) hit_off[r_next++] = n_hits;
-    if (cig_off) cig_off[n_hits] = co;
-    if (cig_needed) *cig_needed = co;
-    if (cigar && co > cig_cap) return bwt_fail(BWT_ENOSPC, "cigar capacity too small");
-    return 0;
+    return bwt_hits_expand_narrow(n, read_len, off, shift, nullptr, nullptr, nullptr, 0, hits, n_hits, extra, n_extra, xcigar, xcigar_len, hit_off, score,
+                                  pos, win_off, win_len, cig_off, cigar, cig_cap, cig_needed);
 }

@@ -49,7 +49,7 @@ struct Slot {
     bwt_batch *batch = nullptr;
     PinBuf bases, off, codes, exc;                 // inputs (pinned): ASCII form / packed form
     uint8_t *ascii = nullptr; size_t ascii_cap = 0; // pageable staging for bwt_pipe_submit_ascii (malloc: not zero-filled)
-    PinBuf rstat, rec, extra, cig;                 // results (pinned): the compact hit table
+    PinBuf rstat, rec, extra, cig, nwoff, nscore;  // results (pinned): the compact hit table (+ the narrow arrays of its narrow form)
     SlotState state = FREE;
     SlotMode mode = M_ASCII;
     uint32_t n = 0, read_len = 0, reads_cap = 0;
@@ -57,7 +57,7 @@ struct Slot {
     int rc = 0;
     std::string err;
     bwt_batch_counts counts{};
-    uint64_t n_hits = 0, n_extra = 0, cig_bytes = 0;
+    uint64_t n_hits = 0, n_extra = 0, cig_bytes = 0, n_narrow = 0;
     double ms[4] = {0, 0, 0, 0};                   // upload, kernels, download, waiting for a turn
     uint64_t seq = 0;                              // submission number: the order of the turns below
     std::thread th;
@@ -163,13 +163,16 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
                 p->trace(si, "kernels done");
             }
         }
-        uint64_t need[3] = {0, 0, 0};
+        // (the table as the device made it: its narrow form when the slot's batch runs with bwt_options.hits_narrow, else no narrow
+        // reads at all and this is the compact table)
+        uint64_t need[4] = {0, 0, 0, 0};                   // narrow, hits, extras, text
         if (!rc) {
             // sizes first (no table copied); the pinned result buffers grow outside the download's turn
-            rc = bwt_batch_fetch_hits_compact(s.batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, need);
+            rc = bwt_batch_fetch_hits_narrow(s.batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, need);
             if (rc == BWT_ENOSPC) rc = 0;
-            if (!rc && ((rc = s.rstat.ensure((size_t)s.n + 16)) || (rc = s.rec.ensure(((size_t)need[0] + 1) * 16)) ||
-                        (rc = s.extra.ensure(((size_t)need[1] + 1) * 16)) || (rc = s.cig.ensure((size_t)need[2] + 16)))) {
+            if (!rc && ((rc = s.rstat.ensure((size_t)s.n + 16)) || (rc = s.rec.ensure(((size_t)need[1] + 1) * 16)) ||
+                        (rc = s.extra.ensure(((size_t)need[2] + 1) * 16)) || (rc = s.cig.ensure((size_t)need[3] + 16)) ||
+                        (rc = s.nwoff.ensure(((size_t)need[0] + 4) * 4)) || (rc = s.nscore.ensure(((size_t)need[0] + 8) * 2)))) {
             }
         }
         {
@@ -181,15 +184,15 @@ static void slot_worker(bwt_pipe *p, uint32_t si) {
                 p->trace(si, "download begins");
                 const auto t0 = clk::now();
                 struct T { double &d; clk::time_point a; ~T() { d = std::chrono::duration<double, std::milli>(clk::now() - a).count(); } } tt{s.ms[2], t0};
-                rc = bwt_batch_fetch_hits_compact(s.batch, (int8_t *)s.rstat.p, (bwt_hit_rec *)s.rec.p, (bwt_hit_extra *)s.extra.p,
-                                                  (char *)s.cig.p, need[0], need[1], need[2], need);
+                rc = bwt_batch_fetch_hits_narrow(s.batch, (int8_t *)s.rstat.p, (uint32_t *)s.nwoff.p, (int16_t *)s.nscore.p, (bwt_hit_rec *)s.rec.p,
+                                                 (bwt_hit_extra *)s.extra.p, (char *)s.cig.p, need[0], need[1], need[2], need[3], need);
             }
         }
         {
             std::lock_guard<std::mutex> lk(p->mu);
             s.rc = rc;
             s.err = rc ? bwt_last_error() : "";
-            s.n_hits = need[0]; s.n_extra = need[1]; s.cig_bytes = need[2];
+            s.n_narrow = need[0]; s.n_hits = need[1]; s.n_extra = need[2]; s.cig_bytes = need[3];
             s.state = DONE;
         }
         p->trace(si, "done");
@@ -227,7 +230,7 @@ extern "C" void bwt_pipe_destroy(bwt_pipe *p) {
     for (auto &s : p->slots) {
         if (s.th.joinable()) s.th.join();
         if (s.batch) bwt_batch_destroy(s.batch);
-        PinBuf *all[] = {&s.bases, &s.off, &s.codes, &s.exc, &s.rstat, &s.rec, &s.extra, &s.cig};
+        PinBuf *all[] = {&s.bases, &s.off, &s.codes, &s.exc, &s.rstat, &s.rec, &s.extra, &s.cig, &s.nwoff, &s.nscore};
         for (auto b : all) b->release();
         free(s.ascii);
     }
@@ -403,6 +406,7 @@ extern "C" int bwt_pipe_wait(bwt_pipe *p, bwt_pipe_result *res) {
     res->extra = (const bwt_hit_extra *)s.extra.p; res->cigar = (const char *)s.cig.p;
     res->counts = s.counts;
     res->ms_upload = s.ms[0]; res->ms_kernels = s.ms[1]; res->ms_download = s.ms[2]; res->ms_waiting = s.ms[3];
+    res->n_narrow = s.n_narrow; res->narrow_off = (const uint32_t *)s.nwoff.p; res->narrow_score = (const int16_t *)s.nscore.p;
     if (s.rc) return fail(s.rc, "bwt_pipe: batch failed: " + s.err);
     return 0;
 }

@@ -26,6 +26,7 @@ EXPORTS = [
     "bwt_batch_set_reads_packed", "bwt_batch_fetch_hits_compact", "bwt_hits_expand", "bwt_pipe_set_options", "bwt_pipe_profile",
     "bwt_pipe_kernel_times", "bwt_pipe_acquire_packed", "bwt_pipe_submit_packed", "bwt_pipe_submit_ascii", "bwt_pipe_batch",
     "bwt_batch_compact_to_device",
+    "bwt_batch_fetch_hits_narrow", "bwt_hits_expand_narrow",
     "bwt_small_create", "bwt_small_destroy", "bwt_small_set_options", "bwt_small_align", "bwt_small_profile", "bwt_small_kernel_times",
 ]
 
@@ -56,7 +57,7 @@ class RunStats(C.Structure):
 
 
 OPTION_FIELDS = ("seed_fuse", "seed_fast", "seed_big", "search_ilp", "sw_prefilter", "sw_fuse_cand", "sw_wave", "sw_band", "sw_band_min",
-                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug")
+                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow")
 
 
 class Options(C.Structure):
@@ -104,7 +105,7 @@ class PipeResult(C.Structure):
     _fields_ = [("slot", C.c_uint32), ("n_reads", C.c_uint32), ("status", C.c_int32), ("read_len", C.c_uint32), ("n_hits", C.c_uint64),
                 ("n_extra", C.c_uint64), ("cigar_bytes", C.c_uint64), ("read_status", C.c_void_p), ("hits", C.c_void_p),
                 ("extra", C.c_void_p), ("cigar", C.c_void_p), ("counts", BatchCounts), ("ms_upload", C.c_double), ("ms_kernels", C.c_double),
-                ("ms_download", C.c_double), ("ms_waiting", C.c_double)]
+                ("ms_download", C.c_double), ("ms_waiting", C.c_double), ("n_narrow", C.c_uint64), ("narrow_off", C.c_void_p), ("narrow_score", C.c_void_p)]
 
 
 class SmallResult(C.Structure):
@@ -193,10 +194,15 @@ def pack_2bit(bases, threads=0):
     return codes, exc[:n_exc.value].copy()
 
 
-def hits_expand(n, read_len, off, shift, hits, extra, xcigar):
-    """bwt_hits_expand: a compact hit table (HIT_REC array, HIT_EXTRA array, text bytes) -> the per-hit arrays of align_batch."""
+def hits_expand(n, read_len, off, shift, hits, extra, xcigar, read_status=None, narrow_off=None, narrow_score=None):
+    """bwt_hits_expand / bwt_hits_expand_narrow: a compact hit table (HIT_REC array, HIT_EXTRA array, text bytes; for its narrow form
+    also the status bytes and the narrow arrays) -> the per-hit arrays of align_batch."""
     hits = np.ascontiguousarray(hits, HIT_REC); extra = np.ascontiguousarray(extra, HIT_EXTRA)
-    nh = len(hits)
+    nn = 0 if narrow_off is None else len(narrow_off)
+    if nn:
+        read_status = np.ascontiguousarray(read_status, np.int8); narrow_off = np.ascontiguousarray(narrow_off, np.uint32)
+        narrow_score = np.ascontiguousarray(narrow_score, np.int16)
+    nh = len(hits) + nn
     xc = np.frombuffer(bytes(xcigar), np.uint8) if not isinstance(xcigar, np.ndarray) else np.ascontiguousarray(xcigar, np.uint8)
     off64 = None if off is None else np.ascontiguousarray(off, np.uint64)
     hoff = np.empty(n + 1, np.uint64); score = np.empty(nh, np.int32); pos = np.empty(nh, np.int64); woff = np.empty(nh, np.int64)
@@ -204,9 +210,10 @@ def hits_expand(n, read_len, off, shift, hits, extra, xcigar):
     need = C.c_uint64(0)
 
     def call(cig, cap):
-        return load().bwt_hits_expand(C.c_uint32(n), C.c_uint32(read_len), _p(off64), C.c_int32(shift), _p(hits), C.c_uint64(nh), _p(extra),
-                                      C.c_uint64(len(extra)), _p(xc), C.c_uint64(len(xc)), _p(hoff), _p(score), _p(pos), _p(woff), _p(wlen), _p(coff), _p(cig),
-                                      C.c_uint64(cap), C.byref(need))
+        return load().bwt_hits_expand_narrow(C.c_uint32(n), C.c_uint32(read_len), _p(off64), C.c_int32(shift), _p(read_status) if nn else None,
+                                             _p(narrow_off) if nn else None, _p(narrow_score) if nn else None, C.c_uint64(nn), _p(hits),
+                                             C.c_uint64(len(hits)), _p(extra), C.c_uint64(len(extra)), _p(xc), C.c_uint64(len(xc)), _p(hoff), _p(score),
+                                             _p(pos), _p(woff), _p(wlen), _p(coff), _p(cig), C.c_uint64(cap), C.byref(need))
     _chk(call(None, 0))
     cig = np.empty(need.value, np.uint8)
     _chk(call(cig, len(cig)))
@@ -530,6 +537,20 @@ class Batch:
         _chk(load().bwt_batch_fetch_hits_compact(self.h, _p(rs), _p(hits), _p(extra), _p(cig), C.c_uint64(nh), C.c_uint64(nx), C.c_uint64(cb), need))
         return dict(read_status=rs, hits=hits, extra=extra, cigar=cig.tobytes())
 
+    def fetch_hits_narrow(self):
+        """The table in its narrow form (set_options(hits_narrow=1) before run) -> dict(read_status i8[n] with 2 = one plain hit in the
+        narrow arrays, narrow_off u32[], narrow_score i16[], hits, extra, cigar)."""
+        need = (C.c_uint64 * 4)()
+        rc = load().bwt_batch_fetch_hits_narrow(self.h, None, None, None, None, None, None, C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), need)
+        if rc not in (0, ENOSPC):
+            _chk(rc)
+        nn, nh, nx, cb = (int(x) for x in need)
+        rs = np.empty(self.n, np.int8); no = np.empty(nn, np.uint32); ns = np.empty(nn, np.int16)
+        hits = np.empty(nh, HIT_REC); extra = np.empty(nx, HIT_EXTRA); cig = np.empty(cb, np.uint8)
+        _chk(load().bwt_batch_fetch_hits_narrow(self.h, _p(rs), _p(no), _p(ns), _p(hits), _p(extra), _p(cig), C.c_uint64(nn), C.c_uint64(nh), C.c_uint64(nx),
+                                                C.c_uint64(cb), need))
+        return dict(read_status=rs, narrow_off=no, narrow_score=ns, hits=hits, extra=extra, cigar=cig.tobytes())
+
     def set_reads_both_strands(self, bases, off):
         """SURVEY 8f-4 (not in the reference): the batch then holds 2n reads, read n + i = reverse complement of read i."""
         bases = np.ascontiguousarray(bases, np.uint8)
@@ -688,15 +709,20 @@ class Pipe:
         r = PipeResult()
         _chk(load().bwt_pipe_wait(self.h, C.byref(r)))
         n, nh, nx = r.n_reads, int(r.n_hits), int(r.n_extra)
+        nn = int(r.n_narrow)
         return dict(slot=r.slot, n_reads=n, read_len=int(r.read_len), read_status=_view(r.read_status, n, np.int8),
+                    narrow_off=_view(r.narrow_off, nn, np.uint32), narrow_score=_view(r.narrow_score, nn, np.int16),
                     hits=_view(r.hits, nh, HIT_REC), extra=_view(r.extra, nx, HIT_EXTRA),
                     cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8).tobytes(), counts=r.counts.as_dict(),
                     stage_ms=dict(upload=r.ms_upload, kernels=r.ms_kernels, download=r.ms_download, waiting=r.ms_waiting))
 
     def expand(self, res, off=None):
         """per-hit arrays of a wait() result (host-side bwt_hits_expand); off = the batch's read offsets when the lengths differ"""
-        out = hits_expand(res["n_reads"], res["read_len"], off, self.index.meta()[1], res["hits"], res["extra"], res["cigar"])
-        out["read_status"] = res["read_status"].astype(np.int32)
+        out = hits_expand(res["n_reads"], res["read_len"], off, self.index.meta()[1], res["hits"], res["extra"], res["cigar"],
+                          res["read_status"], res["narrow_off"], res["narrow_score"])
+        st = res["read_status"].astype(np.int32)
+        st[st == 2] = 0                                    # (the narrow form's "one plain hit" is an ordinary read with hits)
+        out["read_status"] = st
         return out
 
     def batch_handle(self, slot):

@@ -72,6 +72,7 @@ typedef struct {
     int32_t sw_trace_all;       /* 0: score-only DP pass first, traceback for what needs it */
     int32_t pf_blocks_per_cu, sw_blocks_per_cu, sw_waves_per_cu;   /* occupancy caps (experiments) */
     int32_t debug;              /* 1: diagnostic lines on stderr (hand-back reasons of k_seed_fast) */
+    int32_t hits_narrow;        /* 1: the hit table is made in its NARROW form (bwt_batch_fetch_hits_narrow; a pipe's results then carry it) */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 
@@ -332,6 +333,23 @@ int bwt_batch_fetch_hits_raw(bwt_batch *b, int32_t *read_status, uint64_t *hit_o
 typedef struct { uint32_t hit, win_len, cig_off, cig_len; } bwt_hit_extra;
 int bwt_batch_fetch_hits_compact(bwt_batch *b, int8_t *read_status, bwt_hit_rec *hits, bwt_hit_extra *extra, char *cigar,
                                  uint64_t hit_cap, uint64_t extra_cap, uint64_t cig_cap, uint64_t needed[3]);
+/* The NARROW form of the compact table (bwt_options.hits_narrow = 1): most reads of a sequencing run have exactly one hit, and it is
+ * plain -- for such a read nothing goes into hits[]: its read_status byte is 2 (instead of 0) and the k-th such read's hit is
+ *     narrow_off[k]    window offset into Ref1 (u32: an index has fewer than 2^32 - 70000 rows), Pos = narrow_off - 200 + Shift
+ *     narrow_score[k]  the score (i16: the form is only made for batches whose reads have at most 16383 bases; a batch of longer
+ *                      reads simply has no narrow reads)
+ * with win_len = Lq and cigar = "<Lq>M" as for every plain hit: 7 bytes per read down instead of 17.  hits[] / extra[] / cigar hold
+ * everything else exactly as in the compact table (extra[].hit indexes hits[]).  needed = {narrow, hits, extras, cigar bytes}.
+ * bwt_hits_expand_narrow is the decoder (host only); every entry point that hands out 16-byte records (bwt_batch_fetch_hits*,
+ * bwt_batch_*_to_device, bwt_batch_pair_hits) first turns a narrow table back into that form on the device. */
+int bwt_batch_fetch_hits_narrow(bwt_batch *b, int8_t *read_status, uint32_t *narrow_off, int16_t *narrow_score, bwt_hit_rec *hits,
+                                bwt_hit_extra *extra, char *cigar, uint64_t narrow_cap, uint64_t hit_cap, uint64_t extra_cap, uint64_t cig_cap,
+                                uint64_t needed[4]);
+int bwt_hits_expand_narrow(uint32_t n, uint32_t read_len, const uint64_t *off, int32_t shift, const int8_t *read_status,
+                           const uint32_t *narrow_off, const int16_t *narrow_score, uint64_t n_narrow, const bwt_hit_rec *hits, uint64_t n_hits,
+                           const bwt_hit_extra *extra, uint64_t n_extra, const char *xcigar, uint64_t xcigar_len, uint64_t *hit_off,
+                           int32_t *score, int64_t *pos, int64_t *win_off, int32_t *win_len, uint64_t *cig_off, char *cigar,
+                           uint64_t cig_cap, uint64_t *cig_needed);
 /* the same table device to device into caller-owned device memory (the send buffer of the RCCL hit gather): records with
  * `read_base` added to the read ids, extras and text as they are (hit indices and text offsets stay local to this batch: the
  * receiver adds the sender's bases).  Capacities in records / records / bytes. */
@@ -385,6 +403,10 @@ typedef struct {
     bwt_batch_counts counts;
     /* wall time of the slot's thread in its three stages (host packing excluded), and the time it waited for its turn */
     double ms_upload, ms_kernels, ms_download, ms_waiting;
+    /* bwt_options.hits_narrow = 1 on the pipe: the reads with read_status 2 have their one plain hit here, not in hits[] (above) */
+    uint64_t n_narrow;
+    const uint32_t *narrow_off;      /* n_narrow */
+    const int16_t *narrow_score;     /* n_narrow */
 } bwt_pipe_result;
 int bwt_pipe_create(bwt_index *idx, uint32_t depth /* 1..8 */, bwt_pipe **out);
 void bwt_pipe_destroy(bwt_pipe *p);

@@ -194,3 +194,29 @@ def test_hits_expand_on_the_host():
         lib.hits_expand(6, 100, None, 7, hits[:1], extra[:1], text)
     with pytest.raises(lib.BwtError):                          # hits out of order
         lib.hits_expand(6, 100, None, 7, hits[::-1].copy(), extra[:0], text)
+
+
+def test_narrow_table_expands_on_the_host():
+    """bwt_hits_expand_narrow: reads with status 2 take their one plain hit from the narrow arrays (Pos = offset - 200 + Shift), the
+    others from the record stream; a table whose parts disagree is refused, never read out of bounds."""
+    import numpy as np
+    from bwt_amd import lib
+    st = np.array([2, 0, 1, 2, 0, -1], np.int8)
+    noff = np.array([1193, 777], np.uint32); nsc = np.array([200, 197], np.int16)
+    hits = np.array([(1, 190, 50), (1, 188, 5000), (4, 140, -3)], lib.HIT_REC)
+    extra = np.array([(0, 103, 0, 7), (2, 73, 7, 8)], lib.HIT_EXTRA)
+    text = b"50M3D50" + b"30M2I41M"
+    out = lib.hits_expand(6, 100, None, 7, hits, extra, text, st, noff, nsc)
+    assert out["hit_off"].tolist() == [0, 1, 3, 3, 4, 5, 5]
+    assert out["score"].tolist() == [200, 190, 188, 197, 140] and out["pos"].tolist() == [1000, 50, 5000, 584, -3]
+    assert out["win_off"].tolist() == [1193, 243, 5193, 777, 190] and out["win_len"].tolist() == [100, 103, 100, 100, 73]
+    cig = [out["cigar"][int(out["cig_off"][h]):int(out["cig_off"][h + 1])] for h in range(5)]
+    assert cig == [b"100M", b"50M3D50", b"100M", b"100M", b"30M2I41M"]
+    with pytest.raises(lib.BwtError):                          # a narrow read that also has a record
+        lib.hits_expand(6, 100, None, 7, np.array([(0, 1, 1)], lib.HIT_REC), extra[:0], b"", st, noff, nsc)
+    with pytest.raises(lib.BwtError):                          # more status-2 reads than narrow records
+        lib.hits_expand(6, 100, None, 7, hits, extra, text, st, noff[:1], nsc[:1])
+    with pytest.raises(lib.BwtError):                          # fewer
+        lib.hits_expand(6, 100, None, 7, hits, extra, text, np.array([2, 0, 1, 0, 0, -1], np.int8), noff, nsc)
+    with pytest.raises(lib.BwtError):                          # a record for a read the batch does not have
+        lib.hits_expand(4, 100, None, 7, hits, extra, text, st[:4], noff, nsc)

@@ -341,3 +341,82 @@ def test_pipe_api_errors(gpu_index):
         pipe.release(r["slot"])
     finally:
         pipe.close()
+
+
+@pytest.mark.parametrize("opts", [{}, {"sw_prefilter": 0}, {"seed_fast": 0}], ids=str)
+def test_narrow_table_equals_compact_table_and_oracle(gpu_index, orc_fm, ref_bytes, opts):
+    """bwt_options.hits_narrow: a read whose answer is one plain hit leaves the 16-byte record stream (status 2, window offset u32 +
+    score i16 in the narrow arrays).  The table decoded on the host (bwt_hits_expand_narrow), the same table turned back into
+    records on the device (what every per-hit / compact entry point does first), and a run without the option are one and the same,
+    and the oracle's."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    reads = mixed(ref_bytes, 100, 77) + synth_reads(ref_bytes, 600, 100, 78, max_subs=1)
+    bases, off = lib.pack_reads(reads)
+    plain = lib.Batch(gpu_index); plain.set_options(**opts)
+    plain.set_reads(bases, off); plain.run(lib.STAGE_EXTEND)
+    want = plain.fetch_hits()
+    b = lib.Batch(gpu_index); b.set_options(hits_narrow=1, **opts)
+    b.set_reads(bases, off); b.run(lib.STAGE_EXTEND)
+    t = b.fetch_hits_narrow()
+    nn = len(t["narrow_off"])
+    assert int((t["read_status"] == 2).sum()) == nn and (nn > 300 or opts.get("sw_prefilter") == 0)       # (only the prefilter settles hits as plain)
+    assert len(t["hits"]) + nn == len(want["score"]) and not np.isin(np.nonzero(t["read_status"] == 2)[0], t["hits"]["read"]).any()
+    ex = lib.hits_expand(len(reads), 0, off, gpu_index.meta()[1], t["hits"], t["extra"], t["cigar"], t["read_status"], t["narrow_off"], t["narrow_score"])
+    for k in KEYS[1:]:
+        assert np.array_equal(ex[k], want[k]), k
+    assert ex["cigar"] == want["cigar"]
+    st = t["read_status"].astype(np.int32); st[st == 2] = 0
+    assert np.array_equal(st, want["read_status"])
+    t2 = b.fetch_hits_narrow()                                  # (fetching twice: the same table)
+    assert all(np.array_equal(t[k], t2[k]) for k in ("read_status", "narrow_off", "narrow_score", "hits", "extra")) and t["cigar"] == t2["cigar"]
+    # ... and through the entry points that hand out records: widened on the device first
+    c = b.fetch_hits_compact()
+    assert len(c["hits"]) == len(want["score"]) and not (c["read_status"] == 2).any()
+    ex2 = lib.hits_expand(len(reads), 0, off, gpu_index.meta()[1], c["hits"], c["extra"], c["cigar"])
+    got = b.fetch_hits()
+    for k in KEYS:
+        assert np.array_equal(got[k], want[k]), k
+    for k in KEYS[1:]:
+        assert np.array_equal(ex2[k], want[k]), k
+    assert got["cigar"] == want["cigar"] and ex2["cigar"] == want["cigar"]
+    assert len(b.fetch_hits_narrow()["narrow_off"]) == 0       # (the table is in its 16-byte form now)
+    assert oracle_check(got, reads, orc_fm, ref1) > 500
+    # a batch with a read too long for 16-bit scores: no narrow reads at all, same answers
+    long_reads = reads[:50] + [ref_bytes[2000:2000 + 17000]]
+    lb, lo = lib.pack_reads(long_reads)
+    b.set_reads(lb, lo); b.run(lib.STAGE_EXTEND)
+    tl = b.fetch_hits_narrow()
+    assert len(tl["narrow_off"]) == 0 and not (tl["read_status"] == 2).any()
+    plain.set_reads(lb, lo); plain.run(lib.STAGE_EXTEND)
+    wl, gl = plain.fetch_hits(), b.fetch_hits()
+    for k in KEYS:
+        assert np.array_equal(gl[k], wl[k]), k
+    plain.destroy(); b.destroy()
+
+
+def test_pipe_results_in_the_narrow_form(gpu_index, ref_bytes):
+    """a pipe whose batches run with hits_narrow: the result carries the narrow arrays, expand() decodes them, and the table equals the
+    synchronous call's"""
+    from bwt_amd import lib
+    reads = synth_reads(ref_bytes, 3000, 100, 5, max_subs=2) + mixed(ref_bytes, 100, 6)
+    bases, off = lib.pack_reads(reads)
+    want = gpu_index.align_batch(bases, off)
+    codes, exc = lib.pack_2bit(bases)
+    pipe = lib.Pipe(gpu_index, depth=2)
+    pipe.set_options(hits_narrow=1)
+    try:
+        for _ in range(3):
+            s, v = pipe.acquire_packed(len(bases), len(reads), len(exc))
+            v["codes"][:len(codes)] = codes; v["exc"][:len(exc)] = exc
+            pipe.submit_packed(s, len(reads), 100, len(bases), len(exc))
+            r = pipe.wait()
+            assert len(r["narrow_off"]) > 1000 and len(r["narrow_off"]) + len(r["hits"]) == len(want["score"])
+            out = pipe.expand(r)
+            for k in KEYS:
+                assert np.array_equal(out[k], want[k]), k
+            assert out["cigar"] == want["cigar"]
+            pipe.release(r["slot"])
+    finally:
+        pipe.close()
