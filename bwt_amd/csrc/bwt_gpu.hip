@@ -421,6 +421,7 @@ struct bwt_batch {
     // sw slabs
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2, tqw;
     DevBuf bq, bq2, bq3, slab_band;    // k_sw_band: the queues of what its tiers pass on (bq3: first tier -> third), the direction slab
+    DevBuf dq_lo, bq0, bqs;            // the 12-diagonal tier: its queue (filled by the prefilter), what it passes on, what it sends past the next tier
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     DevBuf pfq;                        // candidates the fused prefilter pass listed for the quad-per-candidate pass
@@ -587,7 +588,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->tqw, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs,
-                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status};
+                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -1203,6 +1204,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     if (!first) {
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 48, b->stream));      // band_*, pf_ov, band2_*, band3_*
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band0_in, 0, 20, b->stream));     // band0_*, dq_lo_count
     }
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
@@ -1213,6 +1215,15 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     io.fpq = b->fpq.as<uint32_t>(); io.tq = b->tq.as<uint32_t>(); io.ctr = b->ctr.as<Counters>();
     io.dq = nullptr; io.tq2 = b->tq2.as<uint32_t>(); io.qplanes = qplanes; io.wplanes = wplanes; io.wave_upto = 0;
     io.tq_in = nullptr; io.tq_in_count = nullptr;
+    // the banded tiers run on index-backed batches whose reads fit the kernel; the prefilter then keeps a queue of its own for the
+    // candidates of the 12-diagonal tier (bwt_options.sw_band12 = 0: no such tier, everything starts at 20 diagonals)
+    const uint32_t lq_bound = b->ix ? b->max_lq : max_lq;
+    const bool band_on = qplanes && wplanes && b->opt.sw_prefilter != 0 && lq_bound >= 2 && lq_bound <= SWB_MAX_LQ && b->opt.sw_band != 0;
+    const bool band12 = band_on && b->ix && b->opt.sw_band12 != 0;
+    if (band12) {
+        if ((rc = b->dq_lo.ensure(nc * 4 + 4)) || (rc = b->bq0.ensure(nc * 4 + 4)) || (rc = b->bqs.ensure(nc * 4 + 4))) return rc;
+        io.dq_lo = b->dq_lo.as<uint32_t>();
+    }
     if (qplanes && wplanes && b->opt.sw_prefilter != 0) {
         io.dq = b->dq.as<uint32_t>();
         CandSrc src{};
@@ -1284,7 +1295,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     // the rest -- candidates far from any clean alignment, wide clusters -- moves on in a second queue that takes dq's place
     b->band_ran = false;
     const uint32_t band_min = std::min<uint32_t>(wv_thresh, b->opt.sw_band_min >= 0 ? (uint32_t)b->opt.sw_band_min : 16384u);   // queues up to this size are left to k_sw_wave
-    if (io.dq && max_lq >= 2 && max_lq <= SWB_MAX_LQ && b->opt.sw_band != 0) {
+    if (io.dq && band_on && max_lq >= 2 && max_lq <= SWB_MAX_LQ) {
         const uint32_t rows = max_lq + 1;
         // resident grids: 4 (3 for the wide tiers) waves per SIMD; the direction slab (rows x 1 KiB per wave, 2 KiB in the third tier)
         // stays under 1 GiB
@@ -1300,12 +1311,20 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             ProfScope ps(b, "sw_band");
             const uint32_t *nullq = nullptr;
             const unsigned int *nullc = nullptr;
+            // the 12-diagonal tier on the prefilter's queue of square windows with <= 6 mismatches: what it does not settle goes on to
+            // the 20-diagonal tier's second queue (bq0 / band0_left), what that one cannot settle either to the 32-diagonal one's (bqs)
+            if (band12)
+                hipLaunchKernelGGL((k_sw_band<12, 20>), dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)b->dq_lo.as<uint32_t>(),
+                                   (const unsigned int *)&dc->dq_lo_count, nullq, nullc, b->bq0.as<uint32_t>(), &dc->band0_in, b->bqs.as<uint32_t>(),
+                                   &dc->band0_direct, b->slab_band.as<uint32_t>(), rows, band_min);
             // first tier: what the second cannot settle either goes straight to the third's second queue (bq3 / band_direct)
             hipLaunchKernelGGL((k_sw_band<20, 32>), dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
-                               nullq, nullc, b->bq.as<uint32_t>(), &dc->band_in, b->bq3.as<uint32_t>(), &dc->band_direct,
+                               band12 ? (const uint32_t *)b->bq0.as<uint32_t>() : nullq, band12 ? (const unsigned int *)&dc->band0_left : nullc,
+                               b->bq.as<uint32_t>(), &dc->band_in, b->bq3.as<uint32_t>(), &dc->band_direct,
                                b->slab_band.as<uint32_t>(), rows, band_min);
             hipLaunchKernelGGL((k_sw_band<32, 0>), dim3(blocks2), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq.as<uint32_t>(),
-                               (const unsigned int *)&dc->band_left, nullq, nullc, b->bq2.as<uint32_t>(), &dc->band2_in, (uint32_t *)nullptr,
+                               (const unsigned int *)&dc->band_left, band12 ? (const uint32_t *)b->bqs.as<uint32_t>() : nullq,
+                               band12 ? (const unsigned int *)&dc->band0_direct : nullc, b->bq2.as<uint32_t>(), &dc->band2_in, (uint32_t *)nullptr,
                                (unsigned int *)nullptr, b->slab_band.as<uint32_t>(), rows, band_min);
             // (the first tier's output queue is free again: the third tier passes on into it; bwt_options.sw_band = 2 makes it
             // pass everything on -- the two-tier path, for comparisons)
@@ -1614,8 +1633,10 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->n_float = b->hctr.fp_count; counts->n_traced = (uint64_t)b->hctr.tq_count + b->hctr.tq2_count;
         // (a short DP queue taken by k_sw_wave is traced as a whole; in score-first mode it never reaches tq2)
         if (b->wave_upto && b->hctr.dq_count <= b->wave_upto && !b->hctr.tq2_count) counts->n_traced += b->hctr.dq_count;
-        counts->n_dp = b->band_ran ? b->hctr.band_in : b->hctr.dq_count;
-        counts->n_banded = b->band_ran ? b->hctr.band_in - b->hctr.band3_left : 0;
+        // (with the 12-diagonal tier: band_in = the 20-diagonal tier's own queue + what the 12-diagonal tier passed on to it)
+        const uint64_t n_dp_band = (uint64_t)b->hctr.band_in + b->hctr.band0_in - b->hctr.band0_left;
+        counts->n_dp = b->band_ran ? n_dp_band : b->hctr.dq_count;
+        counts->n_banded = b->band_ran ? n_dp_band - b->hctr.band3_left : 0;
         counts->n_traced += counts->n_banded;
         counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
         counts->n_handed_back = b->hctr.n_gq;

@@ -2169,6 +2169,8 @@ struct SwIO {
     const uint32_t *tq_in;     // k_sw<SW_TRACE>: its queue and count when they are not tq / ctr->tq_count (what the wide pass of k_sw_pk left)
     const unsigned int *tq_in_count;
     Counters *ctr;
+    uint32_t *dq_lo = nullptr; // k_sw_prefilter: DP candidates on a SQUARE window with 3..6 mismatches on its diagonal go here instead of dq
+                               // (count: ctr->dq_lo_count): the 12-diagonal tier of the banded DP settles exactly those; null: all to dq
 };
 
 // writes "<n><op>" right to left, returns the new write position
@@ -2466,10 +2468,10 @@ struct CandSrc {
 template <bool FROM_READS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
-    __shared__ uint32_t wq_[4][3][128];
-    WaveQ qfp, qdp, qov;
+    __shared__ uint32_t wq_[4][4][128];
+    WaveQ qfp, qdp, qov, qlo;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
-    qov.buf = wq_[threadIdx.x >> 6][2]; qov.have = 0;
+    qov.buf = wq_[threadIdx.x >> 6][2]; qov.have = 0; qlo.buf = wq_[threadIdx.x >> 6][3]; qlo.have = 0;
     if (!FROM_READS && src.list) n_items = *src.list_count;
     const uint32_t *qp = io.qplanes, *wp = io.wplanes;
     const int ql = (int)(threadIdx.x & 3);
@@ -2672,11 +2674,16 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
             if (FROM_READS && route != 0 && ql == 0) { src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_woff[c] = wo; }
             // the two queues, staged in LDS (one atomic per 64 entries)
             waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
-            waveq_push(qdp, route == 2 && ql == 0, c, io.dq, &io.ctr->dq_count);
+            // (a square window whose diagonal has at most six mismatches scores >= 2 Lq - 18 on it: what the 12-diagonal band's
+            // certificate covers -- 0.6 of the first tier's cells)
+            const bool lo_q = route == 2 && io.dq_lo != nullptr && square && mism <= 6 && lq >= 24;
+            waveq_push(qdp, route == 2 && !lo_q && ql == 0, c, io.dq, &io.ctr->dq_count);
+            if (io.dq_lo) waveq_push(qlo, lo_q && ql == 0, c, io.dq_lo, &io.ctr->dq_lo_count);
         }
         }
     waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
     waveq_drain(qdp, io.dq, &io.ctr->dq_count);
+    if (io.dq_lo) waveq_drain(qlo, io.dq_lo, &io.ctr->dq_lo_count);
     if (FROM_READS) {
         waveq_drain(qov, src.ovq, src.ov_count);
         const unsigned long long sums[2] = {wave_sum_u64(cells), wave_sum_u64(wbytes)};
@@ -3145,7 +3152,7 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
                const unsigned int *__restrict__ in_count2, uint32_t *__restrict__ rest, unsigned int *__restrict__ ctl,
                uint32_t *__restrict__ skip_q, unsigned int *__restrict__ skip_ctr, uint32_t *__restrict__ slab, uint32_t slab_rows,
                uint32_t skip_upto) {
-    static_assert(B > 16 && B <= 64, "one or two match words per row");
+    static_assert(B >= 12 && B <= 64, "one or two match words per row");
     constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8, NW = (B + 31) / 32;     // NW: 32-cell match words of a row
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);

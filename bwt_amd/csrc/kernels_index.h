@@ -180,5 +180,9 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned int band2_in, band2_left, band2_next, band_direct;   // ... second tier (wider band); band_direct: candidates the first tier sent straight to the third
     unsigned int band3_in, band3_left, band3_next, tqw_count;   // (tqw_count: what the wide pass of k_sw_pk left for the generic trace kernel)   // ... third tier (64 diagonals); what it passes on goes to the full-rectangle kernels
     unsigned long long cig_total;                            // bytes of all CIGAR texts of the batch's hits (k_hits_count)
+    // round 4: a 12-diagonal tier in front of the banded tiers, for the candidates the prefilter found on a square window with at most
+    // six mismatches (its own queue, dq_lo): candidates it was given, those it passed on to the 20-diagonal tier, its work counter, those
+    // it sent straight to the 32-diagonal tier; the length of its queue
+    unsigned int band0_in, band0_left, band0_next, band0_direct, dq_lo_count, pad2_[3];
 };
 

@@ -73,6 +73,7 @@ typedef struct {
     int32_t pf_blocks_per_cu, sw_blocks_per_cu, sw_waves_per_cu;   /* occupancy caps (experiments) */
     int32_t debug;              /* 1: diagnostic lines on stderr (hand-back reasons of k_seed_fast) */
     int32_t hits_narrow;        /* 1: the hit table is made in its NARROW form (bwt_batch_fetch_hits_narrow; a pipe's results then carry it) */
+    int32_t sw_band12;          /* 0: no 12-diagonal tier in front of the banded DP tiers (square windows with <= 6 mismatches start at 20 diagonals) */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 

@@ -37,7 +37,8 @@ def check_against_oracle(out, reads, orc_fm, ref1):
 # every execution option of bwt_options (include/bwt_gpu.h) that selects between equivalent kernels, and the table's summary bitmap
 MODES = [{"seed_big": 1}, {"ktab_summary": 2}, {"ktab_summary": 0}, {"sw_band": 0}, {"sw_band": 2, "sw_band_min": 0}, {"sw_band_min": 0}, {"sw_band_min": 0, "sw_wave": 0},
          {"seed_fuse": 0}, {"sw_prefilter": 0}, {"sw_pk": 0}, {"sw_pk": 2}, {"sw_lds": 0}, {"sw_trace_all": 0, "sw_wave": 0},
-         {"sw_wave": 0, "sw_prefilter": 0}, {"search_ilp": 2}, {"seed_fast": 0}, {"sw_fuse_cand": 0}]
+         {"sw_wave": 0, "sw_prefilter": 0}, {"search_ilp": 2}, {"seed_fast": 0}, {"sw_fuse_cand": 0}, {"sw_band12": 0, "sw_band_min": 0},
+         {"hits_narrow": 1}]
 
 
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: ",".join("%s=%s" % kv for kv in m.items()))
@@ -339,6 +340,48 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
         b.destroy()
 
 
+def test_twelve_diagonal_tier(gpu_index, orc_fm, ref_bytes):
+    """Reads with 3..8 substitutions and no indel: square windows the prefilter cannot settle (more than two mismatches).  Up to six
+    mismatches score >= 2 Lq - 18 on the diagonal: the prefilter queues them for the 12-diagonal tier of the banded DP, whose
+    certificate covers exactly that; with more they start at 20 diagonals as before.  The oracle's answers either way, the same
+    tables with the tier switched off, and the counts say the tier was used."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    rng = np.random.default_rng(12)
+    reads = []
+    for length, n in ((100, 900), (150, 500), (40, 200)):
+        for _ in range(n):
+            a = int(rng.integers(0, len(ref_bytes) - length))
+            q = bytearray(ref_bytes[a:a + length])
+            for p in rng.choice(length, int(rng.integers(3, 9)), replace=False):
+                q[int(p)] = int(rng.choice([x for x in b"ACGT" if x != q[int(p)]]))
+            reads.append(bytes(q))
+    b = lib.Batch(gpu_index)
+    b.set_options(sw_band_min=0)
+    try:
+        b.set_reads(*lib.pack_reads(reads))
+        c = b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        assert check_against_oracle(out, reads, orc_fm, ref1) > 500
+        assert c["n_banded"] > 400 and c["n_dp"] >= c["n_banded"], c
+        b.set_options(sw_band_min=0, sw_band12=0)
+        c0 = b.run(lib.STAGE_EXTEND)
+        out0 = b.fetch_hits()
+        assert c0["n_dp"] == c["n_dp"] and c0["n_banded"] == c["n_banded"]
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(out[k], out0[k]), k
+        assert out["cigar"] == out0["cigar"]
+        b.set_options(sw_band12=1)                                  # the short-queue route: every tier passes its queue on to k_sw_wave
+        b.run(lib.STAGE_EXTEND)
+        out1 = b.fetch_hits()
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(out[k], out1[k]), k
+        assert out["cigar"] == out1["cigar"]
+    finally:
+        b.destroy()
+
+
 @pytest.fixture(scope="module")
 def tandem_index():
     """A 1 M-row genome with 240 tandem repeats (periods 1..31, 120..300 bp each): alignments there have many equally good
@@ -403,7 +446,7 @@ def test_banded_dp_in_tandem_repeats(tandem_index, length):
         # sw_wave = 0: a DP queue this short would otherwise be taken whole by the wave-per-alignment kernel, and the packed
         # kernel's passes -- the wide one above all -- would launch on empty queues: without it they get every item
         for opts in ({"sw_band_min": 0, "sw_pk": 2}, {"sw_band_min": 0, "sw_band": 0}, {"sw_band_min": 0, "sw_band": 0, "sw_pk": 2},
-                     {"sw_band_min": 0, "sw_wave": 0}, {"sw_band_min": 0, "sw_wave": 0, "sw_band": 0}, {"sw_wave": 0, "sw_band": 0, "sw_pk": 2},
+                     {"sw_band_min": 0, "sw_wave": 0}, {"sw_band_min": 0, "sw_wave": 0, "sw_band": 0}, {"sw_wave": 0, "sw_band": 0, "sw_pk": 2}, {"sw_band_min": 0, "sw_band12": 0},
                      {"sw_wave": 0, "sw_band": 0, "sw_trace_all": 0}):
             b.set_options(**opts)
             b.run(lib.STAGE_EXTEND)
