@@ -63,15 +63,19 @@ def main():
     off = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
     print("setup %.1f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
     # through the wire formats of the host boundary (round 3): packed upload, compact hit table, host-side expansion
+    # (round 4: the table in its NARROW form -- what bench.py's pipe downloads -- decoded by bwt_hits_expand_narrow)
     batch = lib.Batch(ix)
+    batch.set_options(hits_narrow=1)
     codes, exc = lib.pack_2bit(bases)
     batch.set_reads_packed(codes, exc, n, read_len=L)
     t0 = time.perf_counter()
     c = batch.run(lib.STAGE_EXTEND)
     t_gpu = time.perf_counter() - t0
-    comp = batch.fetch_hits_compact()
-    hits = lib.hits_expand(n, L, None, ix.meta()[1], comp["hits"], comp["extra"], comp["cigar"])
-    hits["read_status"] = comp["read_status"].astype(np.int32)
+    comp = batch.fetch_hits_narrow()
+    hits = lib.hits_expand(n, L, None, ix.meta()[1], comp["hits"], comp["extra"], comp["cigar"], comp["read_status"], comp["narrow_off"], comp["narrow_score"])
+    st = comp["read_status"].astype(np.int32)
+    st[st == 2] = 0
+    hits["read_status"] = st
     gpu = orc.hits_digest(hits)
     Lc, SA = ix.export()
     ptr, shift = ix.meta()
@@ -91,7 +95,7 @@ def main():
            "workload": "i.i.d. genome of %d bp%s, %d reads of %d bp: 3/4 with 0-%d substitutions, 1/4 with an indel of 1-5 bp "
                        "as well, 2 %% of the reads with an N or IUPAC base%s" % (a.genome_len, (" with 40 segments of 600 bp in %d copies each" % a.repeats) if a.repeats else "",
                                                                                  n, L, a.max_subs, ", a tenth of the reads from the repeats" if a.repeats else ""),
-           "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order); GPU side: packed upload (%d exceptions), compact table (%d extras of %d hits), expanded on the host" % (len(exc), len(comp["extra"]), len(comp["hits"])),
+           "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order); GPU side: packed upload (%d exceptions), narrow hit table (%d narrow reads, %d records, %d extras), expanded on the host; suffix-interval table K = %d, lower levels kept wide %s; head %s" % (len(exc), len(comp["narrow_off"]), len(comp["hits"]), len(comp["extra"]), ix.ktable[0], ix.ktable_wide_levels, os.environ.get("BWT_HEAD", "?")),
            "reads": n, "reads_with_hits": int((np.diff(hits["hit_off"].astype(np.int64)) > 0).sum()), "hits": int(c["n_hits"]),
            "reads_status_minus1": int((hits["read_status"] == -1).sum()), "dp_candidates": int(c["n_dp"]), "fp64_candidates": int(c["n_float"]),
            "handed_back_reads": int(c["n_handed_back"]), "banded": int(c.get("n_banded", 0)), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
