@@ -397,6 +397,7 @@ struct bwt_batch {
     uint64_t total_bases = 0;
     DevBuf bases, off, rplanes;
     DevBuf pk_codes, pk_exc;           // packed upload staging (bwt_batch_set_reads_packed)
+    const uint32_t *pk_zc = nullptr;   // up_zero_copy: the codes were not copied; they are still in the caller's pinned buffer (valid until its next batch)
     uint64_t pk_nexc = 0;
     bool planes_valid = false;         // rplanes already hold this batch's planes (packed upload): the search stage skips k_read_planes
     bool ascii_valid = true;           // `bases` holds every read's bytes (false after a packed upload: only the exceptions' bytes)
@@ -706,18 +707,22 @@ int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_
     b->n = 0; b->done = 0; b->n_cand = 0; b->n_hits = 0; b->cig_bytes = 0; b->n_extra = 0; b->xcig_bytes = 0;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-    if (nwords) HIPCHK(hipMemcpyAsync(b->pk_codes.p, codes, nwords * 8, hipMemcpyHostToDevice, b->stream));
+    // up_zero_copy: the codes stay where they are (pinned host memory) and k_unpack_reads reads them over the link -- one stream of
+    // reads instead of a DMA into HBM followed by a kernel over the copy; the upload is then over when that kernel is
+    const bool zc = b->opt.up_zero_copy == 1 && nwords;
+    b->pk_zc = zc ? codes : nullptr;
+    if (nwords && !zc) HIPCHK(hipMemcpyAsync(b->pk_codes.p, codes, nwords * 8, hipMemcpyHostToDevice, b->stream));
     if (n_exc) HIPCHK(hipMemcpyAsync(b->pk_exc.p, exc, n_exc * 8, hipMemcpyHostToDevice, b->stream));
     unsigned int chk[4] = {0xffffffffu, 0u, 0u, 0u};           // {min length, max length, offset flags, exception flags}
     unsigned int *dchk = b->scan_tmp.as<unsigned int>();
     HIPCHK(hipMemcpyAsync(dchk, chk, sizeof chk, hipMemcpyHostToDevice, b->stream));
     if (read_len) {
-        if (uploaded) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
+        if (uploaded && !zc) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
         if (n) hipLaunchKernelGGL(k_off_uniform, dim3(std::min<uint32_t>(cdiv((uint64_t)n + 1, 256), (uint32_t)cus * 8)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, read_len);
         else HIPCHK(hipMemsetAsync(b->off.p, 0, 8, b->stream));
     } else {
         HIPCHK(hipMemcpyAsync(b->off.p, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
-        if (uploaded) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
+        if (uploaded && !zc) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
         if (n) hipLaunchKernelGGL(k_off_check, dim3(std::min<uint32_t>(cdiv(n, 256), 1024)), dim3(256), 0, b->stream, b->off.as<uint64_t>(), n, dchk);
     }
     {
@@ -728,8 +733,10 @@ int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_
         // the DP kernels (it lists the candidates that reach them: stage_extend makes those reads' bytes then)
         const bool all_ascii = b->opt.sw_prefilter == 0;
         if (nwords)
-            hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), (uint64_t)cus * 16)), dim3(256), 0, b->stream,
-                               (const uint2 *)b->pk_codes.as<uint2>(), nwords, total, b->rplanes.as<uint32_t>(), all_ascii ? b->bases.as<uint8_t>() : (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), zc ? (uint64_t)cus * 2 : (uint64_t)cus * 16)), dim3(256), 0, b->stream,
+                               zc ? (const uint2 *)codes : (const uint2 *)b->pk_codes.as<uint2>(), nwords, total, b->rplanes.as<uint32_t>(),
+                               all_ascii ? b->bases.as<uint8_t>() : (uint8_t *)nullptr);
+        if (uploaded && zc) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));
         if (n_exc)
             hipLaunchKernelGGL(k_unpack_exc, dim3((uint32_t)std::min<uint64_t>(cdiv(n_exc, 256), (uint64_t)cus * 8)), dim3(256), 0, b->stream,
                                (const uint64_t *)b->pk_exc.as<uint64_t>(), n_exc, total, b->rplanes.as<uint32_t>(), b->bases.as<uint8_t>(), dchk + 3);
@@ -767,7 +774,7 @@ static int ascii_all(bwt_batch *b) {
     ProfScope ps(b, "unpack_reads");
     if (nwords)
         hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), (uint64_t)cus * 16)), dim3(256), 0, b->stream,
-                           (const uint2 *)b->pk_codes.as<uint2>(), nwords, b->total_bases, (uint32_t *)nullptr, b->bases.as<uint8_t>());
+                           b->pk_zc ? (const uint2 *)b->pk_zc : (const uint2 *)b->pk_codes.as<uint2>(), nwords, b->total_bases, (uint32_t *)nullptr, b->bases.as<uint8_t>());
     if (b->pk_nexc)            // the exceptions' bytes over the code bytes (their plane bits are set already; setting them again changes nothing)
         hipLaunchKernelGGL(k_unpack_exc, dim3((uint32_t)std::min<uint64_t>(cdiv(b->pk_nexc, 256), (uint64_t)cus * 8)), dim3(256), 0, b->stream,
                            (const uint64_t *)b->pk_exc.as<uint64_t>(), b->pk_nexc, b->total_bases, b->rplanes.as<uint32_t>(), b->bases.as<uint8_t>(),

@@ -131,5 +131,24 @@ int main() {
         for (int i = 0; i < reps; i++) { CK(hipMemcpyAsync(pg.data(), dp, bytes, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
         printf("f  hipMemcpyAsync 64 KB device -> PAGEABLE + sync       %8.2f us\n", us_since(t) / reps);
     }
+    {   // g: a batch's worth of packed reads (312.5 MB) from pinned host memory: DMA against a kernel reading it (zero-copy), by grid
+        const size_t bytes = 312500000ull / 16 * 16;
+        uint8_t *hp = nullptr, *dp = nullptr;
+        CK(hipHostMalloc((void **)&hp, bytes, hipHostMallocDefault)); CK(hipMalloc(&dp, bytes));
+        memset(hp, 3, bytes);
+        for (int i = 0; i < 2; i++) { CK(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
+        auto t = clk::now();
+        for (int i = 0; i < 5; i++) { CK(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
+        double us = us_since(t) / 5;
+        printf("g  hipMemcpyAsync 312.5 MB pinned -> device             %8.0f us  (%.1f GB/s)\n", us, bytes / us / 1e3);
+        for (int G : {16, 64, 256, 1024, 4096}) {
+            hipLaunchKernelGGL(k_copy, dim3(G), dim3(256), 0, s, (const uint4 *)hp, (uint4 *)dp, bytes / 16, (volatile unsigned int *)hflag, 0u);
+            CK(hipStreamSynchronize(s));
+            t = clk::now();
+            for (int i = 0; i < 5; i++) { hipLaunchKernelGGL(k_copy, dim3(G), dim3(256), 0, s, (const uint4 *)hp, (uint4 *)dp, bytes / 16, (volatile unsigned int *)hflag, 0u); CK(hipStreamSynchronize(s)); }
+            us = us_since(t) / 5;
+            printf("g  kernel reads 312.5 MB of pinned memory, %4d blocks   %8.0f us  (%.1f GB/s)\n", G, us, bytes / us / 1e3);
+        }
+    }
     return 0;
 }
