@@ -709,7 +709,13 @@ int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
     // up_zero_copy: the codes stay where they are (pinned host memory) and k_unpack_reads reads them over the link -- one stream of
     // reads instead of a DMA into HBM followed by a kernel over the copy; the upload is then over when that kernel is
-    const bool zc = b->opt.up_zero_copy == 1 && nwords;
+    // (only when `codes` really is pinned: a kernel reading pageable memory faults, so anything else is copied as before)
+    bool zc = false;
+    if (b->opt.up_zero_copy >= 1 && nwords) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, codes) == hipSuccess) zc = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
     b->pk_zc = zc ? codes : nullptr;
     if (nwords && !zc) HIPCHK(hipMemcpyAsync(b->pk_codes.p, codes, nwords * 8, hipMemcpyHostToDevice, b->stream));
     if (n_exc) HIPCHK(hipMemcpyAsync(b->pk_exc.p, exc, n_exc * 8, hipMemcpyHostToDevice, b->stream));
@@ -733,7 +739,7 @@ int bwt_batch_set_reads_packed_hook(bwt_batch *b, const uint32_t *codes, uint64_
         // the DP kernels (it lists the candidates that reach them: stage_extend makes those reads' bytes then)
         const bool all_ascii = b->opt.sw_prefilter == 0;
         if (nwords)
-            hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), zc ? (uint64_t)cus * 2 : (uint64_t)cus * 16)), dim3(256), 0, b->stream,
+            hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(cdiv(nwords, 256), zc ? (uint64_t)(b->opt.up_zero_copy == 1 ? 64 : b->opt.up_zero_copy) : (uint64_t)cus * 16)), dim3(256), 0, b->stream,
                                zc ? (const uint2 *)codes : (const uint2 *)b->pk_codes.as<uint2>(), nwords, total, b->rplanes.as<uint32_t>(),
                                all_ascii ? b->bases.as<uint8_t>() : (uint8_t *)nullptr);
         if (uploaded && zc) HIPCHK(hipEventRecord(b->ev_uploaded, b->stream));

@@ -74,8 +74,10 @@ typedef struct {
     int32_t debug;              /* 1: diagnostic lines on stderr (hand-back reasons of k_seed_fast) */
     int32_t hits_narrow;        /* 1: the hit table is made in its NARROW form (bwt_batch_fetch_hits_narrow; a pipe's results then carry it) */
     int32_t sw_band12;          /* 0: no 12-diagonal tier in front of the banded DP tiers (square windows with <= 6 mismatches start at 20 diagonals) */
-    int32_t up_zero_copy;       /* 1: a packed upload whose `codes` buffer is PINNED host memory (a pipe slot's is) is not copied: the unpack
-                                   kernel reads it over the link itself.  Only set it for buffers from hipHostMalloc / a pipe. */
+    int32_t up_zero_copy;       /* >= 1: a packed upload whose `codes` buffer is PINNED host memory (a pipe slot's is; the library asks
+                                   hipPointerGetAttributes) is not copied: the unpack kernel reads it over the link itself, with 64
+                                   workgroups (1) or with this many (> 1).  A pageable buffer is copied as always.  Off by default:
+                                   DESIGN 8 has the measurement. */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 

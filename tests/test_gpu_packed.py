@@ -420,3 +420,38 @@ def test_pipe_results_in_the_narrow_form(gpu_index, ref_bytes):
             pipe.release(r["slot"])
     finally:
         pipe.close()
+
+
+def test_zero_copy_upload_only_reads_pinned_buffers(gpu_index, ref_bytes):
+    """up_zero_copy = 1: a pipe slot's pinned `codes` buffer is read in place by the unpack kernel (no copy into device memory); a
+    caller's pageable buffer under the same option is copied as before (a kernel reading it would fault).  Both give the default
+    upload's table, with and without the whole-batch ASCII pass (sw_prefilter = 0 reads the codes a second time)."""
+    from bwt_amd import lib
+    reads = synth_reads(ref_bytes, 3000, 100, 15, max_subs=2) + mixed(ref_bytes, 100, 16)
+    bases, off = lib.pack_reads(reads)
+    want = gpu_index.align_batch(bases, off)
+    codes, exc = lib.pack_2bit(bases)
+    for extra in ({}, {"sw_prefilter": 0}):
+        pipe = lib.Pipe(gpu_index, depth=2)
+        pipe.set_options(up_zero_copy=1, **extra)
+        try:
+            for _ in range(3):
+                s, v = pipe.acquire_packed(len(bases), len(reads), len(exc))
+                v["codes"][:len(codes)] = codes; v["exc"][:len(exc)] = exc
+                pipe.submit_packed(s, len(reads), 100, len(bases), len(exc))
+                r = pipe.wait()
+                out = pipe.expand(r)
+                for k in KEYS:
+                    assert np.array_equal(out[k], want[k]), k
+                assert out["cigar"] == want["cigar"]
+                pipe.release(r["slot"])
+        finally:
+            pipe.close()
+        b = lib.Batch(gpu_index)
+        b.set_options(up_zero_copy=1, **extra)
+        b.set_reads_packed(codes, exc, len(reads), read_len=100)       # numpy arrays: pageable
+        b.run(lib.STAGE_EXTEND)
+        got = b.fetch_hits()
+        for k in KEYS:
+            assert np.array_equal(got[k], want[k]), k
+        b.destroy()
