@@ -3407,11 +3407,15 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
     if (!q_over) { q_over = io.tq; q_over_count = &io.ctr->tq_count; }
     if (n_total == 0 || n_total > thresh) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    // (wave-uniform, and the compiler is told so: the item's lengths and the step loop then live in scalar registers)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t *bl = lds_wv + (size_t)(threadIdx.x >> 6) * (maxW1 + (size_t)max_lq * dwords);    // boundary row [j]
     uint32_t *dirs = bl + maxW1;                                                                  // [row][step >> 4]
     for (uint32_t item = wave; item < n_total; item += nwaves) {
+#ifdef SWV_TIMING
+        const uint64_t T0 = wall_clock64();
+#endif
         const uint32_t c = q_in[item];
         const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
         const int64_t wo = io.c_woff[c];
@@ -3419,7 +3423,8 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
             if (lane == 0) { io.c_status[c] = CS_WINDOW_OOR; io.c_ciglen[c] = 0; }
             continue;
         }
-        if (w + 1 > maxW1 || lq > max_lq) {                      // wider than this launch's LDS was sized for -> the next kernel's queue
+        if (w + 1 > maxW1 || lq > max_lq || w > 4094u) {         // wider than this launch's LDS was sized for (or than the column field of
+                                                                 // the last row's key) -> the next kernel's queue
             if (lane == 0) { io.c_status[c] = CS_PENDING; q_over[atomicAdd(q_over_count, 1u)] = c; }
             continue;
         }
@@ -3427,8 +3432,12 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
         const uint8_t *rw = io.rbuf + wo;
         for (uint32_t j = lane; j <= w; j += 64) bl[j] = DIR_UNDEF;           // row 0: {0, undef}
         __builtin_amdgcn_wave_barrier();
-        int best = -(int)(lq + 1) * 4 + DIR_UP;                               // V(Lq, 0)
-        uint32_t bestj = 0;
+#ifdef SWV_TIMING
+        const uint64_t T1 = wall_clock64();
+#endif
+        // leftmost maximum of the last row, as a key: (V << 12) | (4095 - column) -- the larger value wins, among equal values the
+        // smaller column (a window of this kernel is never 4095 bases wide); V(Lq, 0) to begin with
+        int bestkey = (int)(((uint32_t)(-(int)(lq + 1)) << 12) | 4095u);
         // Strips of 128 query rows, TWO ROWS PER LANE (lane t: rows i0 + 2t and i0 + 2t + 1), swept along anti-diagonals of lane
         // pairs: at step k lane t fills column k - t of its upper row and then of its lower one -- the lower cell's `up` is the
         // cell just made, its diagonal the upper row's previous cell, both in registers.  A 100-base read is ONE strip of
@@ -3436,11 +3445,15 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
         // and base, the next window base and boundary value for lane 0, the loop -- is paid once per two cells.
         // Per step a lane needs two values of the lane above it -- that lane's lower cell of the step before (the row above at my
         // column) and the window base it worked on -- and lane 0 needs the next window base and the next value of the boundary
-        // row.  All of it stays in registers: window bases and boundary values are fetched 64 at a time, one per lane, and
-        // handed to lane 0 by v_readlane; the shift down the wave is a DPP move (wave_shr:1, lane 0 keeps the `old` operand).
-        // The step itself is branch-free: a lane outside its rows' columns computes cells nobody keeps.  A row's 2-bit
-        // directions are filed by STEP (word k >> 4, bits 2 (k & 15); column j of lane t at step j + t), so that every
-        // lane stores its words at the same steps -- a scalar branch, not a per-lane one.
+        // row.  All of it stays in registers: window bases and boundary values are fetched 64 at a time, one per lane, and move
+        // UP one lane per step (DPP wave_shl:1), so that lane 0 always holds the next one; the shift down the wave is a DPP move
+        // too (wave_shr:1, lane 0 keeps the `old` operand).
+        // The step is branch-free and as short as it gets (a single wave per SIMD issues one instruction every few cycles: the
+        // kernel's time is its instruction count -- 33 us for a 100 x 110 window at ~90 instructions per step before this form):
+        // a lane computes from the first step on, its cells are only KEPT once its column is >= 1 (what it makes past column W is
+        // read by nobody: the lane below is past W by then as well); a row's 2-bit directions are shifted into a word from the top,
+        // one v_alignbit per cell, filed by STEP (word k >> 4, bits 2 (k & 15); column j of lane t at step j + t), so that
+        // every lane stores its words at the same steps -- a scalar branch.
         const uint32_t ns = (lq + 127) / 128;
         for (uint32_t s = 0; s < ns; s++) {
             const uint32_t i0 = s * 128, ia = i0 + 2 * lane, ib = ia + 1;       // 0-based query rows of this lane
@@ -3453,61 +3466,75 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
             const uint32_t nrow = lq - i0 < 128u ? lq - i0 : 128u;              // rows of this strip
             const uint32_t nlane = (nrow + 1) >> 1;                             // lanes that carry one
             const uint32_t ksteps = w + nlane - 1;                              // its last lane reaches column w at this step
-            const bool has_next = s + 1 < ns, last_strip = !has_next;
-            const uint32_t wla = oka ? w : 0u, wlb = okb ? w : 0u;              // j - 1 < wl  <=>  the row exists and 1 <= j <= w
+            const bool has_next = s + 1 < ns;
             const bool last_is_b = ((lq - 1 - i0) & 1u) != 0;                   // (wave-uniform; only looked at in the last strip)
-            const bool lastlane = lane == ((lq - 1 - i0) >> 1);
+            const uint32_t ll = (lq - 1 - i0) >> 1;                             // ... the lane with the read's last row
+            const bool lastlane = lane == ll;
             uint32_t *drow_a = dirs + (size_t)(oka ? ia : 0u) * dwords, *drow_b = dirs + (size_t)(okb ? ib : 0u) * dwords;
             // (steps in chunks of 64: the chunk's window bases and boundary values are loaded -- and waited for -- once, in front of
-            // an inner loop that reads nothing from memory)
-            for (uint32_t kb0 = 0; kb0 < ksteps; kb0 += 64) {
-                const uint32_t wch = kb0 + lane < w ? rw[kb0 + lane] : 0u;          // window bases of columns kb0 + 1.., one per lane
-                const int bch = (int)bl[kb0 + 1 + lane <= w ? kb0 + 1 + lane : 0];  // boundary row (the strip above) at those columns
-                const uint32_t kend = kb0 + 64 < ksteps ? kb0 + 64 : ksteps;
-                for (uint32_t k = kb0 + 1; k <= kend; k++) {
-                    const int sel = (int)(k - 1 - kb0);
-                    const int nb = __builtin_amdgcn_readlane((int)wch, sel);
-                    const int ub = __builtin_amdgcn_readlane(bch, sel);
-                    const int ua = __builtin_amdgcn_update_dpp(ub, hb, 0x138, 0xF, 0xF, false);          // wave_shr:1; lane 0: the boundary row
-                    rc = (uint32_t)__builtin_amdgcn_update_dpp(nb, (int)rc, 0x138, 0xF, 0xF, false);     // ... lane 0: the next window base
-                    const uint32_t j = k - lane;                                // my column at this step
-                    const bool ona = j - 1u < wla, onb = j - 1u < wlb;
-                    // upper row: diagonal da (row above, column j - 1), left ha, up ua
-                    const int cda = (da | 3) + ((qa == rc) ? 7 : -5);           // 4(Vul + sigma) + up_left
-                    const int cla = ha + __builtin_amdgcn_sbfe((int)0xF5F6F7FCu, (uint32_t)(ha & 3) * 8u, 8u);   // {-4,-9,-10,-11}
-                    const int cua = ua + __builtin_amdgcn_sbfe((int)0xF6F7FCF9u, (uint32_t)(ua & 3) * 8u, 8u);   // {-7,-4,-9,-10}
-                    int hna = cda > cla ? cda : cla;
-                    hna = hna > cua ? hna : cua;
-                    // lower row: diagonal = the upper row's cell of column j - 1 (ha as it still is), left hb, up = the cell just made
-                    const int cdb = (ha | 3) + ((qb == rc) ? 7 : -5);
-                    const int clb = hb + __builtin_amdgcn_sbfe((int)0xF5F6F7FCu, (uint32_t)(hb & 3) * 8u, 8u);
-                    const int cub = hna + __builtin_amdgcn_sbfe((int)0xF6F7FCF9u, (uint32_t)(hna & 3) * 8u, 8u);
-                    int hnb = cdb > clb ? cdb : clb;
-                    hnb = hnb > cub ? hnb : cub;
-                    const uint32_t sh2 = 2u * (k & 15u);
-                    dwa |= ona ? (uint32_t)(hna & 3) << sh2 : 0u;
-                    dwb |= onb ? (uint32_t)(hnb & 3) << sh2 : 0u;
-                    ha = ona ? hna : ha;
-                    hb = onb ? hnb : hb;
-                    if (has_next) { if (lane == 63 && onb) bl[j] = (uint32_t)hnb; }   // boundary row for the next strip (its 128th row)
-                    if (last_strip) {                                           // leftmost maximum of the last row
-                        const int hl = last_is_b ? hnb : hna;
-                        const bool take = (last_is_b ? onb : ona) && lastlane && (hl >> 2) > (best >> 2);
-                        best = take ? hl : best; bestj = take ? j : bestj;
+            // an inner loop that reads nothing from memory; HN: another strip follows, this one's last row is its boundary row)
+            auto sweep = [&](auto HN) {
+                for (uint32_t kb0 = 0; kb0 < ksteps; kb0 += 64) {
+                    int wch = kb0 + lane < w ? (int)rw[kb0 + lane] : 0;             // window bases of columns kb0 + 1.., one per lane
+                    int bch = (int)bl[kb0 + 1 + lane <= w ? kb0 + 1 + lane : 0];    // boundary row (the strip above) at those columns
+                    const uint32_t kend = kb0 + 64 < ksteps ? kb0 + 64 : ksteps;
+                    for (uint32_t k = kb0 + 1; k <= kend; k++) {
+                        const int ua = __builtin_amdgcn_update_dpp(bch, hb, 0x138, 0xF, 0xF, false);             // wave_shr:1; lane 0: the boundary row
+                        rc = (uint32_t)__builtin_amdgcn_update_dpp(wch, (int)rc, 0x138, 0xF, 0xF, false);        // ... lane 0: the next window base
+                        wch = __builtin_amdgcn_update_dpp(wch, wch, 0x130, 0xF, 0xF, false);                     // wave_shl:1: the chunk moves up a lane
+                        bch = __builtin_amdgcn_update_dpp(bch, bch, 0x130, 0xF, 0xF, false);
+                        const bool on = k > lane;                                   // my column k - lane is >= 1
+                        // upper row: diagonal da (row above, column j - 1), left ha, up ua.  (v_bfe takes the low five bits of its
+                        // offset operand: h << 3 selects the byte of h's direction code)
+                        const int cda = (da | 3) + ((qa == rc) ? 7 : -5);           // 4(Vul + sigma) + up_left
+                        const int cla = ha + __builtin_amdgcn_sbfe((int)0xF5F6F7FCu, (uint32_t)ha << 3, 8u);   // {-4,-9,-10,-11}
+                        const int cua = ua + __builtin_amdgcn_sbfe((int)0xF6F7FCF9u, (uint32_t)ua << 3, 8u);   // {-7,-4,-9,-10}
+                        int hna = cda > cla ? cda : cla;
+                        hna = hna > cua ? hna : cua;
+                        // lower row: diagonal = the upper row's cell of column j - 1 (ha as it still is), left hb, up = the cell just made
+                        const int cdb = (ha | 3) + ((qb == rc) ? 7 : -5);
+                        const int clb = hb + __builtin_amdgcn_sbfe((int)0xF5F6F7FCu, (uint32_t)hb << 3, 8u);
+                        const int cub = hna + __builtin_amdgcn_sbfe((int)0xF6F7FCF9u, (uint32_t)hna << 3, 8u);
+                        int hnb = cdb > clb ? cdb : clb;
+                        hnb = hnb > cub ? hnb : cub;
+                        dwa = __builtin_amdgcn_alignbit((uint32_t)hna, dwa, 2u);    // the cell's direction in at the top
+                        dwb = __builtin_amdgcn_alignbit((uint32_t)hnb, dwb, 2u);
+                        ha = on ? hna : ha;
+                        hb = on ? hnb : hb;
+                        if (decltype(HN)::value) {
+                            const uint32_t j = k - lane;
+                            if (lane == 63 && j - 1u < w) bl[j] = (uint32_t)hnb;    // boundary row for the next strip (its 128th row)
+                        } else {
+                            // the last row's cells go to the boundary array as well (their columns are behind what this chunk took from
+                            // it): its leftmost maximum is looked for once, after the sweep, not compared at every step
+                            if (lastlane && k > ll) bl[k - ll] = (uint32_t)(last_is_b ? hnb : hna);
+                        }
+                        if ((k & 15u) == 15u || k == ksteps) {
+                            const uint32_t sh = 30u - 2u * (k & 15u);               // a last word that is not full: down to its place
+                            if (oka) drow_a[k >> 4] = dwa >> sh;
+                            if (okb) drow_b[k >> 4] = dwb >> sh;
+                        }
+                        da = ua;                                                    // the row above at my column: next step's diagonal
                     }
-                    if ((k & 15u) == 15u || k == ksteps) {
-                        if (oka) drow_a[k >> 4] = dwa;
-                        if (okb) drow_b[k >> 4] = dwb;
-                        dwa = 0; dwb = 0;
-                    }
-                    da = ua;                                                    // the row above at my column: next step's diagonal
                 }
-            }
+            };
+            if (has_next) sweep(std::true_type{}); else sweep(std::false_type{});
             __builtin_amdgcn_wave_barrier();
         }
-        const int ll = (int)(((lq - 1) & 127u) >> 1);                           // lane that owns the last row
-        best = __builtin_amdgcn_readlane(best, ll);
-        bestj = (uint32_t)__builtin_amdgcn_readlane((int)bestj, ll);
+#ifdef SWV_TIMING
+        const uint64_t T2 = wall_clock64();
+#endif
+        for (uint32_t j0 = 1; j0 <= w; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            if (j <= w) {
+                const int key = (int)(((uint32_t)((int)bl[j] >> 2) << 12) | (4095u - j));
+                bestkey = key > bestkey ? key : bestkey;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(bestkey, o, 64); bestkey = other > bestkey ? other : bestkey; }
+        const int best = (bestkey >> 12) * 4;                                   // (as 4 V + code: the score is best >> 2)
+        const uint32_t bestj = 4095u - ((uint32_t)bestkey & 4095u);
         {
             // sw.erl:69 after the last row: no_match iff RowMax < -2*(Lq div 2) + 2*Lq
             const int thr = -2 * (int)(lq / 2) + 2 * (int)lq;
@@ -3547,6 +3574,13 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
                 }
             }
         }
+#ifdef SWV_TIMING
+        if (lane == 0) {
+            const uint64_t T3 = wall_clock64();
+            atomicMax(&io.ctr->pad2_[0], (unsigned int)(T1 - T0)); atomicMax(&io.ctr->pad2_[1], (unsigned int)(T2 - T1));
+            atomicMax(&io.ctr->pad2_[2], (unsigned int)(T3 - T2)); atomicMax(&io.ctr->band0_next, w);
+        }
+#endif
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -3629,11 +3663,12 @@ struct HitRec { uint32_t read; int32_t score; int64_t pos; };   // the 16-byte r
 struct HitExtra { uint32_t hit, win_len, cig_off, cig_len; };   // bwt_hit_extra
 
 // one hit: its record, and for a hit that is not plain its extra record and text
-__device__ __forceinline__ void hit_put(uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf, int32_t shift,
-                                    const int32_t *__restrict__ c_score, const uint32_t *__restrict__ c_S, const uint8_t *__restrict__ cig,
-                                    uint32_t cig_stride, HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec, uint8_t *__restrict__ x_cig) {
-    HitRec hr; hr.read = rd; hr.score = c_score[k];
-    hr.pos = (int64_t)c_S[k] - (int64_t)wl + shift;            // worker_bwt.erl:94
+// (score / S: the candidate's c_score / c_S, loaded by the caller -- with those of its neighbours where it can have them in flight together)
+__device__ __forceinline__ void hit_put_v(uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf, int32_t shift,
+                                      int32_t score, uint32_t S, const uint8_t *__restrict__ cig,
+                                      uint32_t cig_stride, HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec, uint8_t *__restrict__ x_cig) {
+    HitRec hr; hr.read = rd; hr.score = score;
+    hr.pos = (int64_t)S - (int64_t)wl + shift;                 // worker_bwt.erl:94
     h_rec[ho1] = hr;
     if (!(clf & CIG_DIAG)) {
         HitExtra x; x.hit = (uint32_t)ho1; x.win_len = wl; x.cig_off = (uint32_t)co1; x.cig_len = clf;
@@ -3659,6 +3694,12 @@ __device__ __forceinline__ void hit_put(uint32_t rd, uint64_t k, uint64_t ho1, u
             if (take & 1) *p = (uint8_t)lo;
         }
     }
+}
+
+__device__ __forceinline__ void hit_put(uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf, int32_t shift,
+                                    const int32_t *__restrict__ c_score, const uint32_t *__restrict__ c_S, const uint8_t *__restrict__ cig,
+                                    uint32_t cig_stride, HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec, uint8_t *__restrict__ x_cig) {
+    hit_put_v(rd, k, ho1, xo1, co1, wl, clf, shift, c_score[k], c_S[k], cig, cig_stride, h_rec, x_rec, x_cig);
 }
 
 __global__ __launch_bounds__(256) void k_hits_write(uint32_t n, int32_t shift, const uint64_t *__restrict__ clus_off,

@@ -22,6 +22,8 @@
 #define SMALL_SEED_CAP (1u << 20)            // seeds left to the cluster kernels (u32 positions)
 #define SMALL_CAND_CAP 32768u                // candidates (= k_sw_wave's queue limit)
 #define SMALL_W_TRACE 2048u                  // widest window the generic traced / fp64 kernels of this path are sized for
+#define SMALL_SEQ_OFF (((size_t)SMALL_MAX_READS + 1) * 8)   // the call number's place in the pinned input block (behind the offsets)
+#define SMALL_ONE_PASS 256u                  // reads up to which k_sw_wave runs once, with full LDS
 #define SMALL_ERR_CAP 16ull                  // Counters::err_flags: a capacity of this path did not hold
 
 struct SmallZero { uint32_t *p[8]; uint32_t words[8]; };
@@ -30,8 +32,12 @@ struct SmallZero { uint32_t *p[8]; uint32_t words[8]; };
 // the arrays the seed stage expects zeroed and the batch's counters.  h_bases is 16-byte aligned.
 __global__ __launch_bounds__(256) void k_small_in(const uint64_t *__restrict__ h_off, const uint8_t *__restrict__ h_bases, uint32_t n,
                                                    uint64_t total, uint64_t *__restrict__ off, uint8_t *__restrict__ bases,
-                                                   uint32_t *__restrict__ planes, uint64_t plane_words, SmallZero z) {
+                                                   uint32_t *__restrict__ planes, uint64_t plane_words, SmallZero z,
+                                                   const unsigned long long *__restrict__ h_seq, unsigned long long *__restrict__ d_seq) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+    // the call's number, for the `done` word the last kernel writes: it travels in the pinned block, not as a launch argument, so
+    // that a captured graph of these launches can be replayed as it is
+    if (tid == 0) *d_seq = *h_seq;
     const uint64_t nseg = (((total + 15) >> 4) + 1) & ~1ull;
     for (uint64_t s = tid; s < nseg; s += nthreads) {
         uint32_t x[4];
@@ -75,47 +81,63 @@ __global__ __launch_bounds__(256) void k_small_scan(SmallScan a, uint32_t n, Cou
 
 // the compact hit table and the run's counters into the pinned result block
 struct SmallHeader { unsigned long long n_hits, n_extra, xcig_bytes, n_cand; Counters ctr; unsigned long long done; };
-__global__ __launch_bounds__(256) void k_small_out(uint32_t n, const uint64_t *__restrict__ hit_off, const uint64_t *__restrict__ x_off,
-                                                    const uint64_t *__restrict__ xcb_off, const uint64_t *__restrict__ clus_off,
-                                                    const int8_t *__restrict__ r_status, const uint4 *__restrict__ h_rec,
-                                                    const uint4 *__restrict__ x_rec, const uint8_t *__restrict__ x_cig, const Counters *__restrict__ ctr,
-                                                    SmallHeader *__restrict__ o_hdr, int8_t *__restrict__ o_status, uint4 *__restrict__ o_hits,
-                                                    uint4 *__restrict__ o_extra, uint8_t *__restrict__ o_cig, uint64_t cap_text) {
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t nh = hit_off[n], nx = x_off[n], nt = xcb_off[n];
-    const bool fits = nh <= SMALL_CAND_CAP && nx <= SMALL_CAND_CAP && nt <= cap_text;
-    if (tid == 0) {
-        o_hdr->n_hits = nh; o_hdr->n_extra = nx; o_hdr->xcig_bytes = nt; o_hdr->n_cand = clus_off[n];
-        Counters c = *ctr;
-        if (!fits) c.err_flags |= SMALL_ERR_CAP;
-        o_hdr->ctr = c;
-    }
-    if (!fits) return;
-    for (uint64_t i = tid; i < (n + 3u) / 4u; i += nthreads) ((uint32_t *)o_status)[i] = ((const uint32_t *)r_status)[i];
-    for (uint64_t i = tid; i < nh; i += nthreads) o_hits[i] = h_rec[i];
-    for (uint64_t i = tid; i < nx; i += nthreads) o_extra[i] = x_rec[i];
-    for (uint64_t i = tid; i < (nt + 3) / 4; i += nthreads) ((uint32_t *)o_cig)[i] = ((const uint32_t *)x_cig)[i];
-}
 
 // hits_count + the three scans + hits_write + the copy out as ONE launch of SMALL_HIT_BLOCKS co-resident blocks (one read per lane):
 //   phase 1  a lane counts its read's hits / extras / text bytes (hit_count_one, as k_hits_count); block totals to bt[]
 //   barrier  an atomic counter every block bumps once and spins on (Counters::pad_, cleared by k_small_in; 16 blocks: ~1 us,
 //            profiles/r4/launch_probe.txt); the spin gives up after ~1 s and flags the batch, so every wave leaves
 //   phase 2  a lane's offsets = the totals of the blocks before its own + its place in the block's scan
-//   phase 3  hit_put (as k_hits_write) straight into the pinned result block; block 0 writes the header
-// A read with more than HITS_FAT candidates (the general kernels take those a wave at a time) raises the capacity flag.
+//   phase 3  hit_put (as k_hits_write) into a device copy of the result block
+//   barrier  (the same counter, on to 2 x blocks)
+//   phase 4  the used part of every section goes to the pinned block 16 bytes a lane, whole lines per wave; block 0 writes the header.
+//            (hit_put's records and text pieces written to host memory one by one -- a status byte, a 16-byte record, 1..8 bytes of
+//            text per store, each its own transaction on the link -- made this kernel 30 us for a list of 200 reads.)
+// one hit into the small path's table.  As hit_put, but the text of a hit that is not plain is not packed against its neighbour's:
+// it takes the whole 16-byte pieces of its slot that hold it (a text sits right-aligned in its slot, slots are 16-byte aligned), so
+// that it moves as one or two uint4 instead of byte pieces at an odd address -- bwt_hit_extra names offset and length of every
+// text, bwt_hits_expand asks for nothing more.  co1: a multiple of 16; returns the bytes taken.
+__device__ __forceinline__ uint32_t small_text_bytes(uint32_t clf) { return (clf + 15u) & ~15u; }
+__device__ __forceinline__ void hit_put_small(uint32_t rd, uint64_t k, uint64_t ho1, uint64_t xo1, uint64_t co1, uint32_t wl, uint32_t clf, int32_t shift,
+                                          int32_t score, uint32_t S, const uint8_t *__restrict__ cig, uint32_t cig_stride,
+                                          HitRec *__restrict__ h_rec, HitExtra *__restrict__ x_rec, uint8_t *__restrict__ x_cig) {
+    HitRec hr; hr.read = rd; hr.score = score;
+    hr.pos = (int64_t)S - (int64_t)wl + shift;                 // worker_bwt.erl:94
+    h_rec[ho1] = hr;
+    if (!(clf & CIG_DIAG)) {
+        const uint32_t padded = small_text_bytes(clf);
+        HitExtra x; x.hit = (uint32_t)ho1; x.win_len = wl; x.cig_off = (uint32_t)co1 + (padded - clf); x.cig_len = clf;
+        x_rec[xo1] = x;
+        const uint4 *src = (const uint4 *)(cig + (k + 1) * (uint64_t)cig_stride - padded);
+        uint4 *dst = (uint4 *)(x_cig + co1);
+        for (uint32_t i = 0; i < padded / 16; i++) dst[i] = src[i];
+    }
+}
+
 #define SMALL_HIT_BLOCKS (SMALL_MAX_READS / 256u)
 __global__ __launch_bounds__(256) void k_small_hits(uint32_t n, int32_t shift, const uint64_t *__restrict__ clus_off,
                                                      const int32_t *__restrict__ c_status, const int32_t *__restrict__ c_score,
                                                      const uint32_t *__restrict__ c_ciglen, const uint32_t *__restrict__ c_S,
                                                      const uint32_t *__restrict__ c_wlen, const uint8_t *__restrict__ cig, uint32_t cig_stride,
                                                      const uint32_t *__restrict__ r_qty, Counters *ctr, unsigned long long *bt /* blocks x 4 */,
-                                                     SmallHeader *__restrict__ o_hdr, int8_t *__restrict__ o_status, HitRec *__restrict__ o_hits,
-                                                     HitExtra *__restrict__ o_extra, uint8_t *__restrict__ o_cig, uint64_t cap_text,
-                                                     unsigned long long seq) {
-    // seq: the call's number; the LAST block to finish writes it to the header's `done` word -- every block fences its writes to
+                                                     uint8_t *__restrict__ h_out, uint8_t *__restrict__ d_out, uint32_t off_status, uint32_t off_hits,
+                                                     uint32_t off_extra, uint32_t off_cig, uint64_t cap_text,
+                                                     const unsigned long long *__restrict__ d_seq) {
+    // h_out: the pinned result block (header at 0, then the four sections at off_*); d_out: its copy in device memory
+    SmallHeader *const o_hdr = (SmallHeader *)h_out;
+    int8_t *const o_status = (int8_t *)(d_out + off_status);
+    HitRec *const o_hits = (HitRec *)(d_out + off_hits);
+    HitExtra *const o_extra = (HitExtra *)(d_out + off_extra);
+    uint8_t *const o_cig = d_out + off_cig;
+    // *d_seq: the call's number (k_small_in left it there); the LAST block to finish writes it to the header's `done` word -- every block fences its writes to
     // host memory and bumps the counter once more, and the host, spinning on that word, knows the whole table has landed without
     // paying hipStreamSynchronize's wake-up (6 against 12 us, profiles/r4/launch_probe.txt)
+#ifdef SMALL_HITS_TIMING
+    unsigned long long TT[12]; int tti = 0;
+#define TMARK() do { __syncthreads(); TT[tti++] = wall_clock64(); } while (0)
+#else
+#define TMARK() do { } while (0)
+#endif
+    TMARK();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < n;
     uint32_t nh = 0, nx = 0, xcb = 0;
@@ -124,9 +146,53 @@ __global__ __launch_bounds__(256) void k_small_hits(uint32_t n, int32_t shift, c
     if (valid && (r_qty[r] >> 31)) st = -1;
     const uint64_t a = valid ? clus_off[r] : 0ull, b = valid ? clus_off[r + 1] : 0ull;
     if (b > a) st = 0;
-    if (b - a > HITS_FAT) atomicOr(&ctr->err_flags, SMALL_ERR_CAP);
-    else for (uint64_t k = a; k < b; k++) hit_count_one(c_status[k], c_ciglen, k, nh, nx, xcb, cbr, st, ctr);
+    // Counting and writing both take the wave's 64 reads' candidates -- one contiguous range -- 64 at a time, a LANE PER CANDIDATE;
+    // a lane finds its candidate's read by bisection over the reads' range ends (sb[], relative to the wave's first candidate).
+    // (A lane per READ looping over its candidates: a contig's repeats give a few reads per list thirty clusters each, and those
+    // lanes' loops were 24 of this kernel's 30 us.)
+    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ uint32_t sb_all[4][64];
+    __shared__ uint32_t acc_all[4][64][5];                // per read: hits, extras, text bytes (padded), CIGAR bytes, window out of range
+    uint32_t *const sb = sb_all[threadIdx.x >> 6];
+    uint32_t (*const acc)[5] = acc_all[threadIdx.x >> 6];
+    const uint32_t r0 = r - lane;
+    const bool wave_on = r0 < n;
+    const uint32_t nvalid = wave_on ? (n - r0 < 64u ? n - r0 : 64u) : 1u;
+    const uint64_t A = (uint64_t)__shfl((long long)a, 0, 64), B = (uint64_t)__shfl((long long)b, (int)nvalid - 1, 64);
+    sb[lane] = valid ? (uint32_t)(b - A) : 0xffffffffu;                          // (at most SMALL_CAND_CAP candidates in all)
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[lane][i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    auto read_of = [&](uint32_t krel) {                                          // the first read whose range ends behind candidate A + krel
+        uint32_t lo = 0, hi = nvalid - 1;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool gt = sb[mid] > krel;
+            hi = gt ? mid : hi; lo = gt ? lo : (mid + 1 < hi ? mid + 1 : hi);
+        }
+        return lo;
+    };
+    if (wave_on) {
+        for (uint64_t k0 = A; k0 < B; k0 += 64) {
+            const uint64_t k = k0 + lane;
+            if (k < B) {
+                const int32_t cs = c_status[k];
+                const uint32_t clf = c_ciglen[k];
+                const uint32_t L = read_of((uint32_t)(k - A));
+                if (cs == CS_OK) {
+                    atomicAdd(&acc[L][0], 1u); atomicAdd(&acc[L][3], clf & ~CIG_DIAG);
+                    if (!(clf & CIG_DIAG)) { atomicAdd(&acc[L][1], 1u); atomicAdd(&acc[L][2], small_text_bytes(clf)); }
+                } else if (cs == CS_WINDOW_OOR) atomicOr(&acc[L][4], 1u);
+                else if (cs != CS_NO_MATCH) atomicOr(&ctr->err_flags, cs == CS_CIG_OVERFLOW ? 2ull : 4ull);      // (as hit_count_one)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nh = acc[lane][0]; nx = acc[lane][1]; xcb = acc[lane][2]; cbr = acc[lane][3];
+        if (acc[lane][4]) st = -2;
+    }
     if (st == -2) { nh = 0; nx = 0; xcb = 0; cbr = 0; }
+    TMARK();
     uint64_t eh, ex, et, ec;
     const uint64_t th = block_scan_u64(nh, eh);
     __syncthreads();
@@ -146,6 +212,7 @@ __global__ __launch_bounds__(256) void k_small_hits(uint32_t n, int32_t shift, c
         }
     }
     __syncthreads();
+    TMARK();
     uint64_t bh = 0, bx = 0, btx = 0, gh = 0, gx = 0, gt = 0, gc = 0;
     for (uint32_t k = 0; k < gridDim.x; k++) {
         const uint64_t v0 = __hip_atomic_load(&bt[k * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(&bt[k * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -155,30 +222,104 @@ __global__ __launch_bounds__(256) void k_small_hits(uint32_t n, int32_t shift, c
     }
     const unsigned long long flags = __hip_atomic_load(&ctr->err_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool fits = gh <= SMALL_CAND_CAP && gx <= SMALL_CAND_CAP && gt <= cap_text && flags == 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        o_hdr->n_hits = gh; o_hdr->n_extra = gx; o_hdr->xcig_bytes = gt; o_hdr->n_cand = clus_off[n];
+    TMARK();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                // (the header too is assembled in device memory and copied in lines)
+        SmallHeader *const dh = (SmallHeader *)d_out;
+        dh->n_hits = gh; dh->n_extra = gx; dh->xcig_bytes = gt; dh->n_cand = clus_off[n];
         Counters c = *ctr;
         c.err_flags = flags | (fits || flags ? 0ull : SMALL_ERR_CAP);
         c.cig_total = gc;
-        o_hdr->ctr = c;
+        dh->ctr = c;
     }
+    TMARK();
     if (fits && valid) o_status[r] = (int8_t)st;
-    if (fits && valid && st == 0 && nh) {
-        uint64_t ho = bh + eh, xo = bx + ex, co = btx + et;
-        for (uint64_t k = b; k-- > a;) {                  // reverse of the cluster order
-            if (c_status[k] != CS_OK) continue;
-            const uint32_t wl = c_wlen[k], clf = c_ciglen[k];
-            hit_put(r, k, ho, xo, co, wl, clf, shift, c_score, c_S, cig, cig_stride, o_hits, o_extra, o_cig);
-            if (!(clf & CIG_DIAG)) { xo++; co += clf; }
-            ho++;
+    const bool live = fits && valid && st == 0 && nh;
+    // The hits, a lane per candidate again, from the top of the wave's range down (a read's hits go out in the reverse of its cluster
+    // order: lane 0 has the round's highest candidate).  The read's place in the table comes by shuffles, the hit's place inside the
+    // read from the lanes before it that belong to the same read (ballots; a scan of the text sizes) plus what the rounds before
+    // carried over for the read that straddles the round's end.
+    if (fits && wave_on) {
+        const uint32_t ho32 = (uint32_t)(bh + eh), xo32 = (uint32_t)(bx + ex), co32 = (uint32_t)(btx + et);
+        uint32_t carry_L = 0xffffffffu, ch = 0, cx = 0, ct = 0;
+        for (uint64_t kend = B; kend > A; kend = kend - A > 64 ? kend - 64 : A) {
+            const bool in = kend - A > lane;
+            const uint64_t k = in ? kend - 1 - lane : A;
+            const uint32_t krel = (uint32_t)(k - A);
+            const uint32_t L = read_of(krel);
+            const uint64_t bL = A + sb[L];
+            const bool liveL = __shfl((int)live, (int)L, 64) != 0;
+            const uint32_t hoL = (uint32_t)__shfl((int)ho32, (int)L, 64), xoL = (uint32_t)__shfl((int)xo32, (int)L, 64), coL = (uint32_t)__shfl((int)co32, (int)L, 64);
+            const int32_t cs = c_status[k], sc = c_score[k];
+            const uint32_t wl = c_wlen[k], clf = c_ciglen[k], cS = c_S[k];
+            const bool ok = in && liveL && cs == CS_OK;
+            const bool ex = ok && !(clf & CIG_DIAG);
+            const unsigned long long mok = __ballot(ok), mex = __ballot(ex);
+            const uint32_t first = kend > bL ? (uint32_t)(kend - bL) : 0u;          // the lane with the read's highest candidate of this round
+            const unsigned long long seg = ((1ull << lane) - 1ull) & ~((1ull << first) - 1ull);
+            const uint32_t tl = ex ? small_text_bytes(clf) : 0u, incl = dpp_scan_incl_u32(tl), excl = incl - tl;
+            const uint32_t excl_first = (uint32_t)__shfl((int)excl, (int)first, 64);
+            const bool mine = L == carry_L;
+            if (ok) hit_put_small(r0 + L, k, (uint64_t)hoL + (mine ? ch : 0u) + (uint32_t)__popcll(mok & seg), (uint64_t)xoL + (mine ? cx : 0u) + (uint32_t)__popcll(mex & seg),
+                                  (uint64_t)coL + (mine ? ct : 0u) + (excl - excl_first), wl, clf, shift, sc, cS, cig, cig_stride, o_hits, o_extra, o_cig);
+            if (kend - A > 63) {                                                     // a full round: the read of its last lane may go on in the next
+                const uint32_t L63 = (uint32_t)__builtin_amdgcn_readlane((int)L, 63), f63 = (uint32_t)__builtin_amdgcn_readlane((int)first, 63);
+                const unsigned long long s63 = ~((1ull << f63) - 1ull);
+                const uint32_t add_h = (uint32_t)__popcll(mok & s63), add_x = (uint32_t)__popcll(mex & s63);
+                const uint32_t add_t = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - (uint32_t)__shfl((int)excl, (int)f63, 64);
+                if (L63 == carry_L) { ch += add_h; cx += add_x; ct += add_t; }
+                else { carry_L = L63; ch = add_h; cx = add_x; ct = add_t; }
+            }
+        }
+    }
+    // ---- every block's part of the table is in d_out: across the link in whole lines
+    TMARK();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(&ctr->pad_, 1u);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&ctr->pad_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2u * gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) break;                     // (flagged at the first barrier already if blocks are missing)
         }
     }
     __syncthreads();
+    TMARK();
+    {
+        const uint64_t hdr8 = offsetof(SmallHeader, done) / 8;                      // everything in front of the `done` word
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hdr8; i += (uint64_t)gridDim.x * blockDim.x)
+            ((unsigned long long *)h_out)[i] = ((const unsigned long long *)d_out)[i];
+    }
+    if (fits) {
+        const uint64_t u_st = ((uint64_t)n + 15) >> 4, u_h = gh, u_x = gx, u_t = gt >> 4;             // 16-byte units per section
+        const uint64_t total_u = u_st + u_h + u_x + u_t;
+        for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total_u; u += (uint64_t)gridDim.x * blockDim.x) {
+            uint64_t k = u;
+            uint32_t sec = off_status;
+            if (k >= u_st) { k -= u_st; sec = off_hits; if (k >= u_h) { k -= u_h; sec = off_extra; if (k >= u_x) { k -= u_x; sec = off_cig; } } }
+            const uint4 v = ((const uint4 *)(d_out + sec))[k];
+            ((uint4 *)(h_out + sec))[k] = v;
+        }
+    }
+    __syncthreads();
+    TMARK();
     if (threadIdx.x == 0) {
         __threadfence_system();
-        if (atomicAdd(&ctr->pad_, 1u) == 2u * gridDim.x - 1u) { __threadfence_system(); *(volatile unsigned long long *)&o_hdr->done = seq; }
+#ifdef SMALL_HITS_TIMING
+        TT[tti++] = wall_clock64();
+        if (blockIdx.x == 0) for (int i = 0; i < tti; i++) bt[64 + i] = TT[i];
+        __threadfence();
+#endif
+        if (atomicAdd(&ctr->pad_, 1u) == 3u * gridDim.x - 1u) { __threadfence_system(); *(volatile unsigned long long *)&o_hdr->done = *d_seq; }
     }
+#undef TMARK
 }
+
+// what the launches of a small batch depend on besides the contents of the pinned block: a graph captured for one key is replayed
+// only for the same key.  sig: the device addresses the launches were given (small_ptr_sig: the handle's buffers have fixed
+// capacities, so they only move when the general path ran on the handle -- which drops the graph anyway -- and the index's arrays
+// when its table is rebuilt).
+struct SmallKey { uint32_t n, max_lq, ulen, cig_stride; uint64_t total, sig; bwt_options opt; };
 
 struct bwt_small {
     bwt_index *ix = nullptr;
@@ -192,6 +333,14 @@ struct bwt_small {
     // what the general path returned when the call was redone through it
     std::vector<int8_t> g_status; std::vector<bwt_hit_rec> g_hits; std::vector<bwt_hit_extra> g_extra; std::vector<char> g_cig;
     uint64_t calls = 0, fallbacks = 0;
+    DevBuf dseq;                                        // the call number on the device (k_small_in -> k_small_hits)
+    DevBuf dout;                                        // the result block as the hit kernel assembles it (same layout as h_out)
+    // a batch of the same shape as the one before it replays the launches as ONE hipGraph (profiles/r4/launch_probe.txt: ~2.3 us per
+    // kernel inside a graph against ~4.5 us for launches that follow each other on a stream)
+    SmallKey last_key{}, graph_key{};
+    bool have_last = false, graph_broken = false;
+    hipGraphExec_t gexec = nullptr;
+    uint64_t graph_launches = 0, graph_captures = 0;
 };
 
 extern "C" int bwt_small_create(bwt_index *ix, bwt_small **out) {
@@ -204,7 +353,7 @@ extern "C" int bwt_small_create(bwt_index *ix, bwt_small **out) {
     // CIGAR slots of 128 bytes from the start: the general path begins at 32 and redoes a batch with wider slots when a text does
     // not fit -- here that would be a whole second run through the general path for the first read with two indels
     s->b->cig_stride = 128;
-    s->in_off_bytes = (((size_t)SMALL_MAX_READS + 1) * 8 + 15) & ~(size_t)15;
+    s->in_off_bytes = (SMALL_SEQ_OFF + 8 + 15) & ~(size_t)15;
     s->in_bytes = s->in_off_bytes + SMALL_MAX_BASES + 64;
     s->cap_text = (uint64_t)SMALL_CAND_CAP * 32;
     s->o_status = (sizeof(SmallHeader) + 63) & ~(size_t)63;
@@ -219,6 +368,7 @@ extern "C" int bwt_small_create(bwt_index *ix, bwt_small **out) {
         return fail(BWT_ENOMEM, "bwt_small_create: hipHostMalloc of the pinned staging blocks failed");
     }
     memset(s->h_out, 0, sizeof(SmallHeader));
+    if ((rc = s->dseq.ensure(64)) || (rc = s->dout.ensure(s->out_bytes))) { bwt_small_destroy(s); return rc; }
     if (hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
     *out = s;
     return 0;
@@ -227,6 +377,9 @@ extern "C" int bwt_small_create(bwt_index *ix, bwt_small **out) {
 extern "C" void bwt_small_destroy(bwt_small *s) {
     if (!s) return;
     if (s->ix) (void)hipSetDevice(s->ix->device);
+    if (s->b && s->b->stream) (void)hipStreamSynchronize(s->b->stream);
+    if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
+    s->dseq.release(); s->dout.release();
     if (s->b) bwt_batch_destroy(s->b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -246,8 +399,25 @@ extern "C" int bwt_small_kernel_times(bwt_small *s, char *names, uint32_t names_
 // the directions of max_lq rows
 static uint32_t small_wave_wcap(uint32_t max_lq) {
     uint32_t w = 0;
-    while (((uint64_t)(w + 16 + 1) + (uint64_t)max_lq * swv_dwords(w + 16)) * 16 <= 150 * 1024) w += 16;
+    while (w + 16 <= 4080 && ((uint64_t)(w + 16 + 1) + (uint64_t)max_lq * swv_dwords(w + 16)) * 16 <= 150 * 1024) w += 16;
     return w;
+}
+
+// the addresses a captured run holds: every buffer small_size_buffers sizes, the counters, the index's arrays and scalars
+static uint64_t small_ptr_sig(const bwt_small *s) {
+    const bwt_batch *b = s->b;
+    const DevBuf *bufs[] = {&b->bases, &b->off, &b->rplanes, &b->t_def, &b->t_sp, &b->t_ep, &b->t_info, &b->t_cnt, &b->r_P, &b->r_qty, &b->r_pend,
+                            &b->r_K, &b->r_cl, &b->bigq, &b->mid2q, &b->mid4q, &b->gq, &b->seed_off, &b->clus_off, &b->pos, &b->c_read, &b->c_S,
+                            &b->c_D, &b->c_qoff, &b->c_qlen, &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->fpq, &b->tq,
+                            &b->dq, &b->tq2, &b->pfq, &b->cig, &b->scan_tmp, &b->slab_bnd_t, &b->slab_dir, &b->slab_bnd_fp, &b->slab_bndv,
+                            &b->slab_dir_fp, &b->ctr, &s->dseq, &s->dout};
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    auto mix = [&](uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); };
+    for (const DevBuf *d : bufs) mix((uint64_t)(uintptr_t)d->p);
+    const unsigned char *ib = (const unsigned char *)&s->ix->d;
+    for (size_t i = 0; i + 8 <= sizeof(DevIndex); i += 8) { uint64_t v; memcpy(&v, ib + i, 8); mix(v); }
+    mix((uint64_t)s->ix->shift);
+    return h;
 }
 
 // every device buffer of the run at its fixed capacity (a compare each once they are there)
@@ -267,7 +437,7 @@ static int small_size_buffers(bwt_small *s, uint32_t maxT, uint32_t max_lq) {
         (rc = b->c_status.ensure(nc * 4 + 4)) || (rc = b->c_score.ensure(nc * 4 + 4)) || (rc = b->c_ciglen.ensure(nc * 4 + 4)) ||
         (rc = b->fpq.ensure(nc * 4 + 4)) || (rc = b->tq.ensure(nc * 4 + 4)) || (rc = b->dq.ensure(nc * 4 + 4)) || (rc = b->tq2.ensure(nc * 4 + 4)) ||
         (rc = b->pfq.ensure(nc * 4 + 256)) || (rc = b->cig.ensure(nc * b->cig_stride + 16)) ||
-        (rc = b->scan_tmp.ensure(SMALL_HIT_BLOCKS * 4 * 8 + 64)))
+        (rc = b->scan_tmp.ensure(SMALL_HIT_BLOCKS * 4 * 8 + 64 + 128)))
         return rc;
     // the generic traced / fp64 kernels: 16 waves each, windows of up to SMALL_W_TRACE bases
     const uint64_t maxW1 = SMALL_W_TRACE + 1, strips = (max_lq + SW_R - 1) / SW_R, waves = 16;
@@ -300,7 +470,8 @@ static int small_launch(bwt_small *s, uint32_t n, uint32_t max_lq, uint32_t ulen
         const uint64_t nseg = (((total + 15) >> 4) + 1) & ~1ull;
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nseg + 255) / 256, (uint64_t)cus * 2));
         KLAUNCH(b, "small_in", k_small_in, grid, 256, (const uint64_t *)s->h_in, (const uint8_t *)(s->h_in + s->in_off_bytes), n, total,
-                b->off.as<uint64_t>(), b->bases.as<uint8_t>(), b->rplanes.as<uint32_t>(), rp_words(total), z);
+                b->off.as<uint64_t>(), b->bases.as<uint8_t>(), b->rplanes.as<uint32_t>(), rp_words(total), z,
+                (const unsigned long long *)(s->h_in + SMALL_SEQ_OFF), s->dseq.as<unsigned long long>());
     }
     // ---- seed search (+ clustering where the table's top level carries the seeds): the general path's launches
     if ((rc = launch_search(b, n, maxT, false, true, true))) return rc;
@@ -362,12 +533,20 @@ static int small_launch(bwt_small *s, uint32_t n, uint32_t max_lq, uint32_t ulen
         const uint32_t wcap = std::min<uint32_t>(wfull, ((max_lq + 96 + 15) / 16) * 16);
         const uint32_t grid = std::min<uint32_t>(1024, std::max<uint32_t>(64, n));
         ProfScope ps(b, "sw_wave");
+        // (one list of the reference's 200 reads: a few hundred candidates, fewer than the 1024 waves that run side by side with all
+        // the LDS a block can have -- one pass, one launch less)
+        if (n <= SMALL_ONE_PASS)
+            hipLaunchKernelGGL(k_sw_wave, dim3(256), dim3(256), (size_t)(((uint64_t)wfull + 1 + (uint64_t)max_lq * swv_dwords(wfull)) * 16), b->stream, io,
+                               SMALL_CAND_CAP, wfull + 1, swv_dwords(wfull), max_lq, (const uint32_t *)nullptr, (const unsigned int *)nullptr,
+                               (uint32_t *)nullptr, (unsigned int *)nullptr);
+        else {
         hipLaunchKernelGGL(k_sw_wave, dim3(grid), dim3(256), (size_t)(((uint64_t)wcap + 1 + (uint64_t)max_lq * swv_dwords(wcap)) * 16), b->stream, io,
                            SMALL_CAND_CAP, wcap + 1, swv_dwords(wcap), max_lq, (const uint32_t *)nullptr, (const unsigned int *)nullptr,
                            b->tq2.as<uint32_t>(), &dc->tq2_count);
         hipLaunchKernelGGL(k_sw_wave, dim3(std::min<uint32_t>(grid, 256)), dim3(256), (size_t)(((uint64_t)wfull + 1 + (uint64_t)max_lq * swv_dwords(wfull)) * 16),
                            b->stream, io, SMALL_CAND_CAP, wfull + 1, swv_dwords(wfull), max_lq, (const uint32_t *)b->tq2.as<uint32_t>(),
                            (const unsigned int *)&dc->tq2_count, (uint32_t *)nullptr, (unsigned int *)nullptr);
+        }
     }
     {
         // what is left: windows wider than any LDS (traced integer kernel) and candidates with a base outside ACGT (fp64), one launch
@@ -380,8 +559,8 @@ static int small_launch(bwt_small *s, uint32_t n, uint32_t max_lq, uint32_t ulen
     KLAUNCH(b, "small_hits", k_small_hits, cdiv(n, 256), 256, n, ix->shift, (const uint64_t *)b->clus_off.as<uint64_t>(), (const int32_t *)b->c_status.as<int32_t>(),
             (const int32_t *)b->c_score.as<int32_t>(), (const uint32_t *)b->c_ciglen.as<uint32_t>(), (const uint32_t *)b->c_S.as<uint32_t>(),
             (const uint32_t *)b->c_wlen.as<uint32_t>(), (const uint8_t *)b->cig.as<uint8_t>(), b->cig_stride, (const uint32_t *)b->r_qty.as<uint32_t>(), dc,
-            b->scan_tmp.as<unsigned long long>(), (SmallHeader *)s->h_out, (int8_t *)(s->h_out + s->o_status), (HitRec *)(s->h_out + s->o_hits),
-            (HitExtra *)(s->h_out + s->o_extra), (uint8_t *)(s->h_out + s->o_cig), s->cap_text, (unsigned long long)s->calls);
+            b->scan_tmp.as<unsigned long long>(), s->h_out, s->dout.as<uint8_t>(), (uint32_t)s->o_status, (uint32_t)s->o_hits, (uint32_t)s->o_extra,
+            (uint32_t)s->o_cig, s->cap_text, (const unsigned long long *)s->dseq.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -418,8 +597,44 @@ extern "C" int bwt_small_align(bwt_small *s, const uint8_t *bases, const uint64_
         const uint64_t o0 = off[0];
         for (uint32_t i = 0; i <= n; i++) ho[i] = off[i] - o0;
         memcpy(s->h_in + s->in_off_bytes, bases + o0, total);
+        *(unsigned long long *)(s->h_in + SMALL_SEQ_OFF) = (unsigned long long)s->calls;
         res->us_copy_in = us_since(t0);
-        int rc = small_launch(s, n, maxlq, ulen, total);
+        int rc = small_size_buffers(s, std::max<uint32_t>(1, maxlq / BWT_MIN_LEN), maxlq);
+        if (rc) return rc;
+        // the second batch in a row of one shape captures its launches into a hipGraph, the ones after it replay that graph; anything
+        // that changes what a launch was given (another shape, options, a device buffer of the library moved) drops it
+        SmallKey key;
+        memset(&key, 0, sizeof key);
+        key.n = n; key.max_lq = maxlq; key.ulen = ulen; key.cig_stride = b->cig_stride; key.total = total;
+        key.sig = small_ptr_sig(s); key.opt = b->opt;
+        const bool graph_on = b->opt.small_graph != 0 && !b->prof && !s->graph_broken;
+        const bool same_as_last = s->have_last && !memcmp(&key, &s->last_key, sizeof key);
+        s->last_key = key; s->have_last = true;
+        if (s->gexec && (!graph_on || memcmp(&key, &s->graph_key, sizeof key))) { (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }
+        bool launched = false;
+        if (s->gexec) {
+            if (hipGraphLaunch(s->gexec, b->stream) == hipSuccess) { launched = true; s->graph_launches++; res->graph = 1; }
+            else { (void)hipGetLastError(); (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; s->graph_broken = true; }
+        } else if (graph_on && same_as_last) {
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                rc = small_launch(s, n, maxlq, ulen, total);
+                const hipError_t e = hipStreamEndCapture(b->stream, &g);
+                if (!rc && e == hipSuccess && g && hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    s->graph_key = key; s->graph_captures++;
+                    if (hipGraphLaunch(s->gexec, b->stream) == hipSuccess) { launched = true; s->graph_launches++; res->graph = 2; }
+                }
+                if (g) (void)hipGraphDestroy(g);
+                if (!launched) {
+                    (void)hipGetLastError();
+                    if (s->gexec) { (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }
+                    s->graph_broken = true; rc = 0;
+                }
+                // shapes that keep changing after two batches each: capturing costs more than it saves
+                if (s->graph_captures >= 16 && s->graph_launches < 4 * s->graph_captures) s->graph_broken = true;
+            } else { (void)hipGetLastError(); s->graph_broken = true; }
+        }
+        if (!launched) rc = small_launch(s, n, maxlq, ulen, total);
         res->us_enqueue = us_since(t0);
         if (rc) { (void)hipStreamSynchronize(b->stream); return rc; }
         const SmallHeader *h = (const SmallHeader *)s->h_out;
@@ -437,6 +652,18 @@ extern "C" int bwt_small_align(bwt_small *s, const uint8_t *bases, const uint64_
         }
         res->us_wait = us_since(t0);
         b->hctr = h->ctr;
+#ifdef SMALL_HITS_TIMING
+        if ((s->calls % 10) == 0) {
+            unsigned long long tt[12];
+            (void)hipStreamSynchronize(b->stream);
+            (void)hipMemcpy(tt, b->scan_tmp.as<unsigned long long>() + 64, sizeof tt, hipMemcpyDeviceToHost);
+            fprintf(stderr, "k_small_hits block 0, ticks of 10 ns: count %llu, scans+barrier %llu, totals %llu, header %llu, write %llu, barrier %llu, copy %llu, fence %llu\n", tt[1] - tt[0],
+                    tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7]);
+        }
+#endif
+#ifdef SWV_TIMING
+        if ((s->calls % 10) == 0) fprintf(stderr, "k_sw_wave slowest wave: prologue %u, DP %u, traceback %u ticks of 10 ns; widest window %u\n", h->ctr.pad2_[0], h->ctr.pad2_[1], h->ctr.pad2_[2], h->ctr.band0_next);
+#endif
         res->overflow_flags = h->ctr.err_flags;
         if (h->ctr.err_flags == 0) {
             small_ok = true;
@@ -453,6 +680,8 @@ extern "C" int bwt_small_align(bwt_small *s, const uint8_t *bases, const uint64_
     if (!small_ok) {
         // the general path (a capacity of this one did not hold, or the batch is not one it takes): same handle, same results
         if (eligible) s->fallbacks++;
+        if (s->gexec) { (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }      // (the general path may move the handle's buffers)
+        s->have_last = false;
         int rc;
         bwt_batch_counts c{};
         uint64_t need[3] = {0, 0, 0};

@@ -57,7 +57,7 @@ class RunStats(C.Structure):
 
 
 OPTION_FIELDS = ("seed_fuse", "seed_fast", "seed_big", "search_ilp", "sw_prefilter", "sw_fuse_cand", "sw_wave", "sw_band", "sw_band_min",
-                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow", "sw_band12", "up_zero_copy")
+                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow", "sw_band12", "up_zero_copy", "small_graph")
 
 
 class Options(C.Structure):
@@ -112,7 +112,8 @@ class SmallResult(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("path", C.c_uint32), ("n_hits", C.c_uint64), ("n_extra", C.c_uint64), ("cigar_bytes", C.c_uint64),
                 ("read_status", C.c_void_p), ("hits", C.c_void_p), ("extra", C.c_void_p), ("cigar", C.c_void_p),
                 ("n_candidates", C.c_uint64), ("n_dp", C.c_uint64), ("n_float", C.c_uint64), ("overflow_flags", C.c_uint64),
-                ("us_copy_in", C.c_double), ("us_enqueue", C.c_double), ("us_wait", C.c_double), ("us_total", C.c_double)]
+                ("us_copy_in", C.c_double), ("us_enqueue", C.c_double), ("us_wait", C.c_double), ("us_total", C.c_double),
+                ("graph", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 SMALL_MAX_READS = 4096
@@ -745,6 +746,7 @@ class SmallBatch:
         self.last = None
         self.fallbacks = 0
         self.paths = {0: 0, 1: 0, 2: 0}
+        self.graphs = {0: 0, 1: 0, 2: 0}              # calls by SmallResult.graph (launched one by one / replayed / captured)
 
     def close(self):
         if self.h:
@@ -767,6 +769,8 @@ class SmallBatch:
         _chk(load().bwt_small_align(self.h, _p(bases), _p(off), C.c_uint32(len(off) - 1), C.byref(r)))
         self.last = r
         self.paths[int(r.path)] += 1
+        if r.path == 1:
+            self.graphs[int(r.graph)] += 1
         if r.path == 2:
             self.fallbacks += 1
         return r
@@ -778,13 +782,13 @@ class SmallBatch:
         r = self.align_raw(bases, off)
         n, nh, nx = int(r.n_reads), int(r.n_hits), int(r.n_extra)
         comp = dict(read_status=_view(r.read_status, n, np.int8), hits=_view(r.hits, nh, HIT_REC), extra=_view(r.extra, nx, HIT_EXTRA),
-                    cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8), path=int(r.path), overflow_flags=int(r.overflow_flags),
+                    cigar=_view(r.cigar, int(r.cigar_bytes), np.uint8), path=int(r.path), overflow_flags=int(r.overflow_flags), graph=int(r.graph),
                     counts=dict(n_clusters=int(r.n_candidates), n_dp=int(r.n_dp), n_float=int(r.n_float), n_hits=nh))
         if not expand:
             return comp
         out = hits_expand(n, 0, off - off[0], self.index.meta()[1], comp["hits"], comp["extra"], comp["cigar"])
         out["read_status"] = comp["read_status"].astype(np.int32)
-        out["path"] = comp["path"]; out["counts"] = comp["counts"]; out["overflow_flags"] = comp["overflow_flags"]
+        out["path"] = comp["path"]; out["counts"] = comp["counts"]; out["overflow_flags"] = comp["overflow_flags"]; out["graph"] = comp["graph"]
         return out
 
     def stage_us(self):

@@ -78,6 +78,8 @@ typedef struct {
                                    hipPointerGetAttributes) is not copied: the unpack kernel reads it over the link itself, with 64
                                    workgroups (1) or with this many (> 1).  A pageable buffer is copied as always.  Off by default:
                                    DESIGN 8 has the measurement. */
+    int32_t small_graph;        /* 0: bwt_small_align never replays its launches as a hipGraph (it does from the second batch of one
+                                   shape in a row) */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 
@@ -453,6 +455,9 @@ typedef struct {
     uint64_t n_candidates, n_dp, n_float;   /* {S,D} candidates, those that ran a DP kernel, those that took the fp64 one */
     uint64_t overflow_flags;         /* path 2: why the small path gave up (2 a CIGAR longer than its slot, 16 a fixed capacity, ...) */
     double us_copy_in, us_enqueue, us_wait, us_total;   /* host clock since the call began: reads in pinned memory, kernels queued, results back, done */
+    uint32_t graph;                  /* path 1: 0 the kernels were launched one by one, 1 they were replayed as one hipGraph (a batch of the
+                                        same shape -- read count, lengths, options -- as the one before it), 2 the graph was captured in this call */
+    uint32_t reserved_;
 } bwt_small_result;
 int bwt_small_create(bwt_index *idx, bwt_small **out);
 void bwt_small_destroy(bwt_small *s);

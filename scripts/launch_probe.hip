@@ -6,6 +6,8 @@
 //   d  the same chain as ONE instantiated hipGraph launch
 //   e  one kernel of G blocks that passes N grid-wide barriers (atomic counter, every block resident)
 //   f  64 KB read from pinned host memory by a kernel / written to it (zero-copy), against hipMemcpyAsync of the same
+//   g  a batch's worth of packed reads (312.5 MB) from pinned memory: DMA against a kernel reading it, by grid
+//   h  straight-line code run once by one wave: first pass (cold instruction cache) against second
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -42,6 +44,40 @@ __global__ void k_barriers(unsigned int *ctr, int nbar, volatile unsigned int *f
 __global__ void k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, volatile unsigned int *flag, unsigned int v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
     (void)flag; (void)v;
+}
+
+// h: a stretch of straight-line code a wave runs through ONCE (what the many small kernels of a small batch mostly are): N dependent
+// multiply-adds, timed inside the kernel on the first pass (instructions come from memory) and on the second (from the instruction cache)
+template <int N>
+__global__ void k_code(unsigned int *out, unsigned long long *ticks, unsigned int x) {
+    unsigned int a = x + threadIdx.x;
+    for (int rep = 0; rep < 2; rep++) {
+        const unsigned long long t0 = wall_clock64();
+#pragma unroll
+        for (int i = 0; i < N; i++) a = a * 1664525u + (1013904223u + (unsigned int)i * 2654435761u);
+        const unsigned long long t1 = wall_clock64();
+        if (threadIdx.x == 0) ticks[blockIdx.x * 2 + rep] = t1 - t0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a;
+}
+template <int N>
+static void probe_code(hipStream_t s, unsigned int *dflag) {
+    unsigned long long *dt = nullptr, ht[2] = {0, 0};
+    unsigned int *dout = nullptr;
+    CK(hipMalloc(&dt, 64)); CK(hipMalloc(&dout, 4096));
+    double first = 0, second = 0;
+    const int reps = 20;
+    for (int i = 0; i < reps + 3; i++) {
+        // (something else runs in between, as the other kernels of a batch do)
+        for (int k = 0; k < 4; k++) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, s, dflag);
+        hipLaunchKernelGGL(k_code<N>, dim3(1), dim3(64), 0, s, dout, dt, (unsigned int)i);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(ht, dt, sizeof ht, hipMemcpyDeviceToHost));
+        if (i >= 3) { first += (double)ht[0]; second += (double)ht[1]; }
+    }
+    printf("h  %5d dependent multiply-adds, one wave: first pass %8.2f us, second pass %8.2f us  (%.1f / %.1f ns per instruction pair)\n", N,
+           first / reps / 100.0, second / reps / 100.0, first / reps * 10.0 / N, second / reps * 10.0 / N);
+    CK(hipFree(dt)); CK(hipFree(dout));
 }
 
 int main() {
@@ -150,5 +186,6 @@ int main() {
             printf("g  kernel reads 312.5 MB of pinned memory, %4d blocks   %8.0f us  (%.1f GB/s)\n", G, us, bytes / us / 1e3);
         }
     }
+    probe_code<256>(s, dflag); probe_code<1024>(s, dflag); probe_code<4096>(s, dflag);
     return 0;
 }

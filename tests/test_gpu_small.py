@@ -236,3 +236,61 @@ def test_widened_lower_levels_every_read_length(repeat_index):
             same_tables(ix.align_batch(bases, off), out)
     finally:
         ix.set_ktable(-1, -1)
+
+
+def test_batches_of_one_shape_replay_a_graph(gpu_index, ref_bytes):
+    """The second batch in a row of one shape (read count, lengths, options) captures the launches of the small path into a hipGraph and
+    the ones after it replay it; the answers stay the general path's for every batch, a batch of another shape is launched kernel by
+    kernel again, and so is everything under small_graph = 0, while profiling, and after an option changes."""
+    from bwt_amd import lib
+    sb = lib.SmallBatch(gpu_index)
+    try:
+        seen = []
+        for k in range(5):
+            reads = mixed_reads(ref_bytes, 200, seed=300 + k)           # the same shape, other reads each time
+            bases, off = lib.pack_reads(reads)
+            out = sb.align(bases, off)
+            assert out["path"] == 1
+            seen.append(out["graph"])
+            same_tables(out, gpu_index.align_batch(bases, off))
+        assert seen == [0, 2, 1, 1, 1], seen
+        other = mixed_reads(ref_bytes, 150, seed=9)
+        bo, oo = lib.pack_reads(other)
+        o = sb.align(bo, oo)
+        assert o["graph"] == 0
+        same_tables(o, gpu_index.align_batch(bo, oo))
+        for k in range(3):                                              # back to the first shape: captured again on the second in a row
+            reads = mixed_reads(ref_bytes, 200, seed=400 + k)
+            bases, off = lib.pack_reads(reads)
+            out = sb.align(bases, off)
+            assert out["graph"] == (0, 2, 1)[k]
+            same_tables(out, gpu_index.align_batch(bases, off))
+        # 2000 reads (the two-pass DP launches), 150 bp reads (18 sub-reads per read)
+        for n, length in ((2000, 100), (300, 150)):
+            got = []
+            for k in range(3):
+                reads = mixed_reads(ref_bytes, n, seed=500 + k, length=length)
+                bases, off = lib.pack_reads(reads)
+                out = sb.align(bases, off)
+                got.append(out["graph"])
+                same_tables(out, gpu_index.align_batch(bases, off))
+            assert got == [0, 2, 1], (n, got)
+        sb.set_options(seed_fast=0)                                     # an option changes what is launched: not the old graph
+        reads = mixed_reads(ref_bytes, 300, seed=77, length=150)
+        bases, off = lib.pack_reads(reads)
+        out = sb.align(bases, off)
+        assert out["graph"] == 0
+        same_tables(out, gpu_index.align_batch(bases, off))
+        sb.set_options(small_graph=0)
+        for k in range(3):
+            assert sb.align(bases, off)["graph"] == 0
+        sb.set_options()
+        sb.profile(True)
+        for k in range(3):
+            out = sb.align(bases, off)
+            assert out["graph"] == 0
+        sb.profile(False)
+        assert [sb.align(bases, off)["graph"] for _ in range(2)] == [2, 1]
+        same_tables(sb.align(bases, off), gpu_index.align_batch(bases, off))
+    finally:
+        sb.close()
