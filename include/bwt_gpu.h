@@ -451,7 +451,8 @@ typedef struct {
     const int8_t *read_status;       /* n_reads   (values as bwt_align_batch) */
     const bwt_hit_rec *hits;         /* n_hits, ascending by read */
     const bwt_hit_extra *extra;      /* n_extra, ascending by hit */
-    const char *cigar;               /* cigar_bytes: the text of the extras */
+    const char *cigar;               /* cigar_bytes: the text of the extras, each at its extra's cig_off / cig_len (NOT packed against
+                                        each other here: a text takes the whole 16-byte pieces of its device slot) */
     uint64_t n_candidates, n_dp, n_float;   /* {S,D} candidates, those that ran a DP kernel, those that took the fp64 one */
     uint64_t overflow_flags;         /* path 2: why the small path gave up (2 a CIGAR longer than its slot, 16 a fixed capacity, ...) */
     double us_copy_in, us_enqueue, us_wait, us_total;   /* host clock since the call began: reads in pinned memory, kernels queued, results back, done */

@@ -47,15 +47,16 @@ __global__ void k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, s
 }
 
 // h: a stretch of straight-line code a wave runs through ONCE (what the many small kernels of a small batch mostly are): N dependent
-// multiply-adds, timed inside the kernel on the first pass (instructions come from memory) and on the second (from the instruction cache)
+// steps of three instructions, timed inside the kernel on the first pass (instructions come from memory) and on the second (from the instruction cache)
 template <int N>
 __global__ void k_code(unsigned int *out, unsigned long long *ticks, unsigned int x) {
     unsigned int a = x + threadIdx.x;
     for (int rep = 0; rep < 2; rep++) {
-        const unsigned long long t0 = wall_clock64();
+        unsigned long long t0, t1;                     // (the clock reads are tied to the chain's value: nothing moves across them)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "+v"(a));
 #pragma unroll
-        for (int i = 0; i < N; i++) a = a * 1664525u + (1013904223u + (unsigned int)i * 2654435761u);
-        const unsigned long long t1 = wall_clock64();
+        for (int i = 0; i < N; i++) a = (a * 1664525u) ^ (a >> 13);          // (not affine: the compiler cannot fold the chain)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "+v"(a));
         if (threadIdx.x == 0) ticks[blockIdx.x * 2 + rep] = t1 - t0;
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a;
@@ -75,7 +76,7 @@ static void probe_code(hipStream_t s, unsigned int *dflag) {
         CK(hipMemcpy(ht, dt, sizeof ht, hipMemcpyDeviceToHost));
         if (i >= 3) { first += (double)ht[0]; second += (double)ht[1]; }
     }
-    printf("h  %5d dependent multiply-adds, one wave: first pass %8.2f us, second pass %8.2f us  (%.1f / %.1f ns per instruction pair)\n", N,
+    printf("h  %5d dependent steps (v_mul_lo, v_lshrrev, v_xor), one wave: first pass %8.2f us, second pass %8.2f us  (%.1f / %.1f ns per step)\n", N,
            first / reps / 100.0, second / reps / 100.0, first / reps * 10.0 / N, second / reps * 10.0 / N);
     CK(hipFree(dt)); CK(hipFree(dout));
 }
