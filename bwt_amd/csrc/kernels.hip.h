@@ -2455,7 +2455,7 @@ struct CandSrc {
     uint32_t *ovq; unsigned int *ov_count;
     const uint32_t *list; const unsigned int *list_count;
     uint32_t ulen;                               // > 0: every read has this length (no offset loads)
-    uint32_t kcap;                               // FROM_READS: candidates of a read the fused pass tests itself (0 = PF_KCAP; the small-batch path: all)
+    uint32_t kcap;                               // FROM_READS: 1 + the candidates of a read the fused pass tests itself (0 = PF_KCAP)
 };
 // A wave of the fused pass takes 16 reads and loops to the LARGEST cluster count among them: on a repeat-rich genome one read in
 // twelve has a dozen or more clusters, three waves in four hold such a read, and the other fifteen quads idle through its loop
@@ -2525,7 +2525,7 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
                 maxlq = lq_r > maxlq ? lq_r : maxlq;
             }
         }
-        const uint32_t kcap = src.kcap ? src.kcap : PF_KCAP;
+        const uint32_t kcap = src.kcap ? src.kcap - 1u : PF_KCAP;
         if (FROM_READS && kmax > kcap) {
             // the candidates past the first PF_KCAP of every read of this pass: descriptors and list entries, four per quad step
             for (uint32_t kb = kcap; kb < kmax; kb += 4) {

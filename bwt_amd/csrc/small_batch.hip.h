@@ -516,13 +516,16 @@ static int small_launch(bwt_small *s, uint32_t n, uint32_t max_lq, uint32_t ulen
         src.c_qlen = b->c_qlen.as<uint32_t>(); src.c_woff = b->c_woff.as<int64_t>(); src.c_wlen = b->c_wlen.as<uint32_t>();
         src.ovq = b->pfq.as<uint32_t>(); src.ov_count = &dc->pf_ov;
         src.ulen = ulen;
-        // (every candidate of a read in the fused pass, src.kcap = ~0 and no second launch, was tried: 40 / 65 us for 200 / 2000
-        // reads against 23 / 36 for the two launches -- the wave's sixteen reads wait for the one with the most clusters)
+        // The fused pass tests NO candidate itself here (kcap 0): it only writes every candidate's descriptor and lists it, and the
+        // list pass tests them all, a quad per candidate -- 6.9 + 6.4 us for a list of 200 reads where the general path's split (two
+        // per read in the fused pass) took 12.2 + 9.0 and everything in the fused pass 40: a wave of the fused pass holds sixteen
+        // reads and loops to the largest cluster count among them, each turn a round trip to the window planes.
+        src.kcap = 1;
         const uint32_t pf_grid = (uint32_t)std::min<uint64_t>(cdiv((uint64_t)n * 4, 256), (uint64_t)cus * 5);
         KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, pf_grid, 256, io, n, src);
         CandSrc rest{};
         rest.list = b->pfq.as<uint32_t>(); rest.list_count = &dc->pf_ov;
-        KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>((uint32_t)cus, cdiv((uint64_t)n * 4, 256)), 256, io, SMALL_CAND_CAP, rest);
+        KLAUNCH(b, "sw_prefilter", k_sw_prefilter<false>, std::min<uint32_t>((uint32_t)cus * 4, cdiv((uint64_t)n * 12, 256)), 256, io, SMALL_CAND_CAP, rest);
     }
     {
         // k_sw_wave over the whole DP queue (never longer than its limit here), twice: first with LDS for windows up to 96 bases wider
