@@ -3593,7 +3593,12 @@ __global__ __launch_bounds__(256) void k_sw_wave(SwIO io, uint32_t thresh, uint3
 // that are not "plain" -- plain = settled on a square window with CIGAR "<Lq>M" (CIG_DIAG), for which window and text follow
 // from the record.  The per-hit arrays of bwt_align_batch (window offset / length, CIGAR offsets, all texts) are expanded from
 // it on demand (k_hits_expand) -- a batch whose results leave as compact tables never writes them.
-#define HITS_FAT 128u          // candidates of a read from which on the wave takes the read together (k_hits_count, k_hits_write)
+// candidates of a read from which on its wave takes the read together (k_hits_count, k_hits_write).  Repeat-rich batch, count + write:
+// 128 -> 0.67 + 2.25 ms, 16 -> 0.45 + 1.33, 8 -> 0.44 + 1.43 (a lane's loop over its read's candidates is the wave's time; a read
+// taken together costs the wave a round of its own)
+#ifndef HITS_FAT
+#define HITS_FAT 16u
+#endif
 // one candidate of a read into the read's totals (the fold of src/worker_bwt.erl:84-97: no_match drops out, the rest is a hit)
 __device__ __forceinline__ void hit_count_one(int32_t cs, const uint32_t *__restrict__ c_ciglen, uint64_t k, uint32_t &nh, uint32_t &nx,
                                               uint32_t &xcb, unsigned long long &cbr, int32_t &st, Counters *ctr) {

@@ -294,3 +294,40 @@ def test_batches_of_one_shape_replay_a_graph(gpu_index, ref_bytes):
         same_tables(sb.align(bases, off), gpu_index.align_batch(bases, off))
     finally:
         sb.close()
+
+
+def test_two_handles_on_one_index_from_two_threads(gpu_index, ref_bytes):
+    """several bwt_small handles may share an index (include/bwt_gpu.h): two threads, a handle each, batches of one shape each -- both
+    capture and replay their own graph while the other runs, and every table is the general path's"""
+    import threading
+    from bwt_amd import lib
+    jobs = []
+    for t, (n, length) in enumerate(((200, 100), (333, 120))):
+        batches = []
+        for k in range(12):
+            bases, off = lib.pack_reads(mixed_reads(ref_bytes, n, seed=900 + 50 * t + k, length=length))
+            batches.append((bases, off, gpu_index.align_batch(bases, off)))
+        jobs.append(batches)
+    errors, graphs = [], [None, None]
+
+    def work(t):
+        sb = lib.SmallBatch(gpu_index)
+        try:
+            for rep in range(3):
+                for bases, off, want in jobs[t]:
+                    out = sb.align(bases, off)
+                    assert out["path"] == 1
+                    same_tables(out, want)
+            graphs[t] = dict(sb.graphs)
+        except Exception as e:                                     # noqa: BLE001 (reported below, from the main thread)
+            errors.append((t, repr(e)))
+        finally:
+            sb.close()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    assert all(g[1] >= 30 and g[2] == 1 for g in graphs), graphs      # one capture, then replays
