@@ -421,7 +421,7 @@ def repeat_rich_record(args):
             "ms_per_step": d["ms_per_step"], "steps": d["steps"], "value_is": d["value_is"],
             "resident": {"reads_per_s": d["resident"]["reads_per_s"], "ms_per_step": d["resident"]["ms_per_step"]},
             "dominant_kernel": d["dominant_kernel"], "kernels_ms_per_step": d["resident"]["kernels_ms_per_step"],
-            "counts_per_step": {k: d["counts_per_step"][k] for k in ("n_clusters", "n_dp", "n_banded", "n_hits", "n_handed_back", "n_float")},
+            "counts_per_step": {k: d["counts_per_step"][k] for k in ("n_clusters", "n_dp", "n_banded", "n_certified", "n_hits", "n_handed_back", "n_float") if k in d["counts_per_step"]},
             "host_boundary": {k: d["host_boundary"][k] for k in ("bytes_up_per_read", "bytes_down_per_read", "steady_state_ms_per_batch")},
             "parity_sample": cb.get("parity_sample"), "parity_aggregate": cb.get("parity_aggregate"),
             "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}, "wall_s": time.perf_counter() - t0}
@@ -816,7 +816,8 @@ def main():
             left = counts["n_dp"] - counts.get("n_banded", 0)
             t_dp = ((per.get("sw_band", 0.0) if banded else 0.0) + (per.get("sw_wave", 0.0) if left <= 32768 else per.get("sw_extend", 0.0))) / 1e3
             line["extend"] = {"candidates": counts["n_clusters"],
-                              "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"],
+                              "settled_by_prefilter": counts["n_clusters"] - counts["n_dp"] - counts["n_float"] - counts.get("n_certified", 0),
+                              "settled_by_certificate": counts.get("n_certified", 0),      # k_sw_cert: past the prefilter, no DP (sw_cert.h)
                               "dp_candidates": counts["n_dp"],
                               "settled_by_banded_dp": counts.get("n_banded", 0),
                               "dp_kernel": ("k_sw_band (20, then 32, then 64 diagonals + certificate), then " if banded else "") +

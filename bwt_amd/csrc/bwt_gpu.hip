@@ -423,6 +423,7 @@ struct bwt_batch {
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2, tqw;
     DevBuf bq, bq2, bq3, slab_band;    // k_sw_band: the queues of what its tiers pass on (bq3: first tier -> third), the direction slab
     DevBuf dq_lo, bq0, bqs;            // the 12-diagonal tier: its queue (filled by the prefilter), what it passes on, what it sends past the next tier
+    DevBuf cq;                         // what k_sw_cert leaves of dq_lo (the 12-diagonal tier's queue when the certificate kernel runs)
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     DevBuf pfq;                        // candidates the fused prefilter pass listed for the quad-per-candidate pass
@@ -589,7 +590,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->tqw, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs,
-                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs};
+                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs, &b->cq};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -1217,7 +1218,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     if (!first) {
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 48, b->stream));      // band_*, pf_ov, band2_*, band3_*
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band0_in, 0, 20, b->stream));     // band0_*, dq_lo_count
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band0_in, 0, 28, b->stream));     // band0_*, dq_lo_count, cert_*
     }
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
@@ -1320,6 +1321,22 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             (rc = b->slab_band.ensure(std::max<uint64_t>((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4, (uint64_t)blocks3 * 4 * rows * 8 * 64 * 4))))
             return rc;
         Counters *dc = b->ctr.as<Counters>();
+        // the 12-diagonal tier's queue: the prefilter's dq_lo -- after the certificate kernel has taken out of it what needs no DP at
+        // all (bwt_options.sw_cert = 0: nothing)
+        const uint32_t *q12 = b->dq_lo.as<uint32_t>();
+        const unsigned int *n12 = &dc->dq_lo_count;
+        if (band12 && b->opt.sw_cert != 0 && max_lq <= 160) {
+            if ((rc = b->cq.ensure(nc * 4 + 4))) return rc;
+            ProfScope pc(b, "sw_cert");
+            const uint32_t cblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * 8));
+            if (max_lq <= 128)
+                hipLaunchKernelGGL((k_sw_cert<5, 4>), dim3(cblocks), dim3(256), 0, b->stream, io, q12, n12, b->cq.as<uint32_t>(), &dc->cert_left,
+                                   &dc->cert_done, band_min);
+            else
+                hipLaunchKernelGGL((k_sw_cert<5, 5>), dim3(cblocks), dim3(256), 0, b->stream, io, q12, n12, b->cq.as<uint32_t>(), &dc->cert_left,
+                                   &dc->cert_done, band_min);
+            q12 = b->cq.as<uint32_t>(); n12 = &dc->cert_left;
+        }
         {
             ProfScope ps(b, "sw_band");
             const uint32_t *nullq = nullptr;
@@ -1327,9 +1344,8 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             // the 12-diagonal tier on the prefilter's queue of square windows with <= 6 mismatches: what it does not settle goes on to
             // the 20-diagonal tier's second queue (bq0 / band0_left), what that one cannot settle either to the 32-diagonal one's (bqs)
             if (band12)
-                hipLaunchKernelGGL((k_sw_band<12, 20>), dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)b->dq_lo.as<uint32_t>(),
-                                   (const unsigned int *)&dc->dq_lo_count, nullq, nullc, b->bq0.as<uint32_t>(), &dc->band0_in, b->bqs.as<uint32_t>(),
-                                   &dc->band0_direct, b->slab_band.as<uint32_t>(), rows, band_min);
+                hipLaunchKernelGGL((k_sw_band<12, 20>), dim3(blocks1), dim3(256), 0, b->stream, io, q12, n12, nullq, nullc, b->bq0.as<uint32_t>(),
+                                   &dc->band0_in, b->bqs.as<uint32_t>(), &dc->band0_direct, b->slab_band.as<uint32_t>(), rows, band_min);
             // first tier: what the second cannot settle either goes straight to the third's second queue (bq3 / band_direct)
             hipLaunchKernelGGL((k_sw_band<20, 32>), dim3(blocks1), dim3(256), 0, b->stream, io, (const uint32_t *)io.dq, (const unsigned int *)&dc->dq_count,
                                band12 ? (const uint32_t *)b->bq0.as<uint32_t>() : nullq, band12 ? (const unsigned int *)&dc->band0_left : nullc,
@@ -1653,6 +1669,7 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         counts->n_traced += counts->n_banded;
         counts->n_lookups = b->hctr.kt_lookups; counts->n_small = b->n_small;
         counts->n_handed_back = b->hctr.n_gq;
+        counts->n_certified = b->hctr.cert_done;
     }
     return 0;
 }

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "kernels_index.h"
+#include "sw_cert.h"
 
 // ------------------------------------------------------------------------------------------------
 // wave helpers
@@ -3382,6 +3383,72 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sw_cert<X, NW>: in front of the 12-diagonal tier.  Its queue holds the candidates the prefilter found on a SQUARE window with
+// 3 .. X + 1 mismatches on the diagonal and no base outside ACGT: diverged copies of a repeat, whose answer is nearly always the
+// plain diagonal -- {2 Lq - 3 m, "<Lq>M"} -- and for which the banded DP fills 12 x Lq cells, stores their directions and walks them
+// back only to find that out.  A lane takes a candidate, loads the code planes of read and window (the window with 32 bases
+// either side), and runs sw_cert.h on them: mismatch masks of the diagonals -X .. X, an upper bound on what any other path can
+// gain over the diagonal, a coarse DP over the m + 1 stretches between mismatch rows (the proof is in that header; the same text is
+// checked on the CPU against the oracle's full table, tests/cert_check/).  Where the certificate holds the candidate is settled like
+// one of the prefilter's own (score, CIG_DIAG length, no text); the others go on to the banded tiers in a queue of their own.
+// ~2 k lane-instructions per candidate against ~10 k in k_sw_band<12> -- and no direction slab, no traceback, no extra record.
+template <int X, int NW>
+__global__ __launch_bounds__(256) void k_sw_cert(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count,
+                                                 uint32_t *__restrict__ rest, unsigned int *__restrict__ rest_count, unsigned int *__restrict__ done_count,
+                                                 uint32_t skip_upto) {
+    __shared__ uint32_t wq_[4][128];
+    WaveQ qr;
+    qr.buf = wq_[threadIdx.x >> 6]; qr.have = 0;
+    const uint32_t n_items = *in_count;
+    if (n_items <= skip_upto) {
+        // a short queue is k_sw_wave's: handed through (the band tiers do the same)
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = in_q[t];
+        if (blockIdx.x == 0 && threadIdx.x == 0) *rest_count = n_items;
+        return;
+    }
+    uint32_t ndone = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < n_items; t0 += stride) {          // whole waves iterate together
+        const uint32_t t = t0 + (threadIdx.x & 63u);
+        const bool have = t < n_items;
+        const uint32_t c = have ? in_q[t] : 0u;
+        bool pass_on = false;
+        if (have) {
+            const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
+            const int64_t wo = io.c_woff[c];
+            const uint64_t qo = io.c_qoff[c];
+            // the planes of the 32 bases in front of the window and of up to 32 behind its last word must exist
+            bool ok = w == lq && lq >= 24 && lq <= 32u * NW && wo >= 32 && (uint64_t)wo + 32u * (NW + 1) <= io.rbuf_len;
+            int m = 0;
+            if (ok) {
+                uint32_t qlo[NW], qhi[NW], rlo[NW + 2], rhi[NW + 2];
+#pragma unroll
+                for (int k = 0; k < NW; k++) { const uint4 v = planes4(io.qplanes, qo + 32u * k); qlo[k] = v.x; qhi[k] = v.y; }
+#pragma unroll
+                for (int k = 0; k < NW + 2; k++) { const uint4 v = planes4(io.wplanes, (uint64_t)wo - 32u + 32u * k); rlo[k] = v.x; rhi[k] = v.y; }
+                ok = sw_diag_cert<X, NW>(qlo, qhi, rlo, rhi, (int)lq, m);
+            }
+            if (ok) {
+                uint32_t len = 2;
+                for (uint32_t v = lq; v >= 10; v /= 10) len++;
+                io.c_score[c] = 2 * (int)lq - 3 * m;
+                io.c_ciglen[c] = len | CIG_DIAG;
+                io.c_status[c] = len > io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                ndone++;
+            } else pass_on = true;
+        }
+        waveq_push(qr, pass_on, c, rest, rest_count);
+    }
+    waveq_drain(qr, rest, rest_count);
+    const unsigned long long sums[1] = {wave_sum_u64(ndone)};
+    unsigned long long *const g64[1] = {nullptr};
+    unsigned int *const g32[1] = {done_count};
+    const uint32_t mx[1] = {0};
+    unsigned int *const gmx[1] = {nullptr};
+    block_counters(sums, g64, g32, mx, gmx);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -183,6 +183,8 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     // round 4: a 12-diagonal tier in front of the banded tiers, for the candidates the prefilter found on a square window with at most
     // six mismatches (its own queue, dq_lo): candidates it was given, those it passed on to the 20-diagonal tier, its work counter, those
     // it sent straight to the 32-diagonal tier; the length of its queue
-    unsigned int band0_in, band0_left, band0_next, band0_direct, dq_lo_count, pad2_[3];
+    unsigned int band0_in, band0_left, band0_next, band0_direct, dq_lo_count;
+    // ... and in front of that tier the certificate kernel k_sw_cert: what it could not settle (the 12-diagonal tier's queue then), what it settled
+    unsigned int cert_left, cert_done, pad2_[1];
 };
 

@@ -46,7 +46,7 @@ class Constants(C.Structure):
 class BatchCounts(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_reads", "n_tasks", "lf_steps", "sa_reads", "n_clusters", "sw_cells",
                                           "n_hits", "cigar_bytes", "window_bytes", "n_float", "n_traced", "n_dp", "n_lookups", "n_small",
-                                          "n_handed_back", "n_banded")]
+                                          "n_handed_back", "n_banded", "n_certified")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -57,7 +57,7 @@ class RunStats(C.Structure):
 
 
 OPTION_FIELDS = ("seed_fuse", "seed_fast", "seed_big", "search_ilp", "sw_prefilter", "sw_fuse_cand", "sw_wave", "sw_band", "sw_band_min",
-                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow", "sw_band12", "up_zero_copy", "small_graph")
+                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow", "sw_band12", "up_zero_copy", "small_graph", "sw_cert")
 
 
 class Options(C.Structure):

@@ -80,6 +80,8 @@ typedef struct {
                                    DESIGN 8 has the measurement. */
     int32_t small_graph;        /* 0: bwt_small_align never replays its launches as a hipGraph (it does from the second batch of one
                                    shape in a row) */
+    int32_t sw_cert;            /* 0: no mismatch-mask certificate (k_sw_cert) in front of the 12-diagonal tier: every candidate of its queue
+                                   runs the banded DP */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 
@@ -261,6 +263,8 @@ typedef struct {
     uint64_t n_small;                /* reads with 1..64 seeds left to k_cluster_small (the rest: none, fused, or wider kernels) */
     uint64_t n_handed_back;          /* reads k_seed_fast handed back to the general seed kernel (0 when it did not run) */
     uint64_t n_banded;               /* DP candidates settled by the banded kernel (exact by its certificate); n_dp counts them too */
+    uint64_t n_certified;            /* candidates past the prefilter that k_sw_cert settled without a DP (square window, 3..6 mismatches on
+                                        its diagonal, no other path can reach it: bwt_amd/csrc/sw_cert.h); n_dp does NOT count them */
 } bwt_batch_counts;
 int bwt_batch_create(bwt_index *idx, bwt_batch **out);
 void bwt_batch_destroy(bwt_batch *b);

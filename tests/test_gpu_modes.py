@@ -38,7 +38,7 @@ def check_against_oracle(out, reads, orc_fm, ref1):
 MODES = [{"seed_big": 1}, {"ktab_summary": 2}, {"ktab_summary": 0}, {"sw_band": 0}, {"sw_band": 2, "sw_band_min": 0}, {"sw_band_min": 0}, {"sw_band_min": 0, "sw_wave": 0},
          {"seed_fuse": 0}, {"sw_prefilter": 0}, {"sw_pk": 0}, {"sw_pk": 2}, {"sw_lds": 0}, {"sw_trace_all": 0, "sw_wave": 0},
          {"sw_wave": 0, "sw_prefilter": 0}, {"search_ilp": 2}, {"seed_fast": 0}, {"sw_fuse_cand": 0}, {"sw_band12": 0, "sw_band_min": 0},
-         {"hits_narrow": 1}]
+         {"hits_narrow": 1}, {"sw_cert": 0, "sw_band_min": 0}]
 
 
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: ",".join("%s=%s" % kv for kv in m.items()))
@@ -332,7 +332,7 @@ def test_banded_dp_settles_what_its_certificate_covers(gpu_index, orc_fm, ref_by
         b.set_options(sw_band_min=0, sw_band=0)
         c0 = b.run(lib.STAGE_EXTEND)
         out0 = b.fetch_hits()
-        assert c0["n_banded"] == 0 and c0["n_dp"] == c["n_dp"]
+        assert c0["n_banded"] == 0 and c0["n_certified"] == 0 and c0["n_dp"] == c["n_dp"] + c["n_certified"]      # (no band tiers: no certificate kernel either)
         for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
             assert np.array_equal(out[k], out0[k]), k
         assert out["cigar"] == out0["cigar"]
@@ -358,13 +358,13 @@ def test_twelve_diagonal_tier(gpu_index, orc_fm, ref_bytes):
                 q[int(p)] = int(rng.choice([x for x in b"ACGT" if x != q[int(p)]]))
             reads.append(bytes(q))
     b = lib.Batch(gpu_index)
-    b.set_options(sw_band_min=0)
+    b.set_options(sw_band_min=0, sw_cert=0)
     try:
         b.set_reads(*lib.pack_reads(reads))
         c = b.run(lib.STAGE_EXTEND)
         out = b.fetch_hits()
         assert check_against_oracle(out, reads, orc_fm, ref1) > 500
-        assert c["n_banded"] > 400 and c["n_dp"] >= c["n_banded"], c
+        assert c["n_banded"] > 400 and c["n_dp"] >= c["n_banded"] and c["n_certified"] == 0, c
         b.set_options(sw_band_min=0, sw_band12=0)
         c0 = b.run(lib.STAGE_EXTEND)
         out0 = b.fetch_hits()
@@ -372,14 +372,78 @@ def test_twelve_diagonal_tier(gpu_index, orc_fm, ref_bytes):
         for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
             assert np.array_equal(out[k], out0[k]), k
         assert out["cigar"] == out0["cigar"]
-        b.set_options(sw_band12=1)                                  # the short-queue route: every tier passes its queue on to k_sw_wave
+        b.set_options(sw_band12=1, sw_cert=0)                       # the short-queue route: every tier passes its queue on to k_sw_wave
         b.run(lib.STAGE_EXTEND)
         out1 = b.fetch_hits()
         for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
             assert np.array_equal(out[k], out1[k]), k
         assert out["cigar"] == out1["cigar"]
+        # the certificate kernel in front of the tier (the default): the same tables, most of the tier's queue settled without a DP
+        b.set_options(sw_band_min=0)
+        c2 = b.run(lib.STAGE_EXTEND)
+        out2 = b.fetch_hits()
+        assert c2["n_certified"] > 300 and c2["n_dp"] + c2["n_certified"] == c["n_dp"], (c2, c)
+        for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+            assert np.array_equal(out[k], out2[k]), k
+        assert out["cigar"] == out2["cigar"]
     finally:
         b.destroy()
+
+
+def _sub_reads(rng, ref, n, lengths, where=None, clump=False):
+    """reads with 3..6 substitutions and no indel; where: (start, length) regions to sample from; clump: the substitutions within a
+    dozen bases of each other (and of a read end, one time in three)"""
+    reads = []
+    for i in range(n):
+        L = int(lengths[i % len(lengths)])
+        if where:
+            st, ln = where[int(rng.integers(0, len(where)))]
+            a = int(np.clip(int(rng.integers(st - L // 2, st + ln - L // 2)), 0, len(ref) - L))
+        else:
+            a = int(rng.integers(0, len(ref) - L))
+        q = bytearray(ref[a:a + L])
+        m = int(rng.integers(3, 7))
+        if clump:
+            c0 = 0 if i % 3 == 0 else L - 13 if i % 3 == 1 else int(rng.integers(0, L - 12))
+            ps = c0 + rng.choice(12, m, replace=False)
+        else:
+            ps = rng.choice(L, m, replace=False)
+        for p in ps:
+            q[int(p)] = int(rng.choice([x for x in b"ACGT" if x != q[int(p)]]))
+        reads.append(bytes(q))
+    return reads
+
+
+def _same_tables(a, b, what):
+    for k in ("read_status", "hit_off", "score", "pos", "win_off", "win_len", "cig_off"):
+        assert np.array_equal(a[k], b[k]), (what, k)
+    assert a["cigar"] == b["cigar"], what
+
+
+def test_certificate_kernel_every_word_count(gpu_index, orc_fm, ref_bytes):
+    """k_sw_cert (bwt_amd/csrc/sw_cert.h): read lengths around its word boundaries (the four-word instance takes up to 128 bases, the
+    five-word one up to 160, longer batches skip it), substitutions spread and in clumps at the read's ends -- where its start and
+    end rules decide.  Against the oracle, and against the same batch with the kernel switched off."""
+    from bwt_amd import lib
+    from oracle import erl_literal as E
+    ref1 = E.make_ref1(ref_bytes)
+    rng = np.random.default_rng(77)
+    for lengths, expect in (((100,), True), ((24, 31, 32, 33, 64, 96, 127, 128), True), ((129, 150, 159, 160), True), ((100, 161), False)):
+        reads = _sub_reads(rng, ref_bytes, 700, lengths) + _sub_reads(rng, ref_bytes, 500, lengths, clump=True)
+        b = lib.Batch(gpu_index)
+        b.set_options(sw_band_min=0)
+        try:
+            b.set_reads(*lib.pack_reads(reads))
+            c = b.run(lib.STAGE_EXTEND)
+            out = b.fetch_hits()
+            assert check_against_oracle(out, reads, orc_fm, ref1) > 300
+            assert (c["n_certified"] > 200) == expect, (lengths, c)
+            b.set_options(sw_band_min=0, sw_cert=0)
+            c0 = b.run(lib.STAGE_EXTEND)
+            assert c0["n_certified"] == 0 and c0["n_dp"] == c["n_dp"] + c["n_certified"], (c0, c)
+            _same_tables(out, b.fetch_hits(), lengths)
+        finally:
+            b.destroy()
 
 
 @pytest.fixture(scope="module")
@@ -408,6 +472,33 @@ def tandem_index():
     ptr, shift = ix.meta()
     yield ix, ref, regions, orc.OrcFM.from_L_SA(L, SA, ptr, shift), E.make_ref1(ref)
     ix.close()
+
+
+def test_certificate_kernel_in_tandem_repeats(tandem_index):
+    """Substitution-only reads inside tandem tracts: the neighbouring diagonals of their square windows match almost everywhere (period
+    1..5 tracts put a perfect copy within the certificate's eleven diagonals), so a detour is often as good as the diagonal -- the case
+    the certificate must refuse, not settle.  Whatever it settles has to be the oracle's answer."""
+    from bwt_amd import lib
+    ix, ref, regions, ofm, ref1 = tandem_index
+    rng = np.random.default_rng(4711)
+    where = [(st, ln) for (st, ln, period) in regions]
+    short = [(st, ln) for (st, ln, period) in regions if period <= 5]
+    reads = (_sub_reads(rng, ref, 700, (100, 150, 64), where) + _sub_reads(rng, ref, 500, (100, 128), where, clump=True) +
+             _sub_reads(rng, ref, 400, (100, 48), short, clump=True))
+    b = lib.Batch(ix)
+    b.set_options(sw_band_min=0)
+    try:
+        b.set_reads(*lib.pack_reads(reads))
+        c = b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        assert check_against_oracle(out, reads, ofm, ref1) > 300
+        assert c["n_certified"] > 50, c
+        b.set_options(sw_band_min=0, sw_cert=0)
+        c0 = b.run(lib.STAGE_EXTEND)
+        assert c0["n_dp"] == c["n_dp"] + c["n_certified"], (c0, c)
+        _same_tables(out, b.fetch_hits(), "tandem")
+    finally:
+        b.destroy()
 
 
 @pytest.mark.parametrize("length", [100, 150])
