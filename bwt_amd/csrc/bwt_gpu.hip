@@ -423,7 +423,7 @@ struct bwt_batch {
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2, tqw;
     DevBuf bq, bq2, bq3, slab_band;    // k_sw_band: the queues of what its tiers pass on (bq3: first tier -> third), the direction slab
     DevBuf dq_lo, bq0, bqs;            // the 12-diagonal tier: its queue (filled by the prefilter), what it passes on, what it sends past the next tier
-    DevBuf cq;                         // what k_sw_cert leaves of dq_lo (the 12-diagonal tier's queue when the certificate kernel runs)
+    DevBuf cq, cq2;                    // what k_sw_cert leaves of dq_lo (the 12-diagonal tier's queue when the certificate kernel runs); the queue of its wider instance
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
     DevBuf pfq;                        // candidates the fused prefilter pass listed for the quad-per-candidate pass
@@ -590,7 +590,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->tqw, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs,
-                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs, &b->cq};
+                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs, &b->cq, &b->cq2};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -1218,7 +1218,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     if (!first) {
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->fp_count, 0, 16, b->stream));     // fp_count, tq_count, dq_count, tq2_count
         HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band_in, 0, 48, b->stream));      // band_*, pf_ov, band2_*, band3_*
-        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band0_in, 0, 28, b->stream));     // band0_*, dq_lo_count, cert_*
+        HIPCHK(hipMemsetAsync(&b->ctr.as<Counters>()->band0_in, 0, 32, b->stream));     // band0_*, dq_lo_count, cert_*
     }
     SwIO io;
     io.qbuf = qbuf; io.rbuf = rbuf; io.rbuf_len = rbuf_len;
@@ -1234,9 +1234,14 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
     const uint32_t lq_bound = b->ix ? b->max_lq : max_lq;
     const bool band_on = qplanes && wplanes && b->opt.sw_prefilter != 0 && lq_bound >= 2 && lq_bound <= SWB_MAX_LQ && b->opt.sw_band != 0;
     const bool band12 = band_on && b->ix && b->opt.sw_band12 != 0;
+    // ... and in front of that tier the certificate kernels (bwt_options.sw_cert = 0: none; 2: the 11-diagonal instance only, which takes
+    // up to six mismatches; else also the 19-diagonal one for seven to ten, whose candidates the prefilter then queues with the others)
+    const bool cert_on = band12 && b->opt.sw_cert != 0 && lq_bound <= 160;
+    const bool cert_wide = cert_on && b->opt.sw_cert != 2;
     if (band12) {
         if ((rc = b->dq_lo.ensure(nc * 4 + 4)) || (rc = b->bq0.ensure(nc * 4 + 4)) || (rc = b->bqs.ensure(nc * 4 + 4))) return rc;
         io.dq_lo = b->dq_lo.as<uint32_t>();
+        io.lo_max_m = cert_wide ? 10u : 6u;
     }
     if (qplanes && wplanes && b->opt.sw_prefilter != 0) {
         io.dq = b->dq.as<uint32_t>();
@@ -1259,6 +1264,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
             Counters *dc = b->ctr.as<Counters>();
             src.ovq = b->pfq.as<uint32_t>(); src.ov_count = &dc->pf_ov;
             src.ulen = b->ulen;
+            if (b->opt.pf_kcap >= 0) src.kcap = (uint32_t)b->opt.pf_kcap + 1u;
             const uint32_t pf_grid = (uint32_t)std::min<uint64_t>(cdiv((uint64_t)b->n * 4, 256), (uint64_t)dev_cus * b->occ_prefilter);
             KLAUNCH(b, "sw_prefilter", k_sw_prefilter<true>, pf_grid, 256, io, b->n, src);
             {
@@ -1325,17 +1331,27 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         // all (bwt_options.sw_cert = 0: nothing)
         const uint32_t *q12 = b->dq_lo.as<uint32_t>();
         const unsigned int *n12 = &dc->dq_lo_count;
-        if (band12 && b->opt.sw_cert != 0 && max_lq <= 160) {
-            if ((rc = b->cq.ensure(nc * 4 + 4))) return rc;
+        if (cert_on) {
+            if ((rc = b->cq.ensure(nc * 4 + 4)) || (rc = b->cq2.ensure(nc * 4 + 4))) return rc;
             ProfScope pc(b, "sw_cert");
             const uint32_t cblocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(nc, 256), (uint64_t)dev_cus * 8));
-            if (max_lq <= 128)
-                hipLaunchKernelGGL((k_sw_cert<5, 4>), dim3(cblocks), dim3(256), 0, b->stream, io, q12, n12, b->cq.as<uint32_t>(), &dc->cert_left,
-                                   &dc->cert_done, band_min);
+            uint32_t *const over = cert_wide ? b->cq2.as<uint32_t>() : nullptr;
+            if (lq_bound <= 128)
+                hipLaunchKernelGGL((k_sw_cert<5, 4>), dim3(cblocks), dim3(256), 0, b->stream, io, q12, n12, b->cq.as<uint32_t>(), &dc->cert_left, over,
+                                   &dc->cert2_in, &dc->cert_done);
             else
-                hipLaunchKernelGGL((k_sw_cert<5, 5>), dim3(cblocks), dim3(256), 0, b->stream, io, q12, n12, b->cq.as<uint32_t>(), &dc->cert_left,
-                                   &dc->cert_done, band_min);
+                hipLaunchKernelGGL((k_sw_cert<5, 5>), dim3(cblocks), dim3(256), 0, b->stream, io, q12, n12, b->cq.as<uint32_t>(), &dc->cert_left, over,
+                                   &dc->cert2_in, &dc->cert_done);
             q12 = b->cq.as<uint32_t>(); n12 = &dc->cert_left;
+            // the wider instance on what had seven to ten mismatches; what it cannot settle joins the 20-diagonal tier's own queue
+            if (cert_wide) {
+                if (lq_bound <= 128)
+                    hipLaunchKernelGGL((k_sw_cert<9, 4>), dim3(cblocks), dim3(256), 0, b->stream, io, (const uint32_t *)b->cq2.as<uint32_t>(),
+                                       (const unsigned int *)&dc->cert2_in, io.dq, &dc->dq_count, (uint32_t *)nullptr, (unsigned int *)nullptr, &dc->cert_done);
+                else
+                    hipLaunchKernelGGL((k_sw_cert<9, 5>), dim3(cblocks), dim3(256), 0, b->stream, io, (const uint32_t *)b->cq2.as<uint32_t>(),
+                                       (const unsigned int *)&dc->cert2_in, io.dq, &dc->dq_count, (uint32_t *)nullptr, (unsigned int *)nullptr, &dc->cert_done);
+            }
         }
         {
             ProfScope ps(b, "sw_band");

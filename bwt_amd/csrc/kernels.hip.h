@@ -36,18 +36,25 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // entries at a time -- one same-address atomic per 64 entries instead of one per wave-iteration (they run at ~88 per us,
 // which a kernel that queues most of its items would spend tens of ms on).  push/drain are reached by whole waves.
 struct WaveQ { uint32_t *buf; uint32_t have; };
+// FL: entries a flush takes queue space for (a multiple of 64; the buffer holds FL + 64).  A kernel that queues most of what it looks
+// at -- the prefilter on a repeat-rich batch: 15 M DP candidates and 13 M list entries -- is bound by that one atomic per 64 entries
+// (240 k same-address atomics = 2.7 ms): its queues flush 256 at a time.
+template <int FL = 64>
 __device__ __forceinline__ void waveq_out(WaveQ &q, uint32_t nout, uint32_t *__restrict__ gq, unsigned int *counter) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(counter, nout);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (lane < nout) gq[base + lane] = q.buf[lane];
-    const uint32_t rest = lane + 64 < q.have ? q.buf[lane + 64] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)FL; k += 64)
+        if (k + lane < nout) gq[base + k + lane] = q.buf[k + lane];
+    const uint32_t rest = lane + nout < q.have ? q.buf[lane + nout] : 0u;          // (fewer than 64 entries are ever left behind a flush)
     __builtin_amdgcn_wave_barrier();
-    if (lane + 64 < q.have) q.buf[lane] = rest;
+    if (lane + nout < q.have) q.buf[lane] = rest;
     q.have -= nout;
     __builtin_amdgcn_wave_barrier();
 }
+template <int FL = 64>
 __device__ __forceinline__ void waveq_push(WaveQ &q, bool pred, uint32_t v, uint32_t *__restrict__ gq, unsigned int *counter) {
     const unsigned long long m = __ballot(pred);
     if (!m) return;
@@ -55,10 +62,12 @@ __device__ __forceinline__ void waveq_push(WaveQ &q, bool pred, uint32_t v, uint
     if (pred) q.buf[q.have + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
     q.have += (uint32_t)__popcll(m);
     __builtin_amdgcn_wave_barrier();
-    if (q.have >= 64) waveq_out(q, 64, gq, counter);
+    if (q.have >= (uint32_t)FL) waveq_out<FL>(q, (uint32_t)FL, gq, counter);
 }
+// (what is left at the end of the kernel: up to FL + 63 entries)
+template <int FL = 64>
 __device__ __forceinline__ void waveq_drain(WaveQ &q, uint32_t *__restrict__ gq, unsigned int *counter) {
-    if (q.have) waveq_out(q, q.have, gq, counter);
+    while (q.have) waveq_out<FL>(q, q.have < (uint32_t)FL ? q.have : (uint32_t)FL, gq, counter);
 }
 // Work counters at the end of a kernel: a wave's (wave-uniform) sums go into block-shared accumulators and ONE thread of the
 // block adds them to the global counters.  Same-address global atomics run at ~88 per us on this part: a launch of a few hundred
@@ -2170,8 +2179,9 @@ struct SwIO {
     const uint32_t *tq_in;     // k_sw<SW_TRACE>: its queue and count when they are not tq / ctr->tq_count (what the wide pass of k_sw_pk left)
     const unsigned int *tq_in_count;
     Counters *ctr;
-    uint32_t *dq_lo = nullptr; // k_sw_prefilter: DP candidates on a SQUARE window with 3..6 mismatches on its diagonal go here instead of dq
-                               // (count: ctr->dq_lo_count): the 12-diagonal tier of the banded DP settles exactly those; null: all to dq
+    uint32_t *dq_lo = nullptr; // k_sw_prefilter: DP candidates on a SQUARE window with 3..lo_max_m mismatches on its diagonal go here instead of dq
+                               // (count: ctr->dq_lo_count): the 12-diagonal tier of the banded DP settles exactly those with up to 6; null: all to dq
+    uint32_t lo_max_m = 6;     // ... 6 without the certificate kernels in front of that tier, as many as their widest instance takes with them
 };
 
 // writes "<n><op>" right to left, returns the new write position
@@ -2469,7 +2479,8 @@ struct CandSrc {
 template <bool FROM_READS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
-    __shared__ uint32_t wq_[4][4][128];
+    constexpr int FL = 256;
+    __shared__ uint32_t wq_[4][4][FL + 64];
     WaveQ qfp, qdp, qov, qlo;
     qfp.buf = wq_[threadIdx.x >> 6][0]; qfp.have = 0; qdp.buf = wq_[threadIdx.x >> 6][1]; qdp.have = 0;
     qov.buf = wq_[threadIdx.x >> 6][2]; qov.have = 0; qlo.buf = wq_[threadIdx.x >> 6][3]; qlo.have = 0;
@@ -2540,7 +2551,7 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
                     cells += (unsigned long long)lq_r * w; wbytes += w;
                     maxw = w > maxw ? w : maxw;
                 }
-                waveq_push(qov, have, c, src.ovq, src.ov_count);
+                waveq_push<FL>(qov, have, c, src.ovq, src.ov_count);
             }
             kmax = kcap;
             K_r = K_r < kcap ? K_r : kcap;
@@ -2674,19 +2685,19 @@ void k_sw_prefilter(SwIO io, uint32_t n_items, CandSrc src) {
             }
             if (FROM_READS && route != 0 && ql == 0) { src.c_qoff[c] = qo; src.c_qlen[c] = lq; src.c_woff[c] = wo; }
             // the two queues, staged in LDS (one atomic per 64 entries)
-            waveq_push(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
+            waveq_push<FL>(qfp, route == 1 && ql == 0, c, io.fpq, &io.ctr->fp_count);
             // (a square window whose diagonal has at most six mismatches scores >= 2 Lq - 18 on it: what the 12-diagonal band's
             // certificate covers -- 0.6 of the first tier's cells)
-            const bool lo_q = route == 2 && io.dq_lo != nullptr && square && mism <= 6 && lq >= 24;
-            waveq_push(qdp, route == 2 && !lo_q && ql == 0, c, io.dq, &io.ctr->dq_count);
-            if (io.dq_lo) waveq_push(qlo, lo_q && ql == 0, c, io.dq_lo, &io.ctr->dq_lo_count);
+            const bool lo_q = route == 2 && io.dq_lo != nullptr && square && mism <= io.lo_max_m && lq >= 24;
+            waveq_push<FL>(qdp, route == 2 && !lo_q && ql == 0, c, io.dq, &io.ctr->dq_count);
+            if (io.dq_lo) waveq_push<FL>(qlo, lo_q && ql == 0, c, io.dq_lo, &io.ctr->dq_lo_count);
         }
         }
-    waveq_drain(qfp, io.fpq, &io.ctr->fp_count);
-    waveq_drain(qdp, io.dq, &io.ctr->dq_count);
-    if (io.dq_lo) waveq_drain(qlo, io.dq_lo, &io.ctr->dq_lo_count);
+    waveq_drain<FL>(qfp, io.fpq, &io.ctr->fp_count);
+    waveq_drain<FL>(qdp, io.dq, &io.ctr->dq_count);
+    if (io.dq_lo) waveq_drain<FL>(qlo, io.dq_lo, &io.ctr->dq_lo_count);
     if (FROM_READS) {
-        waveq_drain(qov, src.ovq, src.ov_count);
+        waveq_drain<FL>(qov, src.ovq, src.ov_count);
         const unsigned long long sums[2] = {wave_sum_u64(cells), wave_sum_u64(wbytes)};
         unsigned long long *const g64[2] = {&io.ctr->sw_cells, &io.ctr->window_bytes};
         unsigned int *const g32[2] = {nullptr, nullptr};
@@ -3395,38 +3406,36 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
 // checked on the CPU against the oracle's full table, tests/cert_check/).  Where the certificate holds the candidate is settled like
 // one of the prefilter's own (score, CIG_DIAG length, no text); the others go on to the banded tiers in a queue of their own.
 // ~2 k lane-instructions per candidate against ~10 k in k_sw_band<12> -- and no direction slab, no traceback, no extra record.
+// `over` / over_count: where candidates with more than X + 1 mismatches go (the queue of the next, wider instance); null: to `rest`
+// with the others.  rest_count may be a queue that already holds entries (the wider instance appends to the 20-diagonal tier's DP queue).
 template <int X, int NW>
 __global__ __launch_bounds__(256) void k_sw_cert(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count,
-                                                 uint32_t *__restrict__ rest, unsigned int *__restrict__ rest_count, unsigned int *__restrict__ done_count,
-                                                 uint32_t skip_upto) {
-    __shared__ uint32_t wq_[4][128];
-    WaveQ qr;
-    qr.buf = wq_[threadIdx.x >> 6]; qr.have = 0;
-    const uint32_t n_items = *in_count;
-    if (n_items <= skip_upto) {
-        // a short queue is k_sw_wave's: handed through (the band tiers do the same)
-        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += gridDim.x * blockDim.x) rest[t] = in_q[t];
-        if (blockIdx.x == 0 && threadIdx.x == 0) *rest_count = n_items;
-        return;
-    }
+                                                 uint32_t *__restrict__ rest, unsigned int *__restrict__ rest_count, uint32_t *__restrict__ over,
+                                                 unsigned int *__restrict__ over_count, unsigned int *__restrict__ done_count) {
+    constexpr int FL = 256;
+    __shared__ uint32_t wq_[4][2][FL + 64];
+    WaveQ qr, qo;
+    qr.buf = wq_[threadIdx.x >> 6][0]; qr.have = 0;
+    qo.buf = wq_[threadIdx.x >> 6][1]; qo.have = 0;
+    const uint32_t n_items = *in_count;          // (a short queue is run like any other: the kernel is a few microseconds then)
     uint32_t ndone = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t t0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < n_items; t0 += stride) {          // whole waves iterate together
         const uint32_t t = t0 + (threadIdx.x & 63u);
         const bool have = t < n_items;
         const uint32_t c = have ? in_q[t] : 0u;
-        bool pass_on = false;
+        bool pass_on = false, too_many = false;
         if (have) {
             const uint32_t lq = io.c_qlen[c], w = io.c_wlen[c];
             const int64_t wo = io.c_woff[c];
-            const uint64_t qo = io.c_qoff[c];
+            const uint64_t qo_ = io.c_qoff[c];
             // the planes of the 32 bases in front of the window and of up to 32 behind its last word must exist
             bool ok = w == lq && lq >= 24 && lq <= 32u * NW && wo >= 32 && (uint64_t)wo + 32u * (NW + 1) <= io.rbuf_len;
             int m = 0;
             if (ok) {
                 uint32_t qlo[NW], qhi[NW], rlo[NW + 2], rhi[NW + 2];
 #pragma unroll
-                for (int k = 0; k < NW; k++) { const uint4 v = planes4(io.qplanes, qo + 32u * k); qlo[k] = v.x; qhi[k] = v.y; }
+                for (int k = 0; k < NW; k++) { const uint4 v = planes4(io.qplanes, qo_ + 32u * k); qlo[k] = v.x; qhi[k] = v.y; }
 #pragma unroll
                 for (int k = 0; k < NW + 2; k++) { const uint4 v = planes4(io.wplanes, (uint64_t)wo - 32u + 32u * k); rlo[k] = v.x; rhi[k] = v.y; }
                 ok = sw_diag_cert<X, NW>(qlo, qhi, rlo, rhi, (int)lq, m);
@@ -3438,11 +3447,13 @@ __global__ __launch_bounds__(256) void k_sw_cert(SwIO io, const uint32_t *__rest
                 io.c_ciglen[c] = len | CIG_DIAG;
                 io.c_status[c] = len > io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
                 ndone++;
-            } else pass_on = true;
+            } else { too_many = over != nullptr && m > X + 1; pass_on = !too_many; }
         }
-        waveq_push(qr, pass_on, c, rest, rest_count);
+        waveq_push<FL>(qr, pass_on, c, rest, rest_count);
+        if (over) waveq_push<FL>(qo, too_many, c, over, over_count);
     }
-    waveq_drain(qr, rest, rest_count);
+    waveq_drain<FL>(qr, rest, rest_count);
+    if (over) waveq_drain<FL>(qo, over, over_count);
     const unsigned long long sums[1] = {wave_sum_u64(ndone)};
     unsigned long long *const g64[1] = {nullptr};
     unsigned int *const g32[1] = {done_count};

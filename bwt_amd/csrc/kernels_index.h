@@ -185,6 +185,6 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     // it sent straight to the 32-diagonal tier; the length of its queue
     unsigned int band0_in, band0_left, band0_next, band0_direct, dq_lo_count;
     // ... and in front of that tier the certificate kernel k_sw_cert: what it could not settle (the 12-diagonal tier's queue then), what it settled
-    unsigned int cert_left, cert_done, pad2_[1];
+    unsigned int cert_left, cert_done, cert2_in;      // (cert2_in: the queue of its wider instance, candidates with 7..10 mismatches)
 };
 

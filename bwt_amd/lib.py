@@ -57,7 +57,7 @@ class RunStats(C.Structure):
 
 
 OPTION_FIELDS = ("seed_fuse", "seed_fast", "seed_big", "search_ilp", "sw_prefilter", "sw_fuse_cand", "sw_wave", "sw_band", "sw_band_min",
-                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow", "sw_band12", "up_zero_copy", "small_graph", "sw_cert")
+                 "sw_lds", "sw_pk", "sw_trace_all", "pf_blocks_per_cu", "sw_blocks_per_cu", "sw_waves_per_cu", "debug", "hits_narrow", "sw_band12", "up_zero_copy", "small_graph", "sw_cert", "pf_kcap")
 
 
 class Options(C.Structure):

@@ -81,7 +81,10 @@ typedef struct {
     int32_t small_graph;        /* 0: bwt_small_align never replays its launches as a hipGraph (it does from the second batch of one
                                    shape in a row) */
     int32_t sw_cert;            /* 0: no mismatch-mask certificate (k_sw_cert) in front of the 12-diagonal tier: every candidate of its queue
-                                   runs the banded DP */
+                                   runs the banded DP; 2: only its 11-diagonal instance (square windows with up to 6 mismatches), not the
+                                   19-diagonal one (7..10) */
+    int32_t pf_kcap;            /* candidates of a read the fused prefilter pass tests itself before it lists the rest for the quad-per-candidate
+                                   pass (default 2; 0: it lists them all) */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 

@@ -36,4 +36,15 @@ out["W>254"] = {"hits": int(len(wide)), "D_percentiles": {str(q): int(np.percent
                 "cells": int(((wide.astype(np.int64) + L) * L).sum())}
 mid = D[(D > 57) & (D <= 154)]
 out["57<D<=154"] = {"hits": int(len(mid)), "cells": int(((mid.astype(np.int64) + L) * L).sum())}
+# round 4: which candidates could a certificate for the plain diagonal take?  Square windows whose answer is "<L>M", by the number of
+# mismatches m = loss / 3; square windows with another answer; wider windows by D, with the share of "<L>M" answers among them
+cig = bytes(t["cigar"]); co = np.asarray(t["cig_off"])
+plain_txt = ("%dM" % L).encode()
+is_plain = np.fromiter((cig[int(co[h]):int(co[h + 1])] == plain_txt for h in range(len(score))), bool, len(score))
+sq = D == 0
+mm = loss[sq & is_plain] // 3
+out["square_plain_by_mismatches"] = {str(k): int((mm == k).sum()) for k in range(0, 34)}
+out["square_not_plain"] = int((sq & ~is_plain).sum())
+out["wider_by_D"] = {str(d): {"hits": int((D == d).sum()), "answer_is_LM": int(((D == d) & is_plain).sum())} for d in range(1, 21)}
+out["wider_D_over_20"] = {"hits": int((D > 20).sum()), "answer_is_LM": int(((D > 20) & is_plain).sum())}
 print(json.dumps(out, indent=1))

@@ -7,7 +7,7 @@
 // Instances lean towards what could break it: mismatches in clumps, at the read's ends, in adjacent rows; two-letter and periodic
 // sequences (neighbouring diagonals match often); reads of 18..160 bases.
 //   cert_check <cases> <seed> [plain]  ->  one line of counts, exit code 1 on the first violation.
-//   plain = 1: reads of 100 bases from an i.i.d. sequence with 3..6 (X = 5), 3..4 (X = 3), 3..8 (X = 7) substitutions at random places -- what
+//   plain = 1: reads of 100 bases from an i.i.d. sequence with 3..6 (X = 5), 3..4 (X = 3), 3..8 (X = 7), 7..10 (X = 9) substitutions at random places -- what
 //   the certificate's share of plain-diagonal answers is on ordinary candidates.
 #include <cstdio>
 #include <cstdlib>
@@ -111,7 +111,7 @@ int main(int argc, char **argv) {
     const bool plain = argc > 3 && atoi(argv[3]) != 0;
     std::mt19937_64 rng(seed);
     auto U = [&](int lo, int hi) { return (int)(lo + rng() % (uint64_t)(hi - lo + 1)); };
-    long counts[4][4] = {};      // per template: cases, bound checks, certified, plain-diagonal answers the certificate missed
+    long counts[6][4] = {};      // per template: cases, bound checks, certified, plain-diagonal answers the certificate missed
     for (long it = 0; it < cases; it++) {
         const int kind = U(0, 9);
         const int L = plain ? 100 : (it % 7 == 0) ? U(18, 160) : (it % 3 == 0 ? 100 : U(24, 128));
@@ -131,7 +131,7 @@ int main(int argc, char **argv) {
         }
         std::vector<uint8_t> q(ref.begin() + margin, ref.begin() + margin + L);
         // mismatches: how many and where
-        const int m = plain ? (it % 4 == 0 ? U(3, 4) : it % 4 == 1 ? U(3, 8) : U(3, 6)) : kind == 9 ? U(0, 12) : U(1, 8);
+        const int m = plain ? (it % 4 == 0 ? U(3, 4) : it % 4 == 1 ? U(3, 8) : it % 4 == 3 ? U(7, 10) : U(3, 6)) : kind == 9 ? U(0, 14) : U(1, 10);
         std::vector<int> posn;
         const int place = plain ? 0 : U(0, 5);
         int anchor = place == 1 ? 0 : place == 2 ? L - 1 : U(0, L - 1);
@@ -157,11 +157,13 @@ int main(int argc, char **argv) {
             if (it % 4 == 1) rc |= run_case<7, 4>(q, ref, margin, L, counts[2]);
         }
         if (it % 4 == 2 || L > 128) rc |= run_case<5, 5>(q, ref, margin, L, counts[3]);
+        if (L <= 128 && it % 2 == 1) rc |= run_case<9, 4>(q, ref, margin, L, counts[4]);
+        if (it % 4 == 3 || (L > 128 && it % 2 == 0)) rc |= run_case<9, 5>(q, ref, margin, L, counts[5]);
         if (rc) return 1;
     }
-    const char *names[4] = {"X5_NW4", "X3_NW4", "X7_NW4", "X5_NW5"};
+    const char *names[6] = {"X5_NW4", "X3_NW4", "X7_NW4", "X5_NW5", "X9_NW4", "X9_NW5"};
     printf("{");
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 6; t++)
         printf("%s\"%s\": {\"cases\": %ld, \"bound_checks\": %ld, \"certified\": %ld, \"plain_but_not_certified\": %ld}", t ? ", " : "", names[t],
                counts[t][0], counts[t][1], counts[t][2], counts[t][3]);
     printf("}\n");

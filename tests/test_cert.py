@@ -22,8 +22,10 @@ def test_certificate_against_the_full_table(tmp_path):
     exe = build(tmp_path)
     out = json.loads(subprocess.check_output([exe, "120000", "20261005"]))
     for name, r in out.items():
-        assert r["bound_checks"] > 10000 and r["certified"] > 5000, (name, r)
+        assert r["bound_checks"] > 5000 and r["certified"] > 3000, (name, r)
     # ordinary candidates (i.i.d. sequence, random places): the certificate settles nine in ten of the plain-diagonal answers
     plain = json.loads(subprocess.check_output([exe, "40000", "7", "1"]))
     r = plain["X5_NW4"]
     assert r["certified"] > 0.9 * (r["certified"] + r["plain_but_not_certified"]), r
+    r = plain["X9_NW4"]                                  # seven to ten substitutions: four in five
+    assert r["certified"] > 0.8 * (r["certified"] + r["plain_but_not_certified"]), r

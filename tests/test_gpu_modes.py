@@ -391,7 +391,7 @@ def test_twelve_diagonal_tier(gpu_index, orc_fm, ref_bytes):
 
 
 def _sub_reads(rng, ref, n, lengths, where=None, clump=False):
-    """reads with 3..6 substitutions and no indel; where: (start, length) regions to sample from; clump: the substitutions within a
+    """reads with 3..10 substitutions (both instances of the certificate kernel) and no indel; where: (start, length) regions to sample from; clump: the substitutions within a
     dozen bases of each other (and of a read end, one time in three)"""
     reads = []
     for i in range(n):
@@ -402,7 +402,7 @@ def _sub_reads(rng, ref, n, lengths, where=None, clump=False):
         else:
             a = int(rng.integers(0, len(ref) - L))
         q = bytearray(ref[a:a + L])
-        m = int(rng.integers(3, 7))
+        m = int(rng.integers(3, 11))
         if clump:
             c0 = 0 if i % 3 == 0 else L - 13 if i % 3 == 1 else int(rng.integers(0, L - 12))
             ps = c0 + rng.choice(12, m, replace=False)
@@ -441,6 +441,12 @@ def test_certificate_kernel_every_word_count(gpu_index, orc_fm, ref_bytes):
             b.set_options(sw_band_min=0, sw_cert=0)
             c0 = b.run(lib.STAGE_EXTEND)
             assert c0["n_certified"] == 0 and c0["n_dp"] == c["n_dp"] + c["n_certified"], (c0, c)
+            _same_tables(out, b.fetch_hits(), lengths)
+            b.set_options(sw_band_min=0, sw_cert=2)                  # the 11-diagonal instance alone: fewer settled, the same tables
+            c2 = b.run(lib.STAGE_EXTEND)
+            assert c2["n_certified"] <= c["n_certified"] and c2["n_dp"] + c2["n_certified"] == c0["n_dp"], (c2, c)
+            if expect:
+                assert c2["n_certified"] < c["n_certified"], (c2, c)
             _same_tables(out, b.fetch_hits(), lengths)
         finally:
             b.destroy()
