@@ -423,6 +423,7 @@ struct bwt_batch {
     DevBuf slab_bnd, slab_bnd_t, slab_bndv, slab_dir, slab_bnd_fp, slab_dir_fp, slab_dir_pk, tq, dq, tq2, tqw;
     DevBuf bq, bq2, bq3, slab_band;    // k_sw_band: the queues of what its tiers pass on (bq3: first tier -> third), the direction slab
     DevBuf dq_lo, bq0, bqs;            // the 12-diagonal tier: its queue (filled by the prefilter), what it passes on, what it sends past the next tier
+    DevBuf hugeq;                      // reads k_cluster_big lists for k_cluster_huge
     DevBuf cq, cq2;                    // what k_sw_cert leaves of dq_lo (the 12-diagonal tier's queue when the certificate kernel runs); the queue of its wider instance
     bool band_ran = false;
     int occ_prefilter = 0;             // resident blocks per CU of k_sw_prefilter<true> (queried once per batch)
@@ -590,7 +591,7 @@ extern "C" void bwt_batch_destroy(bwt_batch *b) {
                      &b->c_woff, &b->c_wlen, &b->c_status, &b->c_score, &b->c_ciglen, &b->cig, &b->fpq, &b->slab_bnd,
                      &b->slab_bndv, &b->slab_dir, &b->slab_bnd_fp, &b->slab_dir_fp, &b->slab_bnd_t, &b->tq, &b->dq, &b->tq2, &b->tqw, &b->bq, &b->bq2, &b->bq3, &b->slab_band, &b->slab_dir_pk, &b->h_rec, &b->h_woff, &b->h_wlen,
                      &b->h_cigoff, &b->h_cig, &b->ctr, &b->r_pend, &b->r_cl, &b->smallq, &b->gq, &b->pairs,
-                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs, &b->cq, &b->cq2};
+                     &b->r_nn, &b->nn_off, &b->n_woff, &b->n_score, &b->w_rec, &b->w_xrec, &b->w_hoff, &b->w_status, &b->dq_lo, &b->bq0, &b->bqs, &b->cq, &b->cq2, &b->hugeq};
     for (auto d : all) d->release();
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -1162,11 +1163,27 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
                 b->mid4q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
                 b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
-    if (b->hctr.n_big)
-        KLAUNCH(b, "cluster_big", k_cluster_big, b->hctr.n_big, 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
+    if (b->hctr.n_big) {
+        // a block per read; a read of more seeds than its LDS holds is listed for k_cluster_huge (1024 threads, 124 KB of LDS per read)
+        if ((rc = b->hugeq.ensure((size_t)b->hctr.n_big * 4 + 4))) return rc;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+        Counters *dc = b->ctr.as<Counters>();
+        KLAUNCH(b, "cluster_big", k_cluster_big, std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus * 8), 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                 b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
-                b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
+                b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, b->hctr.n_big, b->hugeq.as<uint32_t>(), &dc->n_huge);
+        const size_t huge_lds = (size_t)(HUGE_LDS + 1024) * 4;
+        HIPCHK(hipFuncSetAttribute((const void *)k_cluster_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)huge_lds));
+        {
+            ProfScope ps(b, "cluster_big");
+            hipLaunchKernelGGL(k_cluster_huge, dim3(std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus)), dim3(1024), huge_lds, b->stream, b->ix->d, maxT,
+                               (const uint32_t *)b->hugeq.as<uint32_t>(), (const unsigned int *)&dc->n_huge, (const uint32_t *)b->t_def.as<uint32_t>(),
+                               (const uint32_t *)b->t_sp.as<uint32_t>(), (const uint32_t *)b->t_info.as<uint32_t>(), (const uint32_t *)b->t_cnt.as<uint32_t>(),
+                               (const uint32_t *)b->r_P.as<uint32_t>(), (const uint32_t *)b->r_qty.as<uint32_t>(), (const uint64_t *)b->seed_off.as<uint64_t>(),
+                               b->pos.as<uint32_t>(), b->r_K.as<uint32_t>());
+        }
+    }
     if (!all_clustered) {
         if ((rc = dev_scan(b, b->r_K.as<uint32_t>(), b->clus_off.as<uint64_t>(), n))) return rc;
         if ((rc = mail(b, &ncand, b->clus_off.as<uint64_t>() + n, 8))) return rc;
@@ -1671,6 +1688,10 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
     if (b->opt.debug > 0 && b->hctr.n_gq)
         fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u reads: non-ACGT %u, table overflow %u, more seeds than its row holds %u, >%d clusters %u\n",
                 b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
+    if (b->opt.debug > 0)
+        fprintf(stderr, "[libbwtgpu] cluster kernels: %u reads of 1..64 seeds, %u of 65..128, %u of 129..256, %u of more; certificate kernels: %u settled, %u "
+                        "passed to their wider instance, %u to the 12-diagonal tier\n", b->n_small, b->hctr.n_mid2, b->hctr.n_mid4, b->hctr.n_big,
+                b->hctr.cert_done, b->hctr.cert2_in, b->hctr.cert_left);
     if (counts) {
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;
         counts->sa_reads = b->hctr.sa_reads; counts->n_clusters = b->n_cand; counts->sw_cells = b->hctr.sw_cells;

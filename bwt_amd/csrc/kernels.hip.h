@@ -1970,52 +1970,131 @@ __global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, 
     cluster_wave_read<R>(ix, queue[w], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds[threadIdx.x >> 6]);
 }
 
-// k_cluster_big: workgroup per read (P > 64): gather into the read's slice of `pos`, sort it
-// (ascending-only bitonic network: virtual +inf padding past P), cluster sequentially.
+// k_cluster_big: workgroup per read (P > 256): gather, sort (ascending-only bitonic network: virtual +inf padding past P), cluster.
+// Round 4: (i) the seeds are gathered straight into LDS and stay there; (ii) the runs are found by the whole block -- a thread takes
+// a stretch of the sorted list, two block scans carry the last run start and the number of clusters across stretches -- where
+// one thread walked the P elements (20 us for 500 seeds: most of a read's time); (iii) a read of more seeds than this kernel's LDS
+// holds (a low-complexity read whose sub-reads die in not_found with whole intervals: thousands of seeds) is LISTED for
+// k_cluster_huge -- 1024 threads, 120 KB of LDS -- instead of being sorted in HBM by 256 threads: one such read took as long as
+// the other 70 000 of a repeat-rich batch together (2.2 ms).  What is larger still keeps the HBM path.
 #define BIG_LDS 4096
-// (one read, by a whole block; sh = BIG_LDS words of block-shared LDS.  Every thread of the block calls it.)
+#define HUGE_LDS 30720
+// inclusive scan of one value per thread over the block (NT threads, tmp: NT words of LDS); MAXOP: maximum, else sum
+template <int NT, bool MAXOP>
+__device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *tmp) {
+    tmp[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t d = 1; d < (uint32_t)NT; d <<= 1) {
+        const uint32_t o = threadIdx.x >= d ? tmp[threadIdx.x - d] : 0u;
+        __syncthreads();
+        v = MAXOP ? (o > v ? o : v) : v + o;
+        tmp[threadIdx.x] = v;
+        __syncthreads();
+    }
+    return v;
+}
+// get_similar (src/sga.erl:52-64) over the sorted list a[0..P) in LDS by the whole block: runs of neighbours at most BWT_TOLERANCE
+// apart, a run of at least nthr seeds is a cluster {its last seed, its width}; clusters go to reg in DESCENDING order (sga.erl prepends).
+template <int NT>
+__device__ __forceinline__ void cluster_runs_block(const uint32_t *a, uint32_t P, uint32_t nthr, uint32_t *__restrict__ reg, uint32_t *__restrict__ r_K_r,
+                                                   uint32_t *tmp) {
+    const uint32_t C = (P + NT - 1) / NT;
+    const uint32_t lo = threadIdx.x * C < P ? threadIdx.x * C : P, hi = lo + C < P ? lo + C : P;
+    uint32_t last = 0;                                        // index + 1 of the last run start in my stretch
+    for (uint32_t i = lo; i < hi; i++)
+        if (i == 0 || a[i] - a[i - 1] > BWT_TOLERANCE) last = i + 1;
+    (void)block_scan_incl<NT, true>(last, tmp);
+    // the last run start in front of my stretch: the inclusive maximum of the thread before me
+    const uint32_t start0 = threadIdx.x ? tmp[threadIdx.x - 1] : 0u;
+    __syncthreads();
+    uint32_t cur = start0, cnt = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        if (i == 0 || a[i] - a[i - 1] > BWT_TOLERANCE) cur = i + 1;
+        const bool end = i + 1 == P || a[i + 1] - a[i] > BWT_TOLERANCE;
+        if (end && i + 2 - cur >= nthr) cnt++;                // seeds in the run: i - (cur - 1) + 1
+    }
+    const uint32_t incl = block_scan_incl<NT, false>(cnt, tmp);
+    const uint32_t K = tmp[NT - 1];
+    uint32_t rank = incl - cnt;
+    cur = start0;
+    for (uint32_t i = lo; i < hi; i++) {
+        if (i == 0 || a[i] - a[i - 1] > BWT_TOLERANCE) cur = i + 1;
+        const bool end = i + 1 == P || a[i + 1] - a[i] > BWT_TOLERANCE;
+        if (end && i + 2 - cur >= nthr) {
+            const uint32_t k = K - 1 - rank;
+            reg[2 * k] = a[i]; reg[2 * k + 1] = a[i] - a[cur - 1];
+            rank++;
+        }
+    }
+    if (threadIdx.x == 0) *r_K_r = K;
+    __syncthreads();                                          // (tmp and a are reused by the block's next read)
+}
+// (one read, by a whole block of NT threads; sh = cap words of block-shared LDS, tmp = NT more.  Every thread of the block calls it.
+// hugeq / n_huge: where a read of more than cap seeds is listed instead; null: it is sorted in HBM and clustered by one thread)
+template <int NT>
 __device__ __forceinline__ void cluster_big_read(const DevIndex &ix, uint32_t r, uint32_t maxT, const uint32_t *__restrict__ t_def,
                                                  const uint32_t *__restrict__ t_sp, const uint32_t *__restrict__ t_info,
                                                  const uint32_t *__restrict__ t_cnt, const uint32_t *__restrict__ r_P,
                                                  const uint32_t *__restrict__ r_qty, const uint64_t *__restrict__ seed_off,
-                                                 uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K, uint32_t *sh) {
+                                                 uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K, uint32_t *sh, uint32_t cap, uint32_t *tmp,
+                                                 uint32_t *__restrict__ hugeq, unsigned int *__restrict__ n_huge) {
     __syncthreads();                                      // (sh is reused from one read to the next)
     const uint32_t P = r_P[r];
+    const bool in_lds = P <= cap;
+    if (!in_lds && hugeq) {
+        if (threadIdx.x == 0) hugeq[atomicAdd(n_huge, 1u)] = r;
+        return;
+    }
     uint32_t *reg = pos + seed_off[r];
-    uint32_t o = 0;
-    for (uint32_t k = 0; k < maxT; k++) {
-        const uint64_t t = (uint64_t)r * maxT + k;
-        const uint32_t cnt = t_cnt[t];
-        if (!cnt) continue;
-        const uint32_t sp = t_sp[t], nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) reg[o + i] = ix.sa[sp - 1 + i] + nadd;
-        o += cnt;
+    uint32_t *a = in_lds ? sh : reg;
+    if (maxT <= 64) {
+        // the tasks' rows first, all at once (a thread per task), then every seed of the read in one sweep: two round trips to memory
+        // per read where a loop over the tasks made two per TASK (12 tasks: ~20 us of a 25 us read)
+        if (threadIdx.x < maxT) {
+            const uint64_t t = (uint64_t)r * maxT + threadIdx.x;
+            const uint32_t cnt = t_cnt[t];
+            tmp[threadIdx.x] = cnt;
+            tmp[64 + threadIdx.x] = t_sp[t];
+            tmp[128 + threadIdx.x] = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < P; i += NT) {
+            uint32_t k = 0, o = 0;
+            for (; k + 1 < maxT && i >= o + tmp[k]; k++) o += tmp[k];
+            a[i] = ix.sa[tmp[64 + k] - 1 + (i - o)] + tmp[128 + k];
+        }
+    } else {
+        uint32_t o = 0;
+        for (uint32_t k = 0; k < maxT; k++) {
+            const uint64_t t = (uint64_t)r * maxT + k;
+            const uint32_t cnt = t_cnt[t];
+            if (!cnt) continue;
+            const uint32_t sp = t_sp[t], nadd = ((t_info[t] >> 8) & 0xff) + (t_def[t] >> 16);
+            for (uint32_t i = threadIdx.x; i < cnt; i += NT) a[o + i] = ix.sa[sp - 1 + i] + nadd;
+            o += cnt;
+        }
     }
     __syncthreads();
-    const bool in_lds = P <= BIG_LDS;
-    uint32_t *a = in_lds ? sh : reg;
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) sh[i] = reg[i];
-        __syncthreads();
-    }
     uint32_t n2 = 1;
     while (n2 < P) n2 <<= 1;
     for (uint32_t k = 2; k <= n2; k <<= 1) {
-        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {      // flip step
+        for (uint32_t i = threadIdx.x; i < P; i += NT) {      // flip step
             uint32_t j = i ^ (k - 1);
             if (j > i && j < P) { uint32_t x = a[i], y = a[j]; if (x > y) { a[i] = y; a[j] = x; } }
         }
         __syncthreads();
         for (uint32_t js = k >> 2; js > 0; js >>= 1) {
-            for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+            for (uint32_t i = threadIdx.x; i < P; i += NT) {
                 uint32_t j = i ^ js;
                 if (j > i && j < P) { uint32_t x = a[i], y = a[j]; if (x > y) { a[i] = y; a[j] = x; } }
             }
             __syncthreads();
         }
     }
+    const uint32_t nthr = 2 + (r_qty[r] & 0x7fffffffu) / 7;
+    if (in_lds) { cluster_runs_block<NT>(a, P, nthr, reg, r_K + r, tmp); return; }
     if (threadIdx.x == 0) {
-        const uint32_t nthr = 2 + (r_qty[r] & 0x7fffffffu) / 7;
         uint32_t K = 0, p1 = a[0], first = a[0], count = 1;
         for (uint32_t i = 1; i <= P; i++) {
             const bool endl = (i == P);
@@ -2041,11 +2120,25 @@ __global__ __launch_bounds__(256) void k_cluster_big(DevIndex ix, uint32_t maxT,
                                                       const uint32_t *__restrict__ r_qty,
                                                       const uint64_t *__restrict__ seed_off,
                                                       uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
-                                                      const unsigned int *__restrict__ nq_dev) {
-    __shared__ uint32_t sh[BIG_LDS];
-    // nq_dev != null: grid-stride over a queue whose length is read on the device
-    for (uint32_t bi = blockIdx.x; bi < (nq_dev ? *nq_dev : gridDim.x); bi += gridDim.x)
-        cluster_big_read(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, sh);
+                                                      const unsigned int *__restrict__ nq_dev, uint32_t nq, uint32_t *__restrict__ hugeq,
+                                                      unsigned int *__restrict__ n_huge) {
+    __shared__ uint32_t sh[BIG_LDS + 256];
+    // grid-stride over the queue (nq_dev != null: its length is read on the device)
+    if (nq_dev) nq = *nq_dev;
+    for (uint32_t bi = blockIdx.x; bi < nq; bi += gridDim.x)
+        cluster_big_read<256>(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, sh, BIG_LDS, sh + BIG_LDS, hugeq, n_huge);
+}
+// the reads k_cluster_big listed: up to HUGE_LDS seeds each in LDS (dynamic: HUGE_LDS + 1024 words), a block of 1024 threads per read
+__global__ __launch_bounds__(1024) void k_cluster_huge(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ hugeq, const unsigned int *__restrict__ n_huge,
+                                                        const uint32_t *__restrict__ t_def, const uint32_t *__restrict__ t_sp,
+                                                        const uint32_t *__restrict__ t_info, const uint32_t *__restrict__ t_cnt,
+                                                        const uint32_t *__restrict__ r_P, const uint32_t *__restrict__ r_qty,
+                                                        const uint64_t *__restrict__ seed_off, uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
+    extern __shared__ uint32_t dyn_huge[];
+    const uint32_t nq = *n_huge;
+    for (uint32_t bi = blockIdx.x; bi < nq; bi += gridDim.x)
+        cluster_big_read<1024>(ix, hugeq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, dyn_huge, HUGE_LDS, dyn_huge + HUGE_LDS,
+                               (uint32_t *)nullptr, (unsigned int *)nullptr);
 }
 // the three queues of reads with more than 64 seeds in ONE launch (the small-batch path: queue lengths read on the device, a
 // launch saved twice): waves take the entries of the 65..128 and 129..256 queues, then blocks those of the workgroup-per-read one
@@ -2055,7 +2148,7 @@ __global__ __launch_bounds__(256) void k_cluster_rest(DevIndex ix, uint32_t maxT
                                                        const uint32_t *__restrict__ t_info, const uint32_t *__restrict__ t_cnt,
                                                        const uint32_t *__restrict__ r_P, const uint32_t *__restrict__ r_qty,
                                                        const uint64_t *__restrict__ seed_off, uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K) {
-    __shared__ uint32_t lds[BIG_LDS];                      // 4 waves x 2 x 256 words for the wave kernels = 2048; BIG_LDS for the block one
+    __shared__ uint32_t lds[BIG_LDS + 256];                // 4 waves x 2 x 256 words for the wave kernels = 2048; BIG_LDS (+ 256 of scan space) for the block one
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n2 = ctr->n_mid2, n4 = ctr->n_mid4, nb = ctr->n_big;
     uint32_t *mine = lds + (threadIdx.x >> 6) * 512;
@@ -2068,7 +2161,8 @@ __global__ __launch_bounds__(256) void k_cluster_rest(DevIndex ix, uint32_t maxT
         __builtin_amdgcn_wave_barrier();
     }
     for (uint32_t bi = blockIdx.x; bi < nb; bi += gridDim.x)
-        cluster_big_read(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds);
+        cluster_big_read<256>(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds, BIG_LDS, lds + BIG_LDS,
+                              (uint32_t *)nullptr, (unsigned int *)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

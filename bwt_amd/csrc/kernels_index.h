@@ -186,5 +186,6 @@ struct Counters {          // device-side work counters (roofline accounting, SU
     unsigned int band0_in, band0_left, band0_next, band0_direct, dq_lo_count;
     // ... and in front of that tier the certificate kernel k_sw_cert: what it could not settle (the 12-diagonal tier's queue then), what it settled
     unsigned int cert_left, cert_done, cert2_in;      // (cert2_in: the queue of its wider instance, candidates with 7..10 mismatches)
+    unsigned int n_huge, pad3_[3];   // reads of more seeds than k_cluster_big's LDS holds, listed by it for k_cluster_huge
 };
 

@@ -5,5 +5,5 @@ for cfg in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$WL', '$cfg', round(d['ms_per_step'],2), 'ms', {k:round(v,2) for k,v in d['kernels_ms_per_step'].items() if v>0.08}, 'handed_back', d['counts_per_step']['n_handed_back'])"
-  grep "handed back" gpurun_out/exp_$WL.err | tail -1
+  grep "handed back\|cluster kernels" gpurun_out/exp_$WL.err | tail -2
 done

@@ -227,6 +227,47 @@ def test_reads_with_hundreds_of_hits():
         ix.close()
 
 
+def test_reads_with_thousands_of_seeds():
+    """The same construction with 5200 copies: a sub-read that dies after 12 matched bases returns 5200 seeds.  Two such sub-reads
+    (10 400 seeds) and the read is past what k_cluster_big sorts in its own LDS (4096 seeds; the reads of the test above, 720 and 2160
+    seeds, are that kernel's): it lists the read for k_cluster_huge (1024 threads, 30 720 seeds in LDS); six of them (31 200 seeds) and
+    that kernel takes its HBM path.  About 5200 hits per read, against the oracle."""
+    from bwt_amd import lib
+    from oracle import orc, erl_literal as E
+    rng = np.random.default_rng(5200)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    g = bytearray(acgt[rng.integers(0, 4, 2_700_000, dtype=np.uint8)].tobytes())
+    unit = bytes(acgt[rng.integers(0, 4, 100, dtype=np.uint8)].tobytes())
+    for k in range(5200):
+        g[1000 + 500 * k:1100 + 500 * k] = unit
+    ref = bytes(g)
+    ix = lib.Index.build(ref, shift=1)
+    ix.set_ktable(15, 1)
+    try:
+        L, SA = ix.export()
+        ptr, shift = ix.meta()
+        ofm = orc.OrcFM.from_L_SA(L, SA, ptr, shift)
+        ref1 = E.make_ref1(ref)
+
+        def sub(q, ps):
+            q = bytearray(q)
+            for p_ in ps:
+                q[p_] = b"ACGT"[(b"ACGT".index(q[p_]) + 1 + p_ % 3) & 3]
+            return bytes(q)
+        reads = [sub(unit, (87, 71)), sub(unit, (87, 71, 55, 39, 23, 7)), sub(unit, (87, 55, 23))]
+        reads += synth_reads(ref, 100, 100, 13, max_subs=2)
+        b = lib.Batch(ix)
+        b.set_reads(*lib.pack_reads(reads))
+        b.run(lib.STAGE_EXTEND)
+        out = b.fetch_hits()
+        b.destroy()
+        nh = np.diff(out["hit_off"].astype(np.int64))
+        assert nh[0] > 5000 and nh[1] > 5000 and nh[2] > 5000, nh[:3]
+        assert oracle_check(out, reads, ofm, ref1) > 3 * 5000
+    finally:
+        ix.close()
+
+
 def test_pipe_packs_a_batch_that_is_mostly_exceptions(gpu_index, orc_fm, ref_bytes):
     """bwt_pipe_submit_ascii on a batch whose exception list outgrows the slot's buffer (reads that are mostly N): the slot's thread
     grows the pinned buffer and packs again; the answers are still the oracle's."""
