@@ -1176,7 +1176,7 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         const size_t huge_lds = (size_t)(HUGE_LDS + 1024) * 4;
         HIPCHK(hipFuncSetAttribute((const void *)k_cluster_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)huge_lds));
         {
-            ProfScope ps(b, "cluster_big");
+            ProfScope ps(b, "cluster_huge");
             hipLaunchKernelGGL(k_cluster_huge, dim3(std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus)), dim3(1024), huge_lds, b->stream, b->ix->d, maxT,
                                (const uint32_t *)b->hugeq.as<uint32_t>(), (const unsigned int *)&dc->n_huge, (const uint32_t *)b->t_def.as<uint32_t>(),
                                (const uint32_t *)b->t_sp.as<uint32_t>(), (const uint32_t *)b->t_info.as<uint32_t>(), (const uint32_t *)b->t_cnt.as<uint32_t>(),
@@ -1689,8 +1689,8 @@ extern "C" int bwt_batch_run(bwt_batch *b, int stages, bwt_batch_counts *counts)
         fprintf(stderr, "[libbwtgpu] k_seed_fast handed back %u reads: non-ACGT %u, table overflow %u, more seeds than its row holds %u, >%d clusters %u\n",
                 b->hctr.n_gq, b->hctr.why[0], b->hctr.why[1], b->hctr.why[4], CL_STAGE, b->hctr.why[5]);
     if (b->opt.debug > 0)
-        fprintf(stderr, "[libbwtgpu] cluster kernels: %u reads of 1..64 seeds, %u of 65..128, %u of 129..256, %u of more; certificate kernels: %u settled, %u "
-                        "passed to their wider instance, %u to the 12-diagonal tier\n", b->n_small, b->hctr.n_mid2, b->hctr.n_mid4, b->hctr.n_big,
+        fprintf(stderr, "[libbwtgpu] cluster kernels: %u reads of 1..64 seeds, %u of 65..128, %u of 129..256, %u of more (%u of them past k_cluster_big's LDS); certificate kernels: %u settled, %u "
+                        "passed to their wider instance, %u to the 12-diagonal tier\n", b->n_small, b->hctr.n_mid2, b->hctr.n_mid4, b->hctr.n_big, b->hctr.n_huge,
                 b->hctr.cert_done, b->hctr.cert2_in, b->hctr.cert_left);
     if (counts) {
         counts->n_reads = b->n; counts->n_tasks = b->hctr.n_tasks; counts->lf_steps = b->hctr.lf_steps;

@@ -3242,7 +3242,8 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 // settled there -- not eligible, or run here with a best score below the next tier's own threshold: a wider band only adds paths, so
 // its best score is at least this one, but for the substitution-rich candidates that fail here it is the same diagonal again --
 // goes to skip_q / skip_ctr instead (the queue of the tier after the next), and the next tier does not compute it in vain.
-#define SWB_WAVES(B) ((B) > 24 ? 3 : 4)
+#define SWB_WAVES(B) ((B) > 48 ? 2 : (B) > 24 ? 3 : 4)      // (least waves per SIMD asked of the compiler; 64 diagonals: 2..3 -- held to exactly three it spilled 68
+                                                            // registers into scratch at 168 VGPRs; given the range it takes 162 and still runs three)
 #define SWB_RB(B) ((B) > 32 ? 4 : 8)      // rows of directions a traceback stages in LDS at a time (B / 8 words per row and lane)
 // is a candidate one a tier of BB diagonals runs?  (x: its band offset there)
 template <int BB>
@@ -3253,7 +3254,7 @@ __device__ __forceinline__ bool swb_eligible(const SwIO &io, uint32_t lq, uint32
            (uint64_t)wo + w <= io.rbuf_len;
 }
 template <int B, int NEXT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWB_WAVES(B), SWB_WAVES(B))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWB_WAVES(B), (B) > 48 ? 3 : SWB_WAVES(B))))
 void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *__restrict__ in_count, const uint32_t *__restrict__ in_q2,
                const unsigned int *__restrict__ in_count2, uint32_t *__restrict__ rest, unsigned int *__restrict__ ctl,
                uint32_t *__restrict__ skip_q, unsigned int *__restrict__ skip_ctr, uint32_t *__restrict__ slab, uint32_t slab_rows,
