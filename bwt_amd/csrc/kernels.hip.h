@@ -3160,27 +3160,40 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
             uint8_t *slot = io.cig + (uint64_t)c * io.cig_stride;
             int p = (int)io.cig_stride, len = 0;
             if (TRACE) {
-                // traceback (sw.erl:116-160) from the leftmost maximum of the last row up to row 0
+                // traceback (sw.erl:116-160) from the leftmost maximum of the last row up to row 0.  A step's direction word sits in the
+                // slab (one word per column and 8 rows: a diagonal step needs a new one every time), and the step before decides which:
+                // a dependent HBM load per step was most of this kernel's time on short queues (220 steps x ~1.5 us against 0.2 ms of DP
+                // per wave).  So the words of the next eight DIAGONAL steps are asked for together -- most of a traceback is diagonal
+                // runs -- and used as long as the walk stays on the diagonal; the first other step starts a new batch.
                 uint32_t i = LQ, j = bestj;
                 int runop = -1; uint32_t runlen = 0;
-                for (;;) {
-                    int code = -1;
-                    if (i > 0) {
-                        if (j == 0) code = DIR_UP;
-                        else {
-                            const uint32_t t = i - 1, grp = t >> 3;
-                            const uint32_t rows = (grp == (uint32_t)(NDG - 1)) ? (uint32_t)(LQ - 8 * (NDG - 1)) : 8u;
-                            const uint32_t wd = dirs[((uint64_t)j * NDG + grp) * 64];
-                            code = (int)((wd >> (16 * h + 2 * (rows - 1 - (t & 7)))) & 3u);
+                bool walking = true;
+                while (walking) {
+                    uint32_t wd[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const bool in = i > (uint32_t)k && j > (uint32_t)k;
+                        wd[k] = in ? dirs[((uint64_t)(j - k) * NDG + ((i - 1 - k) >> 3)) * 64] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        int code = -1;
+                        if (i > 0) {
+                            if (j == 0) code = DIR_UP;
+                            else {
+                                const uint32_t t = i - 1, grp = t >> 3;
+                                const uint32_t rows = (grp == (uint32_t)(NDG - 1)) ? (uint32_t)(LQ - 8 * (NDG - 1)) : 8u;
+                                code = (int)((wd[k] >> (16 * h + 2 * (rows - 1 - (t & 7)))) & 3u);
+                            }
                         }
+                        if (code == runop) { runlen++; }
+                        else {
+                            if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
+                            runop = code; runlen = 1;
+                        }
+                        if (code < 0) { walking = false; break; }
+                        if (code == DIR_UL) { i--; j--; } else { if (code == DIR_UP) i--; else j--; break; }
                     }
-                    if (code == runop) { runlen++; }
-                    else {
-                        if (runop >= 0) cig_emit(slot, p, len, runlen, runop == DIR_UL ? 'M' : runop == DIR_UP ? 'I' : 'D');
-                        runop = code; runlen = 1;
-                    }
-                    if (code < 0) break;
-                    if (code == DIR_UL) { i--; j--; } else if (code == DIR_UP) i--; else j--;
                 }
                 io.c_score[c] = score;
                 io.c_ciglen[c] = (uint32_t)len;
