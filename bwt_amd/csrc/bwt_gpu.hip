@@ -1339,9 +1339,9 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
         const uint64_t cap_blocks = (1ull << 30) / ((uint64_t)4 * rows * 4 * 64 * 4);
         const uint32_t blocks1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 4), cap_blocks));
         const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(nc, 512), (uint64_t)dev_cus * 3), cap_blocks));
-        const uint32_t blocks3 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks2, cap_blocks / 2));
+        const uint32_t blocks3 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks2, cap_blocks * 4 / ((SWB_B3 + 7) / 8)));
         if ((rc = b->bq.ensure(nc * 4 + 4)) || (rc = b->bq2.ensure(nc * 4 + 4)) || (rc = b->bq3.ensure(nc * 4 + 4)) ||
-            (rc = b->slab_band.ensure(std::max<uint64_t>((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4, (uint64_t)blocks3 * 4 * rows * 8 * 64 * 4))))
+            (rc = b->slab_band.ensure(std::max<uint64_t>((uint64_t)std::max(blocks1, blocks2) * 4 * rows * 4 * 64 * 4, (uint64_t)blocks3 * 4 * rows * ((SWB_B3 + 7) / 8) * 64 * 4))))
             return rc;
         Counters *dc = b->ctr.as<Counters>();
         // the 12-diagonal tier's queue: the prefilter's dq_lo -- after the certificate kernel has taken out of it what needs no DP at
@@ -1390,7 +1390,7 @@ static int run_sw(bwt_batch *b, const uint8_t *qbuf, const uint8_t *rbuf, uint64
                                (unsigned int *)nullptr, b->slab_band.as<uint32_t>(), rows, band_min);
             // (the first tier's output queue is free again: the third tier passes on into it; bwt_options.sw_band = 2 makes it
             // pass everything on -- the two-tier path, for comparisons)
-            hipLaunchKernelGGL((k_sw_band<64, 0>), dim3(blocks3), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq2.as<uint32_t>(),
+            hipLaunchKernelGGL((k_sw_band<SWB_B3, 0>), dim3(blocks3), dim3(256), 0, b->stream, io, (const uint32_t *)b->bq2.as<uint32_t>(),
                                (const unsigned int *)&dc->band2_left, (const uint32_t *)b->bq3.as<uint32_t>(), (const unsigned int *)&dc->band_direct,
                                b->bq.as<uint32_t>(), &dc->band3_in, (uint32_t *)nullptr, (unsigned int *)nullptr, b->slab_band.as<uint32_t>(), rows,
                                b->opt.sw_band == 2 ? 0xffffffffu : band_min);

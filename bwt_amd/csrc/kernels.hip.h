@@ -3243,6 +3243,8 @@ __global__ __launch_bounds__(256) void k_sw_pk(SwIO io, uint32_t n_items, uint32
 // those of the full table, and every row's maximum stays above the early-exit threshold of sw.erl:69 (3x + 3 <= 2 (Lq div 2)
 // is checked).  Candidates that are not eligible or whose S* is lower go on to the full-rectangle kernels untouched.
 #define SWB_XMIN 3
+#define SWB_B3 64                  // diagonals of the third tier (72 would settle every square window of a 100-base read, no_match included -- see the settle
+                                   // step -- but needs 172 VGPRs: two waves per SIMD, 6.0 ms where 64 diagonals take 4.0 on the repeat-rich batch; measured, round 4)
 #define SWB_MAX_LQ 1500            // 8 V + code of both candidates of a lane in 16 bits each
 // Two candidates per lane (low / high 16 bits of every register, the cell algebra of k_sw_pk): they share the row loop and
 // the cell index k, each has its own band offset x, window and last row.
@@ -3263,8 +3265,9 @@ template <int BB>
 __device__ __forceinline__ bool swb_eligible(const SwIO &io, uint32_t lq, uint32_t w, int64_t wo, uint32_t slab_rows, int &x) {
     const int D = (int)w - (int)lq;
     x = (BB - 1 - D) >> 1;
-    return D >= 0 && D <= BB - 1 - 2 * SWB_XMIN && lq >= 2 && lq < slab_rows && lq <= SWB_MAX_LQ && 3 * x + 3 <= 2 * (int)(lq / 2) && wo >= 32 &&
-           (uint64_t)wo + w <= io.rbuf_len;
+    // (round 4: no "3 x + 3 <= 2 (Lq div 2)" here any more -- the kernel compares its best score with the abort threshold of sw.erl:62,69
+    // itself, see the settle step; wo >= 64: the band's first cell lies x <= 35 bases in front of the window)
+    return D >= 0 && D <= BB - 1 - 2 * SWB_XMIN && lq >= 2 && lq < slab_rows && lq <= SWB_MAX_LQ && wo >= 64 && (uint64_t)wo + w <= io.rbuf_len;
 }
 template <int B, int NEXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWB_WAVES(B), (B) > 48 ? 3 : SWB_WAVES(B))))
@@ -3272,7 +3275,7 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
                const unsigned int *__restrict__ in_count2, uint32_t *__restrict__ rest, unsigned int *__restrict__ ctl,
                uint32_t *__restrict__ skip_q, unsigned int *__restrict__ skip_ctr, uint32_t *__restrict__ slab, uint32_t slab_rows,
                uint32_t skip_upto) {
-    static_assert(B >= 12 && B <= 64, "one or two match words per row");
+    static_assert(B >= 12 && B <= 96, "one to three match words per row");
     constexpr int XMAX = (B - 1) / 2, NDW = (B + 7) / 8, NW = (B + 31) / 32;     // NW: 32-cell match words of a row
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -3417,13 +3420,22 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
             }
             // tracebacks (sw.erl:116-160) of the candidates the certificate covers, both of the lane side by side: the directions
             // come back from the slab RB rows at a time (one round trip per RB rows instead of one per step), parked in LDS
-            bool tr[2];
+            bool tr[2], nomatch[2];
             uint32_t ti[2];
             int tk[2], trun[2] = {-1, -1}, tp[2], tlen[2] = {0, 0};
             uint32_t trl[2] = {0, 0};
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                tr[h] = run[h] && best[h] >= 2 * (int)lq[h] - 3 * x[h] - 3;
+                // Certificate: best >= 2 Lq - 3 x - 3 -- the banded maximum is the full table's.  It is a hit when it also reaches the
+                // abort threshold of sw.erl:62,69 (then no row's maximum on the way fell below its own threshold either: a traceback cell
+                // in row r holds >= best - 2 (Lq - r)).  Below the threshold the answer is no_match -- and so it is, without the
+                // certificate, whenever best AND everything the band cannot see (last-row cells outside it and band cells reached from
+                // outside: all <= 2 Lq - 3 x - 4) lie below the threshold: a 72-diagonal band on a square window of a 100-base
+                // read (x = 35: 91 < 100) settles EVERY candidate, hit or not, and nothing of it is left for the full rectangle.
+                const int thr_nm = 2 * (int)lq[h] - 2 * (int)(lq[h] / 2), zmax = 2 * (int)lq[h] - 3 * x[h] - 4;
+                const bool cert = run[h] && best[h] > zmax;
+                tr[h] = cert && best[h] >= thr_nm;
+                nomatch[h] = run[h] && best[h] < thr_nm && (cert || zmax < thr_nm);
                 ti[h] = tr[h] ? lq[h] : 0; tk[h] = kb[h]; tp[h] = (int)io.cig_stride;
             }
             const uint32_t top = ti[0] > ti[1] ? ti[0] : ti[1];
@@ -3480,6 +3492,9 @@ void k_sw_band(SwIO io, const uint32_t *__restrict__ in_q, const unsigned int *_
                     io.c_score[c[h]] = best[h];
                     io.c_ciglen[c[h]] = (uint32_t)tlen[h];
                     io.c_status[c[h]] = tlen[h] > (int)io.cig_stride ? CS_CIG_OVERFLOW : CS_OK;
+                    settled[h] = true;
+                } else if (nomatch[h]) {
+                    io.c_status[c[h]] = CS_NO_MATCH; io.c_ciglen[c[h]] = 0;
                     settled[h] = true;
                 }
         }
