@@ -1169,10 +1169,15 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
         Counters *dc = b->ctr.as<Counters>();
-        KLAUNCH(b, "cluster_big", k_cluster_big, std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus * 8), 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
+        if (maxT <= 64)
+            KLAUNCH(b, "cluster_big", (k_cluster_big<64, 1024>), std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus * 32), 64, b->ix->d, maxT, b->bigq.as<uint32_t>(),
+                    b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
+                    b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
+                    b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, b->hctr.n_big, (uint32_t *)nullptr, (unsigned int *)nullptr, 0u, 1024u);
+        KLAUNCH(b, "cluster_big", (k_cluster_big<256, BIG_LDS>), std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus * 8), 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                 b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
-                b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, b->hctr.n_big, b->hugeq.as<uint32_t>(), &dc->n_huge);
+                b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, b->hctr.n_big, b->hugeq.as<uint32_t>(), &dc->n_huge, maxT <= 64 ? 1024u : 0u, 0xffffffffu);
         const size_t huge_lds = (size_t)(HUGE_LDS + 1024) * 4;
         HIPCHK(hipFuncSetAttribute((const void *)k_cluster_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)huge_lds));
         {

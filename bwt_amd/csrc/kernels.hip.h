@@ -1971,6 +1971,8 @@ __global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, 
 }
 
 // k_cluster_big: workgroup per read (P > 256): gather, sort (ascending-only bitonic network: virtual +inf padding past P), cluster.
+// Two instances: ONE WAVE per read for up to 1024 seeds (no barrier between the sort's stages, 5 KB of LDS: 32 reads per CU in flight
+// where blocks of 256 threads -- most of them idle on 300..550 seeds -- held 8), 256 threads per read for more.
 // Round 4: (i) the seeds are gathered straight into LDS and stay there; (ii) the runs are found by the whole block -- a thread takes
 // a stretch of the sorted list, two block scans carry the last run start and the number of clusters across stretches -- where
 // one thread walked the P elements (20 us for 500 seeds: most of a read's time); (iii) a read of more seeds than this kernel's LDS
@@ -2111,22 +2113,27 @@ __device__ __forceinline__ void cluster_big_read(const DevIndex &ix, uint32_t r,
         r_K[r] = K;
     }
 }
-__global__ __launch_bounds__(256) void k_cluster_big(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ bigq,
-                                                      const uint32_t *__restrict__ t_def,
-                                                      const uint32_t *__restrict__ t_sp,
-                                                      const uint32_t *__restrict__ t_info,
-                                                      const uint32_t *__restrict__ t_cnt,
-                                                      const uint32_t *__restrict__ r_P,
-                                                      const uint32_t *__restrict__ r_qty,
-                                                      const uint64_t *__restrict__ seed_off,
-                                                      uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
-                                                      const unsigned int *__restrict__ nq_dev, uint32_t nq, uint32_t *__restrict__ hugeq,
-                                                      unsigned int *__restrict__ n_huge) {
-    __shared__ uint32_t sh[BIG_LDS + 256];
+// lo / hi: the kernel takes the reads of its queue with lo < P <= hi seeds (the others are another launch's)
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void k_cluster_big(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ bigq,
+                                                     const uint32_t *__restrict__ t_def,
+                                                     const uint32_t *__restrict__ t_sp,
+                                                     const uint32_t *__restrict__ t_info,
+                                                     const uint32_t *__restrict__ t_cnt,
+                                                     const uint32_t *__restrict__ r_P,
+                                                     const uint32_t *__restrict__ r_qty,
+                                                     const uint64_t *__restrict__ seed_off,
+                                                     uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
+                                                     const unsigned int *__restrict__ nq_dev, uint32_t nq, uint32_t *__restrict__ hugeq,
+                                                     unsigned int *__restrict__ n_huge, uint32_t lo, uint32_t hi) {
+    __shared__ uint32_t sh[CAP + 256];
     // grid-stride over the queue (nq_dev != null: its length is read on the device)
     if (nq_dev) nq = *nq_dev;
-    for (uint32_t bi = blockIdx.x; bi < nq; bi += gridDim.x)
-        cluster_big_read<256>(ix, bigq[bi], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, sh, BIG_LDS, sh + BIG_LDS, hugeq, n_huge);
+    for (uint32_t bi = blockIdx.x; bi < nq; bi += gridDim.x) {
+        const uint32_t r = bigq[bi], P = r_P[r];
+        if (P <= lo || P > hi) continue;
+        cluster_big_read<NT>(ix, r, maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, sh, CAP, sh + CAP, hugeq, n_huge);
+    }
 }
 // the reads k_cluster_big listed: up to HUGE_LDS seeds each in LDS (dynamic: HUGE_LDS + 1024 words), a block of 1024 threads per read
 __global__ __launch_bounds__(1024) void k_cluster_huge(DevIndex ix, uint32_t maxT, const uint32_t *__restrict__ hugeq, const unsigned int *__restrict__ n_huge,
