@@ -98,7 +98,7 @@ def main():
            "compared": "per-read digest of the complete hit list (score, pos, window offset and length, CIGAR text, list order); GPU side: packed upload (%d exceptions), narrow hit table (%d narrow reads, %d records, %d extras), expanded on the host; suffix-interval table K = %d, lower levels kept wide %s; head %s" % (len(exc), len(comp["narrow_off"]), len(comp["hits"]), len(comp["extra"]), ix.ktable[0], ix.ktable_wide_levels, os.environ.get("BWT_HEAD", "?")),
            "reads": n, "reads_with_hits": int((np.diff(hits["hit_off"].astype(np.int64)) > 0).sum()), "hits": int(c["n_hits"]),
            "reads_status_minus1": int((hits["read_status"] == -1).sum()), "dp_candidates": int(c["n_dp"]), "fp64_candidates": int(c["n_float"]),
-           "handed_back_reads": int(c["n_handed_back"]), "banded": int(c.get("n_banded", 0)), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
+           "handed_back_reads": int(c["n_handed_back"]), "banded": int(c.get("n_banded", 0)), "certified_without_dp": int(c.get("n_certified", 0)), "mismatching_reads": int(len(bad)), "first_mismatches": bad[:10].tolist(),
            "gpu_s": t_gpu, "cpu_s": t_cpu, "cpu_threads": cores}
     print(json.dumps(out))
     batch.destroy(); ix.close()
