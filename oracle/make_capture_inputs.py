@@ -140,6 +140,28 @@ def main():
         lq = [100, 150, 36][i % 3]
         out.append("line read.%d/1 GL000193.1 %d %s %d %s" % (i, int(rng.integers(-150, 189000)), ["%dM" % lq, "50M2D%dM" % (lq - 50), "3M1I%dM" % (lq - 4)][i % 3],
                                                             int(rng.integers(100, 301)), bytes(rng.choice(list(b"ACGTN"), lq + i % 4).tolist()).decode()))
+    # ---- round 4: sw:sw/2 on SQUARE windows whose diagonal has 3..10 mismatches -- what the certificate kernel (bwt_amd/csrc/sw_cert.h)
+    # settles without filling the table: spread and clumped substitutions, read ends, periodic sequences (neighbouring diagonals match)
+    rng4 = np.random.default_rng(4004)
+    for i in range(240):
+        lq = int(rng4.choice([100, 100, 150, 64, 33, 128]))
+        if i % 4 == 3:
+            unit = bytes(rng4.choice(alpha, int(rng4.integers(1, 8))).tolist())
+            r = bytearray((unit * (lq // len(unit) + 2))[:lq])
+            for _ in range(int(rng4.integers(0, 4))):
+                r[int(rng4.integers(0, lq))] = int(rng4.choice(alpha))
+        else:
+            r = bytearray(rng4.choice(alpha, lq).tolist())
+        q = bytearray(r)
+        m = int(rng4.integers(3, 11))
+        if i % 4 == 1:
+            c0 = [0, lq - 13, int(rng4.integers(0, lq - 12))][i % 3]
+            ps = c0 + rng4.choice(12, m, replace=False)
+        else:
+            ps = rng4.choice(lq, m, replace=False)
+        for p_ in ps:
+            q[int(p_)] = int(rng4.choice([x for x in alpha if x != q[int(p_)]]))
+        out.append("sw %s %s" % (q.decode(), bytes(r).decode()))
     path = os.path.join(ROOT, "tests", "golden", "erlang", "capture_inputs.txt")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
