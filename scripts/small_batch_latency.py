@@ -14,6 +14,8 @@ from bwt_amd import lib     # noqa: E402
 
 g = os.path.join(ROOT, "tests", "golden", "fm_indices", "GL000193.1_p1")
 ix = lib.Index.open(g + ".fm", g + ".ref")
+if len(sys.argv) > 1:                       # "15,1": the suffix-interval table at K = 15 with a wide top level instead of the index's default
+    ix.set_ktable(*[int(x) for x in sys.argv[1].split(",")])
 ref = np.frombuffer(open(g + ".ref", "rb").read(), np.uint8)
 rng = np.random.default_rng(1)
 out = {"index": "bundled GL000193.1_p1 (K = %d, wide = %s)" % ix.ktable, "sizes": {}}
