@@ -2573,8 +2573,10 @@ struct CandSrc {
 // twelve has a dozen or more clusters, three waves in four hold such a read, and the other fifteen quads idle through its loop
 // (8.8 ms for 29 M candidates where 12 M take 1.0 ms).  So the fused pass tests at most PF_KCAP candidates per read; the others
 // get their descriptors written (four per quad step, stores only) and go into a list that a second launch works through with
-// a quad per candidate.
-#define PF_KCAP 2u
+// a quad per candidate.  (Two per read until the queues took their space 256 entries per atomic: while the list's one atomic per 64
+// entries bound the kernel, a longer list cost more than the idle quads of a second turn -- 5.76 against 5.40 ms; since then ONE per
+// read is better, 2.91 against 3.46 ms on the repeat-rich batch, the same on batches of one cluster per read.)
+#define PF_KCAP 1u
 // (Held to more waves per SIMD -- 6: 80 VGPRs, 8: 64 VGPRs, a few dwords of scratch each -- the kernel is slower: 1.12 / 1.55 ms
 // against 1.01 at the compiler's own 91 VGPRs and 5 waves, although it waits on dependent loads ~80 % of its time.)
 template <bool FROM_READS>

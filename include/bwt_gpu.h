@@ -84,7 +84,7 @@ typedef struct {
                                    runs the banded DP; 2: only its 11-diagonal instance (square windows with up to 6 mismatches), not the
                                    19-diagonal one (7..10) */
     int32_t pf_kcap;            /* candidates of a read the fused prefilter pass tests itself before it lists the rest for the quad-per-candidate
-                                   pass (default 2; 0: it lists them all) */
+                                   pass (default 1; 0: it lists them all) */
 } bwt_options;
 void bwt_options_init(bwt_options *o);
 
