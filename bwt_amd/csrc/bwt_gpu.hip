@@ -1157,23 +1157,29 @@ static int stage_cluster(bwt_batch *b, bool to_extend) {
         KLAUNCH(b, "cluster_wave2", k_cluster_wave<2>, cdiv((uint64_t)b->hctr.n_mid2 * 64, 256), 256, b->ix->d, b->hctr.n_mid2,
                 b->mid2q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
-                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
+                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, 0u, 0xffffffffu);
     if (b->hctr.n_mid4)
         KLAUNCH(b, "cluster_wave4", k_cluster_wave<4>, cdiv((uint64_t)b->hctr.n_mid4 * 64, 256), 256, b->ix->d, b->hctr.n_mid4,
                 b->mid4q.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
                 b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
-                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr);
+                b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, 0u, 0xffffffffu);
     if (b->hctr.n_big) {
         // a block per read; a read of more seeds than its LDS holds is listed for k_cluster_huge (1024 threads, 124 KB of LDS per read)
         if ((rc = b->hugeq.ensure((size_t)b->hctr.n_big * 4 + 4))) return rc;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
         Counters *dc = b->ctr.as<Counters>();
-        if (maxT <= 64)
-            KLAUNCH(b, "cluster_big", (k_cluster_big<64, 1024>), std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus * 32), 64, b->ix->d, maxT, b->bigq.as<uint32_t>(),
-                    b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
-                    b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),
-                    b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, b->hctr.n_big, (uint32_t *)nullptr, (unsigned int *)nullptr, 0u, 1024u);
+        if (maxT <= 64) {
+            // up to 1024 seeds: a wave per read, sorted in registers (8 / 16 elements per lane)
+            KLAUNCH(b, "cluster_big", k_cluster_wave<8>, cdiv((uint64_t)b->hctr.n_big * 64, 256), 256, b->ix->d, b->hctr.n_big,
+                    b->bigq.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
+                    b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
+                    b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, 256u, 512u);
+            KLAUNCH(b, "cluster_big", k_cluster_wave<16>, cdiv((uint64_t)b->hctr.n_big * 64, 256), 256, b->ix->d, b->hctr.n_big,
+                    b->bigq.as<uint32_t>(), maxT, b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(),
+                    b->t_cnt.as<uint32_t>(), b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(),
+                    b->pos.as<uint32_t>(), b->r_K.as<uint32_t>(), (const unsigned int *)nullptr, 512u, 1024u);
+        }
         KLAUNCH(b, "cluster_big", (k_cluster_big<256, BIG_LDS>), std::min<uint32_t>(b->hctr.n_big, (uint32_t)cus * 8), 256, b->ix->d, maxT, b->bigq.as<uint32_t>(),
                 b->t_def.as<uint32_t>(), b->t_sp.as<uint32_t>(), b->t_info.as<uint32_t>(), b->t_cnt.as<uint32_t>(),
                 b->r_P.as<uint32_t>(), b->r_qty.as<uint32_t>(), b->seed_off.as<uint64_t>(), b->pos.as<uint32_t>(),

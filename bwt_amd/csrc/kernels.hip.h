@@ -1961,13 +1961,17 @@ __global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, 
                                                        const uint32_t *__restrict__ r_qty,
                                                        const uint64_t *__restrict__ seed_off,
                                                        uint32_t *__restrict__ pos, uint32_t *__restrict__ r_K,
-                                                       const unsigned int *__restrict__ nq_dev) {
+                                                       const unsigned int *__restrict__ nq_dev, uint32_t lo, uint32_t hi) {
     // nq_dev != null: the queue length is read on the device (nq = the most the queue can hold)
+    // lo / hi: the launch takes the reads of its queue with lo < P <= hi seeds (R = 8, 16 on the queue of reads past 256 seeds: a wave
+    // per read and the sort in registers up to 1024 seeds -- 0.83 ms as one wave per read sorting in LDS, round 4)
     __shared__ uint32_t lds[4][2 * 64 * R];
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (nq_dev) nq = *nq_dev;
     if (w >= nq) return;
-    cluster_wave_read<R>(ix, queue[w], maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds[threadIdx.x >> 6]);
+    const uint32_t r = queue[w], P = r_P[r];
+    if (P <= lo || P > hi) return;
+    cluster_wave_read<R>(ix, r, maxT, t_def, t_sp, t_info, t_cnt, r_P, r_qty, seed_off, pos, r_K, lds[threadIdx.x >> 6]);
 }
 
 // k_cluster_big: workgroup per read (P > 256): gather, sort (ascending-only bitonic network: virtual +inf padding past P), cluster.
