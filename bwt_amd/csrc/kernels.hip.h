@@ -1975,8 +1975,10 @@ __global__ __launch_bounds__(256) void k_cluster_wave(DevIndex ix, uint32_t nq, 
 }
 
 // k_cluster_big: workgroup per read (P > 256): gather, sort (ascending-only bitonic network: virtual +inf padding past P), cluster.
-// Two instances: ONE WAVE per read for up to 1024 seeds (no barrier between the sort's stages, 5 KB of LDS: 32 reads per CU in flight
-// where blocks of 256 threads -- most of them idle on 300..550 seeds -- held 8), 256 threads per read for more.
+// (Reads of up to 1024 seeds are k_cluster_wave<8 | 16>'s, launched on the same queue with a seed-count filter: a wave per read, sorted in
+// registers.  Tried between the two: this kernel as ONE WAVE per read -- NT = 64, no barrier between the sort's stages, 5 KB of LDS, 32
+// reads per CU in flight where blocks of 256 threads, most of them idle on 300..550 seeds, held 8 -- 0.92 ms against 1.38; the register
+// sort takes 0.32.  NT stays a parameter.)
 // Round 4: (i) the seeds are gathered straight into LDS and stay there; (ii) the runs are found by the whole block -- a thread takes
 // a stretch of the sorted list, two block scans carry the last run start and the number of clusters across stretches -- where
 // one thread walked the P elements (20 us for 500 seeds: most of a read's time); (iii) a read of more seeds than this kernel's LDS
