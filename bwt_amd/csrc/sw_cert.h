@@ -65,28 +65,37 @@ template <int X, int NW>
 SWC_HD bool sw_diag_cert(const uint32_t (&qlo)[NW], const uint32_t (&qhi)[NW], const uint32_t (&rlo)[NW + 2],
                          const uint32_t (&rhi)[NW + 2], int L, int &m_out, int *g_out = nullptr) {
     constexpr int ND = 2 * X + 1;
-    uint32_t E[ND][NW];                  // E[X + o][w]: rows where diagonal o matches
-    uint32_t vm[NW];
+    constexpr int NQ = (NW + 1) / 2;      // the masks as 64-bit words: the loop below runs per word and, on the GPU, as long as the lane of
+                                          // its wave with the most mismatch rows in that word -- half as many words, fewer idle turns
+    uint64_t E[ND][NQ];                   // E[X + o][q]: rows where diagonal o matches
+    uint64_t vm[NQ];
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-        const int left = L - 32 * w;
-        vm[w] = left >= 32 ? 0xffffffffu : left <= 0 ? 0u : (1u << left) - 1u;
+    for (int q = 0; q < NQ; q++) {
+        const int left = L - 64 * q;
+        vm[q] = left >= 64 ? ~0ull : left <= 0 ? 0ull : (1ull << left) - 1ull;
     }
 #pragma unroll
     for (int d = 0; d < ND; d++) {
         const int o = d - X;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            uint32_t xl, xh;
-            if (o == 0) { xl = rlo[w + 1]; xh = rhi[w + 1]; }
-            else if (o > 0) { xl = swc_funnel(rlo[w + 2], rlo[w + 1], (uint32_t)o); xh = swc_funnel(rhi[w + 2], rhi[w + 1], (uint32_t)o); }
-            else { xl = swc_funnel(rlo[w + 1], rlo[w], (uint32_t)(32 + o)); xh = swc_funnel(rhi[w + 1], rhi[w], (uint32_t)(32 + o)); }
-            E[d][w] = ~((qlo[w] ^ xl) | (qhi[w] ^ xh));
+        for (int q = 0; q < NQ; q++) {
+            uint64_t e = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int w = 2 * q + h;
+                if (w >= NW) continue;
+                uint32_t xl, xh;
+                if (o == 0) { xl = rlo[w + 1]; xh = rhi[w + 1]; }
+                else if (o > 0) { xl = swc_funnel(rlo[w + 2], rlo[w + 1], (uint32_t)o); xh = swc_funnel(rhi[w + 2], rhi[w + 1], (uint32_t)o); }
+                else { xl = swc_funnel(rlo[w + 1], rlo[w], (uint32_t)(32 + o)); xh = swc_funnel(rhi[w + 1], rhi[w], (uint32_t)(32 + o)); }
+                e |= (uint64_t)(uint32_t)~((qlo[w] ^ xl) | (qhi[w] ^ xh)) << (32 * h);
+            }
+            E[d][q] = e;
         }
     }
     int m = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) m += __builtin_popcount(~E[X][w] & vm[w]);
+    for (int q = 0; q < NQ; q++) m += __builtin_popcountll(~E[X][q] & vm[q]);
     m_out = m;
     if (m > X + 1 || 3 * m > 2 * (L / 2)) return false;
 
@@ -115,30 +124,32 @@ SWC_HD bool sw_diag_cert(const uint32_t (&qlo)[NW], const uint32_t (&qhi)[NW], c
     };
 
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-        uint32_t rem = vm[w];
-        uint32_t mw = ~E[X][w] & vm[w];
+    for (int q = 0; q < NQ; q++) {
+        uint64_t rem = vm[q];
+        uint64_t mw = ~E[X][q] & vm[q];
         while (mw) {
-            const uint32_t b = (uint32_t)__builtin_ctz(mw);
-            mw &= mw - 1u;
-            const uint32_t seg = rem & ((1u << b) - 1u);
+            const uint32_t b = (uint32_t)__builtin_ctzll(mw);
+            mw &= mw - 1ull;
+            const uint64_t seg = rem & ((1ull << b) - 1ull);
 #pragma unroll
-            for (int d = 0; d < ND; d++) acc[d] += __builtin_popcount(~E[d][w] & seg);
-            nrows += __builtin_popcount(seg);
+            for (int d = 0; d < ND; d++)
+                if (d != X) acc[d] += __builtin_popcountll(~E[d][q] & seg);
+            nrows += __builtin_popcountll(seg);
             stretch();
             // the mismatch row itself
 #pragma unroll
             for (int d = 0; d < ND; d++) {
                 const int t = d + 1 < ND ? swc_max(g[d + 1] - 1, gu[d + 1]) : SWC_NEG;
-                const int sv = d == X ? 0 : (int)((E[d][w] >> b) & 1u) * 3;
+                const int sv = d == X ? 0 : (int)((E[d][q] >> b) & 1ull) * 3;
                 g[d] = swc_max(g[d] + sv, t);
                 gu[d] = t;
             }
-            rem &= ~((2u << b) - 1u);
+            rem &= ~((2ull << b) - 1ull);
         }
 #pragma unroll
-        for (int d = 0; d < ND; d++) acc[d] += __builtin_popcount(~E[d][w] & rem);
-        nrows += __builtin_popcount(rem);
+        for (int d = 0; d < ND; d++)
+            if (d != X) acc[d] += __builtin_popcountll(~E[d][q] & rem);
+        nrows += __builtin_popcountll(rem);
     }
     stretch();
     bool ok = g[X] <= 0;
