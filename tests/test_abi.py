@@ -220,3 +220,22 @@ def test_narrow_table_expands_on_the_host():
         lib.hits_expand(6, 100, None, 7, hits, extra, text, np.array([2, 0, 1, 0, 0, -1], np.int8), noff, nsc)
     with pytest.raises(lib.BwtError):                          # a record for a read the batch does not have
         lib.hits_expand(4, 100, None, 7, hits, extra, text, st[:4], noff, nsc)
+
+
+def test_makefile_lists_every_local_header():
+    """A header that the library's sources include but the Makefile does not name is a change that does not rebuild the library (round
+    4: an A/B of sw_cert.h measured the old build)."""
+    import re
+    csrc = os.path.join(ROOT, "bwt_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    hdr = set(re.search(r"^HDR = (.*)$", mk, re.M).group(1).split())
+    src = set(re.search(r"^SRC = (.*)$", mk, re.M).group(1).split())
+    seen = set()
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".cpp", ".h")):
+            continue
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(os.path.join(csrc, name)).read(), re.M):
+            seen.add(os.path.normpath(os.path.join(csrc, inc)))
+    listed = {os.path.normpath(os.path.join(csrc, h)) for h in hdr | src}
+    missing = sorted(p for p in seen if p not in listed and os.path.exists(p))
+    assert not missing, missing
